@@ -1,0 +1,293 @@
+#!/usr/bin/env python
+"""
+Generates every fixture under tests/golden/ by EXECUTING THE REFERENCE.
+
+Runs only in the development container (needs /root/reference and the
+compiled reference kernels in oracle/_ref, see oracle/Makefile):
+
+    make -C oracle ref && python tests/golden/make_golden.py
+
+What runs: the reference's own unmodified Python (sp.py, flux.py, math.py,
+integrals.py, ...) loaded from /root/reference by oracle/refharness/loadref.py
+on an eager Theano stand-in, calling the reference's own C++ headers compiled
+in place (oracle/refharness/refshim.cc).  The .npz files hold inputs and the
+outputs the reference produced for them -- data only, no reference source.
+
+Files (L = ydeg):
+  ops_L{L}.npz      Rx, tensordotRz, special_tensordotRz, rTA1, rTA1L, and the
+                    integer layout tables as observed through the reference ops
+  consts_L{L}.npz   inclination-marginalisation constants G, wnp, Wnp
+  moments_L{L}.npz  (mu_y, Sigma_y) for a few hyperparameter sets + everything
+                    FluxIntegral derives from them (ez, Ez, mean, var, yp, a0-a3)
+  cov_L{L}.npz      small-K covariances (marginal / conditional / temporal /
+                    normalised), design matrix, int64 spline indices
+  norm.npz          AlphaBetaOp values
+  lnlike.npz        log-likelihoods for the BASELINE.json configs
+"""
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, ROOT)
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+from oracle.refharness.loadref import load_reference  # noqa: E402
+from starry_process_amd.synthetic import synthetic_star  # noqa: E402
+
+warnings.simplefilter("ignore")
+ref = load_reference()
+SP = ref.sp.StarryProcess
+ops = ref.ops
+
+HYPER = {
+    "default": dict(r=20.0, a=0.40, b=0.27, c=0.1, n=10.0),
+    "hilat": dict(r=15.0, a=0.62, b=0.11, c=0.2, n=5.0),
+    "spread": dict(r=25.0, dr=5.0, a=0.3, b=0.5, c=0.05, n=20.0),
+}
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrays)
+    print("wrote %-18s %8.1f KiB" % (name, os.path.getsize(path) / 1024.0))
+
+
+def A(x):
+    return np.array(np.asarray(x), dtype=np.float64, copy=True)
+
+
+def gen_ops(L, U=2):
+    N = (L + 1) ** 2
+    rng = np.random.RandomState(100 + L)
+    out = {}
+    # --- Rx ---------------------------------------------------------------
+    thetas = np.array([0.5 * np.pi, -np.pi / 3, -1e-15, 0.0, 0.7, -1.3])
+    RxOp = ops.RxOp(ydeg=L, udeg=U)
+    Rs = [RxOp(th) for th in thetas]
+    out["Rx_theta"] = thetas
+    out["Rx_R"] = np.array([A(r[0]) for r in Rs])
+    out["Rx_dR"] = np.array([A(r[1]) for r in Rs])
+    out["nwig"] = np.array(RxOp.infer_shape(None, [()])[0][0])
+    # --- tensordotRz --------------------------------------------------------
+    K = 50
+    tdRz = ops.tensordotRzOp(ydeg=L, udeg=U)
+    M = rng.randn(K, N)
+    th = rng.uniform(-7, 7, K)
+    out["tdRz_seed"] = np.array(100 + L)  # M, theta = randn(K,N), uniform(-7,7,K)
+    out["tdRz_theta"] = th
+    out["tdRz_f"] = A(tdRz(M, th))
+    # integer tables seen through the op: row k = e_k, one angle
+    th0 = 0.05
+    F = A(tdRz(np.eye(N), th0 * np.ones(N)))
+    m_of = np.zeros(N, dtype=np.int32)
+    mirror = np.zeros(N, dtype=np.int32)
+    for n in range(N):
+        # f[k, n] = M[k, n] cos(m_n th) + M[k, mirror(n)] sin(m_n th)
+        col = F[:, n]
+        nz = np.flatnonzero(np.abs(col) > 1e-14)
+        c = col[n]
+        mabs = int(np.rint(np.arccos(np.clip(c, -1, 1)) / th0))
+        if mabs == 0:
+            assert list(nz) == [n]
+            m_of[n], mirror[n] = 0, n
+        else:
+            other = [k for k in nz if k != n]
+            assert len(other) == 1
+            mirror[n] = other[0]
+            m_of[n] = mabs if col[other[0]] > 0 else -mabs
+    out["tab_m_of"] = m_of
+    out["tab_mirror"] = mirror
+    # --- special_tensordotRz ------------------------------------------------
+    sp_op = ops.special_tensordotRzOp(ydeg=L, udeg=U)
+    Tm = rng.randn(N, N)
+    Mm = rng.randn(N, N)
+    # inputs are re-drawn by the tests from the same RandomState(100 + L):
+    # randn(K,N), uniform(-7,7,K), randn(N,N), randn(N,N)  (in that order)
+    out["sptd_f"] = A(sp_op(Tm, Mm, th))
+    # --- rTA1 / rTA1L -------------------------------------------------------
+    out["rTA1"] = A(ops.rTA1Op(ydeg=L, udeg=U)())
+    us = np.array([[0.0, 0.0], [0.4, 0.2], [0.1, 0.5]])
+    ld = ops.rTA1LOp(ydeg=L, udeg=U)
+    out["rTA1L_u"] = us
+    out["rTA1L"] = np.array([A(ld(u)) for u in us])
+    save("ops_L%d.npz" % L, **out)
+
+
+def gen_consts(L):
+    fi = ref.flux.FluxIntegral.__new__(ref.flux.FluxIntegral)
+    fi._ydeg = L
+    fi._nylm = (L + 1) ** 2
+    fi._R = ref.wigner.R(L, cos_alpha=0, sin_alpha=1, cos_gamma=0, sin_gamma=-1)
+    fi._precompute()
+    n = 4 * L + 1
+    G = np.array([[fi._G(i, j) for i in range(n)] for j in range(n)])
+    out = dict(G=G, Wnp=A(fi._Wnp))
+    for l in range(L + 1):
+        out["wnp_%d" % l] = A(fi._wnp[l])
+    save("consts_L%d.npz" % L, **out)
+
+
+def gen_moments(L, names):
+    out = {}
+    for name in names:
+        hp = HYPER[name]
+        sp = SP(ydeg=L, **hp)
+        mu = A(sp._mean_ylm)
+        Sig = A(sp._cov_ylm)
+        out[name + "_mean_ylm"] = mu
+        out[name + "_cov_ylm"] = Sig
+        out[name + "_hyper"] = np.array(
+            [hp["r"], hp.get("dr", np.nan) or np.nan, hp["a"], hp["b"], hp["c"], hp["n"]]
+        )
+        f = sp._flux
+        for utag, u in (("u0", [0.0, 0.0]), ("u1", [0.4, 0.2])):
+            t = np.linspace(0, 1, 3)
+            f._set_params(t, 60.0, 1.0, np.array(u))
+            pre = "%s_%s_" % (name, utag)
+            out[pre + "mean"] = A(f._mean)
+            out[pre + "var"] = A(f._var).reshape(())
+            yp = A(f._a0)  # a0 = yp[1:-2]
+            out[pre + "a0"] = yp
+            out[pre + "a1"] = A(f._a1)
+            out[pre + "a2"] = A(f._a2)
+            out[pre + "a3"] = A(f._a3)
+            out[pre + "xp"] = A(f._xp)
+            out[pre + "dx"] = np.array(f._dx)
+            kern = A(
+                f._special_tensordotRz(f._W, f._Ez, f._xp)
+            ) - float(A(f._mean)) ** 2
+            out[pre + "yp"] = kern
+            if name == "default":
+                out[pre + "W_diag"] = np.diag(A(f._W)).copy()
+                out[pre + "w"] = np.concatenate([A(w).reshape(-1) for w in f._w])
+        if name == "default":
+            out[name + "_ez"] = A(f._ez).reshape(-1)
+            out[name + "_Ez"] = A(f._Ez)
+    save("moments_L%d.npz" % L, **out)
+    return out
+
+
+def gen_cov(L, mom):
+    """Small-K covariances from the `default` hyperparameters."""
+    out = {}
+    K = 64
+    rng = np.random.RandomState(7)
+    t = np.sort(rng.uniform(-3.0, 9.0, K))
+    t[5] = t[4]  # a repeated time: zero lag on an off-diagonal
+    out["t"] = t
+    cases = [
+        ("marg_raw", dict(marginalize_over_inclination=True, normalized=False), dict(p=1.37, u=[0.0, 0.0])),
+        ("marg_norm", dict(marginalize_over_inclination=True, normalized=True), dict(p=1.37, u=[0.4, 0.2])),
+        ("marg_mat32", dict(marginalize_over_inclination=True, normalized=True, tau=2.5), dict(p=0.731, u=[0.0, 0.0])),
+        ("marg_expsq", dict(marginalize_over_inclination=True, normalized=False, tau=1.5, temporal_kernel=ref.temporal.ExpSquaredKernel), dict(p=0.731, u=[0.0, 0.0])),
+        ("cond_raw", dict(marginalize_over_inclination=False, normalized=False), dict(i=63.0, p=1.37, u=[0.0, 0.0])),
+        ("cond_norm", dict(marginalize_over_inclination=False, normalized=True), dict(i=12.5, p=0.9, u=[0.4, 0.2])),
+        ("marg_cp64", dict(marginalize_over_inclination=True, normalized=True, covpts=63), dict(p=2.0, u=[0.0, 0.0])),
+    ]
+    for tag, ctor, call in cases:
+        sp = SP(ydeg=L, **ctor, **HYPER["default"])
+        cov = A(sp.cov(t, **call))
+        out[tag + "_cov"] = cov
+        out[tag + "_mean"] = A(sp.mean(t, **call))
+        out[tag + "_fluxmean"] = A(sp._flux._mean).reshape(())
+        out[tag + "_p"] = np.array(call["p"])
+        out[tag + "_i"] = np.array(call.get("i", 60.0))
+        out[tag + "_u"] = np.array(call["u"])
+        if ctor.get("normalized"):
+            out[tag + "_z"] = A(sp._z).reshape(())
+        if ctor["marginalize_over_inclination"]:
+            f = sp._flux
+            theta = 2 * np.pi * np.mod(t / call["p"], 1.0)
+            x = np.abs(theta[:, None] - theta[None, :]).reshape(-1)
+            out[tag + "_inds"] = np.floor(x / f._dx).astype("int64")
+        else:
+            out[tag + "_A"] = A(sp._flux.design_matrix(t, call["i"], call["p"], np.array(call["u"])))
+    # K = 1 special case (returns the variance), test_variance.py:5-11
+    sp = SP(ydeg=L, normalized=False, **HYPER["default"])
+    out["k1_cov"] = A(sp.cov(np.array([0.3])))
+    out["k2_cov"] = A(sp.cov(np.array([0.0, 0.1])))
+    save("cov_L%d.npz" % L, **out)
+
+
+def gen_norm():
+    op = ops.AlphaBetaOp(20)
+    zs = np.array([0.0, 1e-6, 4.2904487674796314e-4, 5e-3, 0.023, 0.05])
+    vals = np.array([[float(v) for v in op(z)] for z in zs])
+    op10 = ops.AlphaBetaOp(10)
+    vals10 = np.array([[float(v) for v in op10(z)] for z in zs])
+    save("norm.npz", z=zs, abN20=vals, abN10=vals10)
+
+
+def gen_lnlike():
+    out = {}
+    t0 = time.time()
+
+    def run(tag, L, K, stars, ctor, tspan=4.0, call_extra=None, use_i=False):
+        sp = SP(ydeg=L, **ctor, **HYPER["default"])
+        vals = []
+        for s in stars:
+            st = synthetic_star(s, K, tspan)
+            kw = dict(p=st["p"])
+            if use_i:
+                kw["i"] = st["i"]
+            if call_extra:
+                kw.update(call_extra)
+            vals.append(float(sp.log_likelihood(st["t"], st["flux"], st["data_cov"], **kw).eval()))
+        out[tag] = np.array(vals)
+        out[tag + "_stars"] = np.array(list(stars))
+        print("  %-28s %s  (%.1fs)" % (tag, np.array2string(out[tag][:3], precision=12), time.time() - t0))
+
+    marg = dict(marginalize_over_inclination=True, normalized=True)
+    run("cfg1_L5_K100", 5, 100, [0], marg)
+    run("cfg2_L15_K1000", 15, 1000, range(0, 8), marg)
+    run("L15_K1000_raw", 15, 1000, range(0, 2), dict(marginalize_over_inclination=True, normalized=False))
+    run("L15_K200", 15, 200, range(0, 16), marg)
+    run("L15_K200_cond", 15, 200, range(0, 8), dict(marginalize_over_inclination=False, normalized=True), use_i=True)
+    run("L15_K1000_cond", 15, 1000, range(0, 2), dict(marginalize_over_inclination=False, normalized=False), use_i=True)
+    run("L15_K257_ld", 15, 257, range(0, 4), marg, call_extra=dict(u=[0.4, 0.2], baseline_var=1e-4, baseline_mean=1e-3))
+    run("cfg5_L20_K3000", 20, 3000, range(0, 2), dict(tau=3.0, **marg), tspan=30.0, call_extra=dict(u=[0.4, 0.2]))
+    run("L20_K300_mat32", 20, 300, range(0, 4), dict(tau=3.0, **marg), tspan=30.0, call_extra=dict(u=[0.4, 0.2]))
+    # multi-light-curve batch sharing one covariance (sp.py:1087-1099)
+    sp = SP(ydeg=15, **marg, **HYPER["default"])
+    stars = [synthetic_star(s, 200) for s in range(5)]
+    F = np.array([st["flux"] for st in stars])
+    out["L15_K200_batchM5"] = np.array(float(sp.log_likelihood(stars[0]["t"], F, 1e-6, p=1.3).eval()))
+    # vector data_cov
+    dc = 1e-6 * (1 + np.arange(200) / 200.0)
+    out["L15_K200_vecvar"] = np.array(float(sp.log_likelihood(stars[1]["t"], stars[1]["flux"], dc, p=stars[1]["p"]).eval()))
+    out["L15_K200_vecvar_dc"] = dc
+    # Appendix-B anchors: seeds differ from the star recipe
+    K = 1000
+    t = np.linspace(0, 4, K)
+    fl = 1e-2 * np.sin(2 * np.pi * t) + 1e-3 * np.random.RandomState(0).randn(K)
+    out["appB_L15_K1000"] = np.array(float(sp.log_likelihood(t, fl, 1e-6).eval()))
+    # normalisation guard z > zmax -> -inf (sp.py:1178-1183)
+    spz = SP(ydeg=15, r=30.0, a=0.8, b=0.05, c=0.5, n=5.0)
+    st = synthetic_star(0, 100)
+    out["zmax_guard"] = np.array(float(spz.log_likelihood(st["t"], st["flux"], 1e-6).eval()))
+    out["zmax_guard_z"] = A(spz._z).reshape(())
+    out["zmax_guard_mean_ylm"] = A(spz._mean_ylm)
+    out["zmax_guard_cov_ylm"] = A(spz._cov_ylm).astype(np.float64)
+    save("lnlike.npz", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["ops", "consts", "moments", "cov", "norm", "lnlike"]
+    for L in (5, 15, 20):
+        if "ops" in which:
+            gen_ops(L)
+        if "consts" in which:
+            gen_consts(L)
+        if "moments" in which or "cov" in which:
+            names = ["default", "hilat", "spread"] if L == 15 else ["default"]
+            mom = gen_moments(L, names) if "moments" in which else None
+            if "cov" in which:
+                gen_cov(L, mom)
+    if "norm" in which:
+        gen_norm()
+    if "lnlike" in which:
+        gen_lnlike()
