@@ -1,0 +1,252 @@
+/*
+ * starry_process_amd -- C ABI of the MI355X (gfx950) log-likelihood hot path.
+ *
+ * This is the drop-in boundary.  Each entry point
+ * replaces one Theano Op (or a fixed chain of them) of the reference
+ * rodluger/starry_process; the reference interface it stands in for is cited
+ * as  <file>:<line>  relative to the reference checkout.
+ *
+ * Conventions
+ *   - plain C, no Python.h, no torch types; never throws, never aborts;
+ *   - every function returns SP_OK (0) or a negative sp_status;
+ *   - the CALLER owns every buffer.  Pointers named *_dev are device (HBM)
+ *     pointers on the handle's GPU, pointers named *_host are host pointers;
+ *   - all floating point is IEEE fp64, matrices are C-contiguous row-major
+ *     (reference ops/include/utils.h:33-34, theano_helpers.h:55-87);
+ *   - Ylm flat index n(l,m) = l*l + l + m, N = (ydeg+1)^2; packed Wigner
+ *     arrays hold block l (a (2l+1)x(2l+1) row-major matrix) at offset
+ *     nwig(l-1), total NWIG = nwig(ydeg) (reference ops/include/wigner.h:22-30);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *     calls are asynchronous with respect to the host unless stated;
+ *   - numerical failure is data, not an error: a non positive definite
+ *     covariance or z > zmax yields -inf in the log-likelihood output and a
+ *     bit in the per-star status word, exactly like the reference's NaN ->
+ *     -inf rule (reference math.py:82-91, sp.py:1178-1188).
+ */
+#ifndef STARRY_PROCESS_AMD_H
+#define STARRY_PROCESS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sp_handle sp_handle;
+
+typedef enum {
+  SP_OK = 0,
+  SP_ERR_INVALID = -1,  /* bad argument (shape, NULL, unsupported degree)     */
+  SP_ERR_HIP = -2,      /* a HIP runtime call failed (see sp_last_hip_error)  */
+  SP_ERR_NO_DEVICE = -3,/* no usable gfx950 device                            */
+  SP_ERR_STATE = -4,    /* required constants / moments were not set first    */
+  SP_ERR_ALLOC = -5     /* host or device allocation failed                   */
+} sp_status;
+
+/* per-star status bits written by the likelihood kernels */
+#define SP_STAR_NOT_PD 1u   /* Cholesky pivot <= 0 or NaN (math.py:82-91)     */
+#define SP_STAR_ZMAX 2u     /* z > normalization_zmax (sp.py:1178-1183)       */
+#define SP_STAR_NAN 4u      /* NaN reached the final value (sp.py:1186-1188)  */
+
+/* temporal kernels (reference temporal.py:8-16) */
+#define SP_TEMPORAL_NONE 0
+#define SP_TEMPORAL_MATERN32 1
+#define SP_TEMPORAL_EXPSQUARED 2
+
+/* ---- library / handle --------------------------------------------------- */
+
+int sp_version(void);
+const char *sp_strerror(int status);
+/* text of the last failing HIP call on this thread ("" if none) */
+const char *sp_last_hip_error(void);
+/* number of visible HIP devices; does not initialise a device context */
+int sp_device_count(void);
+
+/* One handle per GPU.  ydeg >= 1 (the reference asserts ydeg >= 5,
+ * sp.py:236), 0 <= udeg <= 4.  Computes the per-degree constants the
+ * reference bakes in at compile time through -DSP__LMAX/-DSP__UMAX
+ * (ops/base_op.py:81-90): index tables, Rx(pi/2), rTA1, the LimbDark
+ * constructor (ops/include/flux.h:483-494). */
+int sp_create(int ydeg, int udeg, int device, sp_handle **out);
+void sp_destroy(sp_handle *h);
+int sp_ydeg(const sp_handle *h);
+int sp_udeg(const sp_handle *h);
+int sp_nylm(const sp_handle *h);  /* N    */
+int sp_nwig(const sp_handle *h);  /* NWIG */
+/* blocks until everything queued on `stream` has finished */
+int sp_stream_synchronize(sp_handle *h, void *stream);
+
+/* ---- a1: integer layout tables (host outputs, no GPU needed) ------------- */
+/* l_of,m_of,mirror: N entries; m0: ydeg+1; blk: ydeg+2 (blk[l] = nwig(l-1)).
+ * Replaces the index arithmetic of wigner.h:22-30,319-336 and flux.py:77,200. */
+int sp_index_tables(int ydeg, int32_t *l_of, int32_t *m_of, int32_t *mirror,
+                    int32_t *m0, int32_t *blk);
+/* the integer cos/sin(k*pi/2) factors of the x-rotation, ydeg+1 entries each,
+ * entry 0 unused (wigner.h:232-270) */
+int sp_wigner_int_tables(int ydeg, int32_t *cosmal, int32_t *sinmal,
+                         int32_t *sgn, int32_t *cosmga, int32_t *sinmga);
+
+/* ---- a2: RxOp (ops/wigner/Rx.py:8-43, Rx.cc:10-49, wigner.h:145-284) ------ */
+/* nangles rotation angles (host, radians) -> packed R [nangles, NWIG] and, if
+ * dR_dev != NULL, dR/dtheta of the same shape.  One workgroup per angle. */
+int sp_Rx(sp_handle *h, const double *theta_host, int nangles, double *R_dev,
+          double *dR_dev, void *stream);
+
+/* ---- a3: FluxIntegral._dotRx (flux.py:74-86) ------------------------------ */
+/* out[b] = M[b] . blockdiag(R^l[b]) for b < batch.  M[b] is rows x N with row
+ * stride ldm and element (r, c) at M + b*strideM + r*rs + c*cs (rs/cs let the
+ * caller pass a transposed view, flux.py:61); Rpacked[b] at R + b*strideR
+ * (strideR = 0 shares one rotation).  out is rows x N contiguous per batch. */
+int sp_dotRx(sp_handle *h, const double *M_dev, long strideM, long rs, long cs,
+             int rows, const double *Rpacked_dev, long strideR, double *out_dev,
+             int batch, void *stream);
+
+/* ---- a12: tensordotRzOp (ops/wigner/tensordotRz.py:9-37, wigner.h:289-339) */
+/* f[k, :] = M[k, :] . Rz(theta[k]); M, f are K x N, theta has K entries. */
+int sp_tensordotRz(sp_handle *h, const double *M_dev, const double *theta_dev,
+                   int K, double *f_dev, void *stream);
+
+/* ---- a9: special_tensordotRzOp (ops/wigner/special_tensordotRz.py:9-37,
+ *          wigner.h:409-459) ------------------------------------------------ */
+/* f[k] = sum_j [cosmt.(T o M) + sinmt.(T o mirror(M))]_{kj};  T, M are N x N. */
+int sp_special_tensordotRz(sp_handle *h, const double *T_dev,
+                           const double *M_dev, const double *theta_dev, int K,
+                           double *f_dev, void *stream);
+
+/* ---- a5: rTA1Op / rTA1LOp (ops/flux/rTA1.py:8-21, rTA1L.py:8-43,
+ *          flux.h:302-309, 500-523).  Host in, host out: per-star scalars. --- */
+int sp_rTA1(sp_handle *h, double *rta1_host /* N */);
+int sp_rTA1L(sp_handle *h, const double *u_host /* nsets x udeg */, int nsets,
+             double *rta1l_host /* nsets x N */);
+
+/* ---- a15: AlphaBetaOp (ops/norm/norm.py:8-44).  Host scalar function. ----- */
+int sp_alpha_beta(double z, int order, double *alpha, double *beta,
+                  double *dalpha_dz, double *dbeta_dz);
+
+/* ---- a6: constants of FluxIntegral._precompute (flux.py:121-179) ---------- */
+/* The reference computes these in Python at graph-build time; the host side
+ * (starry_process_amd/flux.py) does the same and hands them over once.
+ * wnp_packed: NWIG doubles (block l = wnp[l]); Wnp: N x N. */
+int sp_set_marginal_constants(sp_handle *h, const double *wnp_packed_host,
+                              const double *Wnp_host);
+
+/* ---- a4: moments of the Ylm process in the polar frame (flux.py:54-62) ---- */
+/* mean_ylm (N) and cov_ylm (N x N) are HOST arrays (the output of the
+ * out-of-scope upstream integrals, sp.py:264-266).  Uploads them and computes
+ * ez = R^T mu, Ez = R^T (Sigma + mu mu^T) R on the device; both stay resident
+ * in the handle until the next call.  Synchronous. */
+int sp_set_ylm_moments(sp_handle *h, const double *mean_ylm_host,
+                       const double *cov_ylm_host);
+/* copies of the resident moments back to the host (any pointer may be NULL) */
+int sp_get_polar_moments(sp_handle *h, double *ez_host, double *Ez_host);
+
+/* ---- a7-a10: inclination integrals + kernel table ------------------------- */
+/* For each of ntab flux operators rta1[i] (N doubles each, DEVICE):
+ *   w, W (flux.py:181-231), mean & var (flux.py:297-308), second moment on the
+ *   lag grid xp = arange(-dx, 2pi+2.5dx, dx), dx = 2pi/covpts (flux.py:310-317),
+ *   yp = mom2 - mean^2 and the cubic coefficients a0..a3 (flux.py:320-330).
+ * xp_host: the covpts+4 grid values (computed by the host exactly like the
+ * reference does with arange so that interpolation indices agree bit for bit).
+ * tab_dev  : [ntab, 5, covpts+4]   rows = yp, a0, a1, a2, a3 (a* use the first
+ *            covpts+1 entries; the rest is zero)
+ * meanvar_dev : [ntab, 2] = (mean, var).                                     */
+int sp_kernel_table(sp_handle *h, const double *rta1_dev, int ntab, int covpts,
+                    const double *xp_host, double *tab_dev,
+                    double *meanvar_dev, void *stream);
+
+/* ---- per-star parameter block -------------------------------------------- */
+/* All batched entry points below take `S` stars with a common number of
+ * cadences K (ragged ensembles are grouped by K on the host side).  The array
+ * of sp_star lives in DEVICE memory like every other batched input.           */
+typedef struct {
+  double period;        /* p  > 0                         (sp.py:1108-1109)   */
+  double inc;           /* inclination in RADIANS, conditional path only       */
+  double tau;           /* temporal timescale; ignored if temporal == NONE     */
+  double baseline_var;  /* added to every entry           (sp.py:1146-1151)   */
+  double baseline_mean; /* subtracted from the flux       (sp.py:1157)        */
+  double data_var;      /* scalar data variance (used when diag_dev == NULL)   */
+  int32_t table;        /* which kernel table / flux operator this star uses   */
+  int32_t reserved;
+} sp_star;
+
+/* ---- a11, a14-a16: marginal-path covariance ------------------------------- */
+/* cov[s] (K x K, leading dimension ldc >= K, star stride stridec) =
+ *   spline(|theta_i - theta_j|)                (flux.py:256-276)
+ *   [* temporal kernel]                        (sp.py:697-698)
+ *   [-> _normalize(1 + mean, .)]               (sp.py:699-727)
+ * t_dev: [S, K]; tab/meanvar: from sp_kernel_table; z_dev (S, may be NULL)
+ * receives the normalisation expansion parameter z.  K == 1 returns the
+ * variance (flux.py:274-275).  Full matrices are written (both triangles).   */
+int sp_cov_marginal_batched(sp_handle *h, int S, int K, const double *t_dev,
+                            const sp_star *stars_dev, int covpts,
+                            const double *tab_dev, const double *meanvar_dev,
+                            int temporal, int normalized, int norm_order,
+                            double *cov_dev, long ldc, long stridec,
+                            double *z_dev, void *stream);
+
+/* ---- a12-a13: conditional path -------------------------------------------- */
+/* A[s] = ((1_K x rTA1[table_s]) . Rx(-inc_s)) Rz(theta_s) Rx(pi/2)
+ * (flux.py:278-281, 88-105).  A_dev: [S, K, N]. */
+int sp_design_matrix(sp_handle *h, int S, int K, const double *t_dev,
+                     const sp_star *stars_dev, const double *rta1_dev,
+                     double *A_dev, void *stream);
+/* mean[s] = (A mu_y)[0], cov[s] = A Sigma_y A^T (flux.py:337-343), then the
+ * same temporal / normalisation steps as the marginal path.                  */
+int sp_cov_conditional_batched(sp_handle *h, int S, int K, const double *t_dev,
+                               const sp_star *stars_dev,
+                               const double *rta1_dev, int temporal,
+                               int normalized, int norm_order, double *cov_dev,
+                               long ldc, long stridec, double *mean_dev,
+                               double *z_dev, void *stream);
+
+/* ---- a17-a18: cho_factor / cho_solve (math.py:75-100) --------------------- */
+/* In-place lower Cholesky of `batch` K x K matrices (row-major, leading
+ * dimension lda, stride strideA).  The strict upper triangle is zeroed like
+ * scipy.linalg.cholesky(lower=True).  A non positive definite matrix is
+ * filled with NaN (math.py:88-91) and info_dev[b] (may be NULL) set to 1.    */
+int sp_cho_factor(sp_handle *h, double *A_dev, int K, long lda, long strideA,
+                  int batch, int32_t *info_dev, void *stream);
+/* x = (L L^T)^{-1} b: b_dev is [batch, K, nrhs] row-major (like the
+ * reference's (K, M) right-hand sides), overwritten with the solution.
+ * NaN in -> NaN out (math.py:27-31).                                         */
+int sp_cho_solve(sp_handle *h, const double *L_dev, int K, long ldl,
+                 long strideL, double *b_dev, int nrhs, int batch,
+                 void *stream);
+
+/* ---- a16-a19 + fused driver: log-likelihood of an ensemble ---------------- */
+/* Size in bytes of the device workspace sp_lnlike_ensemble needs.            */
+long sp_lnlike_workspace_bytes(sp_handle *h, int S, int K, int M);
+
+/* lnlike[s] for S independent stars, each with M light curves that share the
+ * star's covariance (sp.py:1087-1099):
+ *   C_s = cov_s + diag(data var) + baseline_var                (sp.py:1135-1151)
+ *   lnlike_s = -1/2 sum_m r^T C^-1 r - M sum log diag L - KM/2 log 2pi
+ *                                                             (sp.py:1154-1173)
+ *   z > zmax -> -inf (normalized only), NaN -> -inf            (sp.py:1178-1188)
+ * conditional == 0: marginal path (uses tab/meanvar from sp_kernel_table);
+ * conditional != 0: conditional path (uses rta1_dev, stars[s].inc).
+ * t_dev [S,K]; flux_dev [S,M,K]; diag_dev [S,K] per-cadence data variances or
+ * NULL (then stars[s].data_var is used).  lnlike_dev [S]; status_dev [S] (may
+ * be NULL).  workspace_dev must hold sp_lnlike_workspace_bytes(S,K,M) bytes.  */
+int sp_lnlike_ensemble(sp_handle *h, int S, int K, int M, const double *t_dev,
+                       const double *flux_dev, const double *diag_dev,
+                       const sp_star *stars_dev, int conditional, int covpts,
+                       const double *tab_dev, const double *meanvar_dev,
+                       const double *rta1_dev, int temporal, int normalized,
+                       int norm_order, double zmax, void *workspace_dev,
+                       double *lnlike_dev, uint32_t *status_dev, void *stream);
+
+/* The factorisation stage alone: C_dev holds S assembled (K+M padded) systems
+ * as produced internally; exposed for testing and for callers that assemble
+ * their own covariance.  cov_dev: [S, K, K] (ld = K) full symmetric matrices
+ * ALREADY including noise and baseline terms; resid_dev: [S, M, K] residuals.
+ */
+int sp_cholesky_lnlike_batched(sp_handle *h, int S, int K, int M,
+                               const double *cov_dev, const double *resid_dev,
+                               void *workspace_dev, double *lnlike_dev,
+                               uint32_t *status_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STARRY_PROCESS_AMD_H */

@@ -1,0 +1,739 @@
+// extern "C" entry points (include/starry_process_amd.h) and the fused
+// log-likelihood driver.  Host logic only: argument checks, workspace layout,
+// kernel sequencing on the caller's stream.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "sp_internal.h"
+
+// launchers defined in the other translation units
+int sp_launch_kernel_table(sp_handle *h, const double *rta1_dev, int ntab,
+                           int covpts, const double *xp_dev, double *tab_dev,
+                           double *meanvar_dev, hipStream_t st);
+int sp_launch_theta(int S, int K, const double *t, const sp_star *stars,
+                    double *theta, hipStream_t st);
+int sp_launch_spline_index(int K, const double *theta, double dx, long long *out,
+                           hipStream_t st);
+int sp_launch_rowsum(int S, int K, const double *theta, const double *t,
+                     const sp_star *stars, int covpts, const double *tab,
+                     const double *meanvar, const double *xp, int temporal,
+                     const double *raw, double *rowsum, hipStream_t st);
+int sp_launch_norm_coef(int S, int K, const sp_star *stars, const double *meanvar,
+                        const double *condmean, int normalized, int order,
+                        double zmax, const double *rowsum, double *qv, void *coef,
+                        uint32_t *status, hipStream_t st);
+int sp_launch_assemble(int S, int K, int M, int Kp, int system,
+                       const double *theta, const double *t, const sp_star *stars,
+                       int covpts, const double *tab, const double *meanvar,
+                       const double *xp, int temporal, const double *raw,
+                       int normalized, const double *qv, const void *coef,
+                       const double *diag, int add_noise, const double *flux,
+                       double *out, long ldo, long strideo, hipStream_t st);
+int sp_launch_cholesky_systems(double *sys, int S, int K, int Kp, int32_t *info,
+                               hipStream_t st);
+int sp_launch_lnlike_reduce(const double *sys, int S, int K, int M, int Kp,
+                            const int32_t *info, double *lnlike, uint32_t *status,
+                            hipStream_t st);
+int sp_launch_pad_in(const double *A, int K, long lda, long strideA, double *sys,
+                     int Kp, int M, const double *resid, int S, hipStream_t st);
+int sp_launch_pad_out(const double *sys, int Kp, double *A, int K, long lda,
+                      long strideA, const int32_t *info, int S, hipStream_t st);
+int sp_launch_cho_solve(const double *L, int K, long ldl, long strideL, double *B,
+                        int nrhs, int batch, hipStream_t st);
+
+static thread_local char g_hip_err[256] = "";
+
+const char *sp_set_hip_error(hipError_t e, const char *what) {
+  snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s", what, hipGetErrorString(e));
+  return g_hip_err;
+}
+
+namespace {
+
+// ---- small kernels used only by the driver -----------------------------------
+
+__global__ void second_moment_kernel(int N, const double *__restrict__ mu,
+                                     const double *__restrict__ cov,
+                                     double *__restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N * N) return;
+  const int i = e / N, j = e % N;
+  out[e] = cov[e] + mu[i] * mu[j];  // flux.py:58-60
+}
+
+// per star: cos / sin of -inc  (the angle of the first rotation, flux.py:97)
+__global__ void inc_cs_kernel(int S, const sp_star *__restrict__ stars,
+                              double *__restrict__ cs) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  double sn, cn;
+  sincos(-stars[s].inc, &sn, &cn);
+  cs[2 * s] = cn;
+  cs[2 * s + 1] = sn;
+}
+
+// v[s] = rTA1[table_s] . blockdiag(R(-inc_s))   (all K rows of the tiled
+// operator are identical before the phase rotation, flux.py:280,97)
+__global__ __launch_bounds__(256) void cond_prep_kernel(
+    int N, int nwig, const int32_t *__restrict__ l_of, const int32_t *__restrict__ blk,
+    const sp_star *__restrict__ stars, const double *__restrict__ rta1,
+    const double *__restrict__ Rinc, double *__restrict__ v) {
+  const int s = blockIdx.y;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int l = l_of[n], w = 2 * l + 1, base = l * l;
+  const double *row = rta1 + (size_t)stars[s].table * N;
+  const double *B = Rinc + (size_t)s * nwig + blk[l] + (n - base);
+  double acc = 0.0;
+  for (int i = 0; i < w; ++i) acc += row[base + i] * B[i * w];
+  v[(size_t)s * N + n] = acc;
+}
+
+// f[s][k][n] = v[s][n] cos(m th) + v[s][mirror n] sin(m th)   (wigner.h:289-339)
+__global__ __launch_bounds__(256) void cond_rz_kernel(
+    int ydeg, int N, int K, const int32_t *__restrict__ m_of,
+    const int32_t *__restrict__ mirror, const double *__restrict__ v,
+    const double *__restrict__ theta, double *__restrict__ f) {
+  __shared__ double cn[SP_MAX_YDEG + 1], sn[SP_MAX_YDEG + 1];
+  const int k = blockIdx.x, s = blockIdx.y;
+  if (threadIdx.x == 0) {
+    double s1, c1;
+    sincos(theta[(size_t)s * K + k], &s1, &c1);
+    cn[0] = 1.0;
+    sn[0] = 0.0;
+    if (ydeg >= 1) {
+      cn[1] = c1;
+      sn[1] = s1;
+    }
+    for (int n = 2; n <= ydeg; ++n) {
+      cn[n] = 2.0 * cn[n - 1] * c1 - cn[n - 2];
+      sn[n] = 2.0 * sn[n - 1] * c1 - sn[n - 2];
+    }
+  }
+  __syncthreads();
+  const double *vs = v + (size_t)s * N;
+  double *out = f + ((size_t)s * K + k) * N;
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    const int m = m_of[n];
+    const double cm = cn[m < 0 ? -m : m];
+    const double sm = m < 0 ? -sn[-m] : sn[m];
+    out[n] = vs[n] * cm + vs[mirror[n]] * sm;
+  }
+}
+
+// mean[s] = (A mu_y)[0]   (flux.py:340)
+__global__ __launch_bounds__(256) void cond_mean_kernel(int N, int K,
+                                                        const double *__restrict__ A,
+                                                        const double *__restrict__ mu,
+                                                        double *__restrict__ mean) {
+  __shared__ double red[4];
+  const int s = blockIdx.x;
+  const double *row = A + (size_t)s * K * N;
+  double part = 0.0;
+  for (int n = threadIdx.x; n < N; n += 256) part += row[n] * mu[n];
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) mean[s] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void get_z_kernel(int S, const double *__restrict__ coef,
+                             double *__restrict__ z) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < S) z[s] = coef[8 * s + 3];
+}
+
+__global__ void get_gpmean_kernel(int S, const double *__restrict__ coef,
+                                  double *__restrict__ out) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < S) out[s] = coef[8 * s + 6] - 1.0;  // mu - 1 = flux mean
+}
+
+inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Layout {
+  int S, K, M, Kp, N, NWIG;
+  size_t theta, rowsum, qv, coef, info, status, condmean, cs, vrow, Rinc, A, B1,
+      raw, sys, total;
+};
+
+Layout make_layout(const sp_handle *h, int S, int K, int M, bool with_sys) {
+  Layout L;
+  L.S = S;
+  L.K = K;
+  L.M = M;
+  L.Kp = sp_roundup(K + M, SP_NB);
+  L.N = h->N;
+  L.NWIG = h->NWIG;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off += align_up(bytes);
+    return o;
+  };
+  const size_t d = sizeof(double);
+  L.theta = take(d * S * K);
+  L.rowsum = take(d * S * K);
+  L.qv = take(d * S * K);
+  L.coef = take(d * S * 8);
+  L.info = take(sizeof(int32_t) * S);
+  L.status = take(sizeof(uint32_t) * S);
+  L.condmean = take(d * S);
+  L.cs = take(d * S * 2);
+  L.vrow = take(d * S * L.N);
+  L.Rinc = take(d * S * L.NWIG);
+  L.A = take(d * (size_t)S * K * L.N);
+  L.B1 = take(d * (size_t)S * K * L.N);
+  L.raw = take(d * (size_t)S * K * K);
+  L.sys = with_sys ? take(d * (size_t)S * L.Kp * L.Kp) : off;
+  L.total = off;
+  return L;
+}
+
+template <typename T>
+T *at(void *base, size_t off) {
+  return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + off);
+}
+
+// grow-only device scratch owned by the handle (non-fused ops only)
+int ensure_big(sp_handle *h, size_t bytes, void **out);
+
+int check_handle(const sp_handle *h) { return h ? SP_OK : SP_ERR_INVALID; }
+
+}  // namespace
+
+// The handle-owned grow-only buffer lives outside the struct in sp_internal.h
+// to keep that header small.
+struct BigBuf {
+  void *ptr = nullptr;
+  size_t bytes = 0;
+};
+static BigBuf g_big[16];
+
+namespace {
+int ensure_big(sp_handle *h, size_t bytes, void **out) {
+  BigBuf &b = g_big[h->device & 15];
+  if (b.bytes < bytes) {
+    SP_HIP(hipDeviceSynchronize());
+    if (b.ptr) SP_HIP(hipFree(b.ptr));
+    b.ptr = nullptr;
+    b.bytes = 0;
+    hipError_t e = hipMalloc(&b.ptr, bytes);
+    if (e != hipSuccess) {
+      sp_set_hip_error(e, "hipMalloc(scratch)");
+      return SP_ERR_ALLOC;
+    }
+    b.bytes = bytes;
+  }
+  *out = b.ptr;
+  return SP_OK;
+}
+
+// design matrix for S stars into L.A (uses L.theta already filled)
+int build_design(sp_handle *h, const Layout &L, void *ws, const sp_star *stars,
+                 const double *rta1, double *A_out, hipStream_t st) {
+  const int S = L.S, K = L.K, N = L.N;
+  double *cs = at<double>(ws, L.cs), *vrow = at<double>(ws, L.vrow);
+  double *Rinc = at<double>(ws, L.Rinc), *theta = at<double>(ws, L.theta);
+  double *tmp = at<double>(ws, L.B1);  // reused as the pre-rotation buffer
+  hipLaunchKernelGGL(inc_cs_kernel, dim3((S + 255) / 256), dim3(256), 0, st, S,
+                     stars, cs);
+  SP_LAUNCH_CHECK();
+  int rc = sp_launch_Rx(h, cs, S, Rinc, nullptr, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(cond_prep_kernel, dim3((N + 255) / 256, S), dim3(256), 0, st,
+                     N, h->NWIG, h->d_l_of, h->d_blk, stars, rta1, Rinc, vrow);
+  SP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(cond_rz_kernel, dim3(K, S), dim3(256), 0, st, h->ydeg, N, K,
+                     h->d_m_of, h->d_mirror, vrow, theta, tmp);
+  SP_LAUNCH_CHECK();
+  // all stars share Rx(pi/2): treat the S*K rows as one tall matrix
+  const long rows = (long)S * K;
+  for (long r0 = 0; r0 < rows; r0 += 32768) {
+    const int nr = (int)(rows - r0 < 32768 ? rows - r0 : 32768);
+    rc = sp_launch_dotRx(h, tmp + (size_t)r0 * N, 0, N, 1, nr, h->d_Rx90, 0,
+                         A_out + (size_t)r0 * N, 1, st);
+    if (rc) return rc;
+  }
+  return SP_OK;
+}
+
+// raw (un-normalised, no temporal factor) conditional covariance into L.raw
+int build_conditional_raw(sp_handle *h, const Layout &L, void *ws, hipStream_t st) {
+  const int S = L.S, K = L.K, N = L.N;
+  double *A = at<double>(ws, L.A), *B1 = at<double>(ws, L.B1);
+  double *raw = at<double>(ws, L.raw), *cm = at<double>(ws, L.condmean);
+  hipLaunchKernelGGL(cond_mean_kernel, dim3(S), dim3(256), 0, st, N, K, A,
+                     h->d_mean_ylm, cm);
+  SP_LAUNCH_CHECK();
+  // B1 = A Sigma_y  (Sigma_y symmetric: A . Sigma_y^T), then raw = B1 A^T
+  int rc = sp_launch_gemm_nt(A, N, (long)K * N, h->d_cov_ylm, N, 0, B1, N,
+                             (long)K * N, K, N, N, 1.0, 0, 0, S, st);
+  if (rc) return rc;
+  return sp_launch_gemm_nt(B1, N, (long)K * N, A, N, (long)K * N, raw, K,
+                           (long)K * K, K, K, N, 1.0, 0, 0, S, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *sp_last_hip_error(void) { return g_hip_err; }
+
+int sp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
+  if (!out || ydeg < 1 || ydeg > SP_MAX_YDEG || udeg < 0 || udeg > SP_MAX_UDEG)
+    return SP_ERR_INVALID;
+  *out = nullptr;
+  // device == -1: host-only handle.  It serves the host entry points
+  // (sp_rTA1, sp_rTA1L, sp_ydeg ...) and nothing else: every device entry
+  // point answers SP_ERR_NO_DEVICE.  There is no CPU compute path.
+  const bool host_only = device == -1;
+  if (!host_only) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 ||
+        device >= ndev)
+      return SP_ERR_NO_DEVICE;
+    SP_HIP(hipSetDevice(device));
+  }
+  sp_handle *h = new (std::nothrow) sp_handle();
+  if (!h) return SP_ERR_ALLOC;
+  h->ydeg = ydeg;
+  h->udeg = udeg;
+  h->N = (ydeg + 1) * (ydeg + 1);
+  h->NWIG = sp_nwig_of(ydeg);
+  h->device = device;
+  h->have_marginal = false;
+  h->have_moments = false;
+  h->xp_covpts = -1;
+  h->d_l_of = h->d_m_of = h->d_mirror = h->d_blk = nullptr;
+  h->d_Rx90 = h->d_wnp = h->d_Wnp = h->d_xp = nullptr;
+  h->d_mean_ylm = h->d_cov_ylm = h->d_ez = h->d_Ez = h->d_tmpNN = nullptr;
+  h->d_scratch = nullptr;
+  h->scratch_bytes = 0;
+  const int N = h->N;
+  h->l_of.resize(N);
+  h->m_of.resize(N);
+  h->mirror.resize(N);
+  h->m0.resize(ydeg + 1);
+  h->blk.resize(ydeg + 2);
+  sp_build_index_tables(ydeg, h->l_of.data(), h->m_of.data(), h->mirror.data(),
+                        h->m0.data(), h->blk.data());
+  sp_build_flux_constants(ydeg, udeg, h->rT, h->A1, h->U1, h->rta1);
+  if (host_only) {
+    *out = h;
+    return SP_OK;
+  }
+
+  const size_t d = sizeof(double);
+  SP_HIP(hipMalloc((void **)&h->d_l_of, sizeof(int32_t) * N));
+  SP_HIP(hipMalloc((void **)&h->d_m_of, sizeof(int32_t) * N));
+  SP_HIP(hipMalloc((void **)&h->d_mirror, sizeof(int32_t) * N));
+  SP_HIP(hipMalloc((void **)&h->d_blk, sizeof(int32_t) * (ydeg + 2)));
+  SP_HIP(hipMalloc((void **)&h->d_Rx90, d * h->NWIG));
+  SP_HIP(hipMalloc((void **)&h->d_wnp, d * h->NWIG));
+  SP_HIP(hipMalloc((void **)&h->d_Wnp, d * N * N));
+  SP_HIP(hipMalloc((void **)&h->d_mean_ylm, d * N));
+  SP_HIP(hipMalloc((void **)&h->d_cov_ylm, d * N * N));
+  SP_HIP(hipMalloc((void **)&h->d_ez, d * N));
+  SP_HIP(hipMalloc((void **)&h->d_Ez, d * N * N));
+  SP_HIP(hipMalloc((void **)&h->d_tmpNN, d * N * N));
+  h->scratch_bytes = d * (4 * (size_t)N + 64);
+  SP_HIP(hipMalloc((void **)&h->d_scratch, h->scratch_bytes));
+  h->d_xp = nullptr;
+  SP_HIP(hipMemcpy(h->d_l_of, h->l_of.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice));
+  SP_HIP(hipMemcpy(h->d_m_of, h->m_of.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice));
+  SP_HIP(hipMemcpy(h->d_mirror, h->mirror.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice));
+  SP_HIP(hipMemcpy(h->d_blk, h->blk.data(), sizeof(int32_t) * (ydeg + 2), hipMemcpyHostToDevice));
+
+  // Rx(pi/2): the polar-frame rotation every path uses (flux.py:56,61,62,103)
+  const double th = 0.5 * M_PI;
+  int rc = sp_Rx(h, &th, 1, h->d_Rx90, nullptr, nullptr);
+  if (rc != SP_OK) {
+    sp_destroy(h);
+    return rc;
+  }
+  SP_HIP(hipDeviceSynchronize());
+  *out = h;
+  return SP_OK;
+}
+
+void sp_destroy(sp_handle *h) {
+  if (!h) return;
+  if (h->device < 0) {
+    delete h;
+    return;
+  }
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  void *ptrs[] = {h->d_l_of, h->d_m_of,   h->d_mirror, h->d_blk,   h->d_Rx90,
+                  h->d_wnp,  h->d_Wnp,    h->d_mean_ylm, h->d_cov_ylm, h->d_ez,
+                  h->d_Ez,   h->d_tmpNN,  h->d_scratch, h->d_xp};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  delete h;
+}
+
+int sp_ydeg(const sp_handle *h) { return h ? h->ydeg : SP_ERR_INVALID; }
+int sp_udeg(const sp_handle *h) { return h ? h->udeg : SP_ERR_INVALID; }
+int sp_nylm(const sp_handle *h) { return h ? h->N : SP_ERR_INVALID; }
+int sp_nwig(const sp_handle *h) { return h ? h->NWIG : SP_ERR_INVALID; }
+
+int sp_stream_synchronize(sp_handle *h, void *stream) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h) return SP_ERR_INVALID;
+  SP_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return SP_OK;
+}
+
+int sp_Rx(sp_handle *h, const double *theta_host, int nangles, double *R_dev,
+          double *dR_dev, void *stream) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || !theta_host || !R_dev || nangles < 0) return SP_ERR_INVALID;
+  if (nangles == 0) return SP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  // cos/sin on the host with libm, like the reference (wigner.h:153-154)
+  std::vector<double> cs(2 * (size_t)nangles);
+  for (int i = 0; i < nangles; ++i) {
+    cs[2 * i] = std::cos(theta_host[i]);
+    cs[2 * i + 1] = std::sin(theta_host[i]);
+  }
+  double *d_cs = nullptr;
+  SP_HIP(hipMalloc((void **)&d_cs, sizeof(double) * cs.size()));
+  SP_HIP(hipMemcpyAsync(d_cs, cs.data(), sizeof(double) * cs.size(),
+                        hipMemcpyHostToDevice, st));
+  int rc = sp_launch_Rx(h, d_cs, nangles, R_dev, dR_dev, st);
+  SP_HIP(hipStreamSynchronize(st));
+  SP_HIP(hipFree(d_cs));
+  return rc;
+}
+
+int sp_rTA1(sp_handle *h, double *rta1_host) {
+  if (!h || !rta1_host) return SP_ERR_INVALID;
+  memcpy(rta1_host, h->rta1.data(), sizeof(double) * h->N);
+  return SP_OK;
+}
+
+int sp_rTA1L(sp_handle *h, const double *u_host, int nsets, double *out) {
+  if (!h || !out || nsets < 0 || (h->udeg > 0 && !u_host)) return SP_ERR_INVALID;
+  for (int i = 0; i < nsets; ++i)
+    sp_host_rTA1L(h, u_host ? u_host + (size_t)i * h->udeg : nullptr,
+                  out + (size_t)i * h->N);
+  return SP_OK;
+}
+
+int sp_set_marginal_constants(sp_handle *h, const double *wnp, const double *Wnp) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || !wnp || !Wnp) return SP_ERR_INVALID;
+  SP_HIP(hipSetDevice(h->device));
+  SP_HIP(hipMemcpy(h->d_wnp, wnp, sizeof(double) * h->NWIG, hipMemcpyHostToDevice));
+  SP_HIP(hipMemcpy(h->d_Wnp, Wnp, sizeof(double) * h->N * h->N, hipMemcpyHostToDevice));
+  h->have_marginal = true;
+  return SP_OK;
+}
+
+int sp_set_ylm_moments(sp_handle *h, const double *mean_ylm, const double *cov_ylm) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || !mean_ylm || !cov_ylm) return SP_ERR_INVALID;
+  const int N = h->N;
+  SP_HIP(hipSetDevice(h->device));
+  SP_HIP(hipMemcpy(h->d_mean_ylm, mean_ylm, sizeof(double) * N, hipMemcpyHostToDevice));
+  SP_HIP(hipMemcpy(h->d_cov_ylm, cov_ylm, sizeof(double) * N * N, hipMemcpyHostToDevice));
+  hipStream_t st = nullptr;
+  // ez = R^T mu  (flux.py:55-57)
+  int rc = sp_launch_dotRx(h, h->d_mean_ylm, 0, N, 1, 1, h->d_Rx90, 0, h->d_ez, 1, st);
+  if (rc) return rc;
+  // Ez = R^T (Sigma + mu mu^T) R  (flux.py:58-62)
+  hipLaunchKernelGGL(second_moment_kernel, dim3((N * N + 255) / 256), dim3(256), 0,
+                     st, N, h->d_mean_ylm, h->d_cov_ylm, h->d_tmpNN);
+  SP_LAUNCH_CHECK();
+  rc = sp_launch_dotRx(h, h->d_tmpNN, 0, N, 1, N, h->d_Rx90, 0, h->d_Ez, 1, st);
+  if (rc) return rc;
+  // transpose view of the intermediate: element (r, c) = Ez_tmp[c, r]
+  rc = sp_launch_dotRx(h, h->d_Ez, 0, 1, N, N, h->d_Rx90, 0, h->d_tmpNN, 1, st);
+  if (rc) return rc;
+  SP_HIP(hipMemcpyAsync(h->d_Ez, h->d_tmpNN, sizeof(double) * N * N,
+                        hipMemcpyDeviceToDevice, st));
+  SP_HIP(hipStreamSynchronize(st));
+  h->have_moments = true;
+  return SP_OK;
+}
+
+int sp_get_polar_moments(sp_handle *h, double *ez, double *Ez) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h) return SP_ERR_INVALID;
+  if (!h->have_moments) return SP_ERR_STATE;
+  SP_HIP(hipSetDevice(h->device));
+  if (ez) SP_HIP(hipMemcpy(ez, h->d_ez, sizeof(double) * h->N, hipMemcpyDeviceToHost));
+  if (Ez)
+    SP_HIP(hipMemcpy(Ez, h->d_Ez, sizeof(double) * h->N * h->N, hipMemcpyDeviceToHost));
+  return SP_OK;
+}
+
+int sp_kernel_table(sp_handle *h, const double *rta1_dev, int ntab, int covpts,
+                    const double *xp_host, double *tab_dev, double *meanvar_dev,
+                    void *stream) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || !rta1_dev || !xp_host || !tab_dev || !meanvar_dev || ntab < 0 ||
+      covpts < 1)
+    return SP_ERR_INVALID;
+  if (!h->have_marginal || !h->have_moments) return SP_ERR_STATE;
+  if (ntab == 0) return SP_OK;
+  const int np = covpts + 4;
+  if (h->xp_covpts != covpts) {
+    SP_HIP(hipDeviceSynchronize());
+    if (h->d_xp) SP_HIP(hipFree(h->d_xp));
+    h->d_xp = nullptr;
+    SP_HIP(hipMalloc((void **)&h->d_xp, sizeof(double) * np));
+    h->xp_covpts = covpts;
+  }
+  SP_HIP(hipMemcpy(h->d_xp, xp_host, sizeof(double) * np, hipMemcpyHostToDevice));
+  return sp_launch_kernel_table(h, rta1_dev, ntab, covpts, h->d_xp, tab_dev,
+                                meanvar_dev, (hipStream_t)stream);
+}
+
+int sp_cov_marginal_batched(sp_handle *h, int S, int K, const double *t_dev,
+                            const sp_star *stars_dev, int covpts,
+                            const double *tab_dev, const double *meanvar_dev,
+                            int temporal, int normalized, int norm_order,
+                            double *cov_dev, long ldc, long stridec,
+                            double *z_dev, void *stream) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || !t_dev || !stars_dev || !tab_dev || !meanvar_dev || !cov_dev || S < 0 ||
+      K < 1 || ldc < K || norm_order < 0 || norm_order > SP_NORM_MAXORDER)
+    return SP_ERR_INVALID;
+  if (h->xp_covpts != covpts) return SP_ERR_STATE;
+  if (S == 0) return SP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  Layout L = make_layout(h, S, K, 0, false);
+  // only the small per-star arrays are needed here
+  void *ws = nullptr;
+  int rc = ensure_big(h, L.condmean + 256, &ws);
+  if (rc) return rc;
+  double *theta = at<double>(ws, L.theta), *rowsum = at<double>(ws, L.rowsum);
+  double *qv = at<double>(ws, L.qv), *coef = at<double>(ws, L.coef);
+  if ((rc = sp_launch_theta(S, K, t_dev, stars_dev, theta, st))) return rc;
+  if (normalized)
+    if ((rc = sp_launch_rowsum(S, K, theta, t_dev, stars_dev, covpts, tab_dev,
+                               meanvar_dev, h->d_xp, temporal, nullptr, rowsum, st)))
+      return rc;
+  if ((rc = sp_launch_norm_coef(S, K, stars_dev, meanvar_dev, nullptr, normalized,
+                                norm_order, INFINITY, rowsum, qv, coef, nullptr, st)))
+    return rc;
+  if ((rc = sp_launch_assemble(S, K, 0, K, 0, theta, t_dev, stars_dev, covpts,
+                               tab_dev, meanvar_dev, h->d_xp, temporal, nullptr,
+                               normalized, qv, coef, nullptr, 0, nullptr, cov_dev,
+                               ldc, stridec, st)))
+    return rc;
+  if (z_dev) {
+    hipLaunchKernelGGL(get_z_kernel, dim3((S + 255) / 256), dim3(256), 0, st, S, coef,
+                       z_dev);
+    SP_LAUNCH_CHECK();
+  }
+  return SP_OK;
+}
+
+int sp_design_matrix(sp_handle *h, int S, int K, const double *t_dev,
+                     const sp_star *stars_dev, const double *rta1_dev,
+                     double *A_dev, void *stream) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || !t_dev || !stars_dev || !rta1_dev || !A_dev || S < 0 || K < 1)
+    return SP_ERR_INVALID;
+  if (S == 0) return SP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  Layout L = make_layout(h, S, K, 0, false);
+  void *ws = nullptr;
+  int rc = ensure_big(h, L.raw, &ws);  // up to and including B1
+  if (rc) return rc;
+  if ((rc = sp_launch_theta(S, K, t_dev, stars_dev, at<double>(ws, L.theta), st)))
+    return rc;
+  return build_design(h, L, ws, stars_dev, rta1_dev, A_dev, st);
+}
+
+int sp_cov_conditional_batched(sp_handle *h, int S, int K, const double *t_dev,
+                               const sp_star *stars_dev, const double *rta1_dev,
+                               int temporal, int normalized, int norm_order,
+                               double *cov_dev, long ldc, long stridec,
+                               double *mean_dev, double *z_dev, void *stream) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || !t_dev || !stars_dev || !rta1_dev || !cov_dev || S < 0 || K < 1 ||
+      ldc < K || norm_order < 0 || norm_order > SP_NORM_MAXORDER)
+    return SP_ERR_INVALID;
+  if (!h->have_moments) return SP_ERR_STATE;
+  if (S == 0) return SP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  Layout L = make_layout(h, S, K, 0, false);
+  void *ws = nullptr;
+  int rc = ensure_big(h, L.total, &ws);
+  if (rc) return rc;
+  double *theta = at<double>(ws, L.theta), *rowsum = at<double>(ws, L.rowsum);
+  double *qv = at<double>(ws, L.qv), *coef = at<double>(ws, L.coef);
+  double *raw = at<double>(ws, L.raw), *cm = at<double>(ws, L.condmean);
+  if ((rc = sp_launch_theta(S, K, t_dev, stars_dev, theta, st))) return rc;
+  if ((rc = build_design(h, L, ws, stars_dev, rta1_dev, at<double>(ws, L.A), st)))
+    return rc;
+  if ((rc = build_conditional_raw(h, L, ws, st))) return rc;
+  if (normalized)
+    if ((rc = sp_launch_rowsum(S, K, theta, t_dev, stars_dev, 1, nullptr, nullptr,
+                               nullptr, temporal, raw, rowsum, st)))
+      return rc;
+  if ((rc = sp_launch_norm_coef(S, K, stars_dev, nullptr, cm, normalized, norm_order,
+                                INFINITY, rowsum, qv, coef, nullptr, st)))
+    return rc;
+  if ((rc = sp_launch_assemble(S, K, 0, K, 0, theta, t_dev, stars_dev, 1, nullptr,
+                               nullptr, nullptr, temporal, raw, normalized, qv, coef,
+                               nullptr, 0, nullptr, cov_dev, ldc, stridec, st)))
+    return rc;
+  if (mean_dev) {
+    hipLaunchKernelGGL(get_gpmean_kernel, dim3((S + 255) / 256), dim3(256), 0, st, S,
+                       coef, mean_dev);
+    SP_LAUNCH_CHECK();
+  }
+  if (z_dev) {
+    hipLaunchKernelGGL(get_z_kernel, dim3((S + 255) / 256), dim3(256), 0, st, S, coef,
+                       z_dev);
+    SP_LAUNCH_CHECK();
+  }
+  return SP_OK;
+}
+
+int sp_cho_factor(sp_handle *h, double *A_dev, int K, long lda, long strideA,
+                  int batch, int32_t *info_dev, void *stream) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || !A_dev || K < 1 || lda < K || batch < 0) return SP_ERR_INVALID;
+  if (batch == 0) return SP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int Kp = sp_roundup(K, SP_NB);
+  const size_t sysb = align_up(sizeof(double) * (size_t)batch * Kp * Kp);
+  void *ws = nullptr;
+  int rc = ensure_big(h, sysb + align_up(sizeof(int32_t) * batch), &ws);
+  if (rc) return rc;
+  double *sys = at<double>(ws, 0);
+  int32_t *info = at<int32_t>(ws, sysb);
+  SP_HIP(hipMemsetAsync(info, 0, sizeof(int32_t) * batch, st));
+  if ((rc = sp_launch_pad_in(A_dev, K, lda, strideA, sys, Kp, 0, nullptr, batch, st)))
+    return rc;
+  if ((rc = sp_launch_cholesky_systems(sys, batch, K, Kp, info, st))) return rc;
+  if ((rc = sp_launch_pad_out(sys, Kp, A_dev, K, lda, strideA, info, batch, st)))
+    return rc;
+  if (info_dev)
+    SP_HIP(hipMemcpyAsync(info_dev, info, sizeof(int32_t) * batch,
+                          hipMemcpyDeviceToDevice, st));
+  return SP_OK;
+}
+
+int sp_cho_solve(sp_handle *h, const double *L_dev, int K, long ldl, long strideL,
+                 double *b_dev, int nrhs, int batch, void *stream) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || !L_dev || !b_dev || K < 1 || ldl < K || nrhs < 0 || batch < 0)
+    return SP_ERR_INVALID;
+  if (nrhs == 0 || batch == 0) return SP_OK;
+  if (nrhs > 65535 || batch > 65535) return SP_ERR_INVALID;
+  return sp_launch_cho_solve(L_dev, K, ldl, strideL, b_dev, nrhs, batch,
+                             (hipStream_t)stream);
+}
+
+long sp_lnlike_workspace_bytes(sp_handle *h, int S, int K, int M) {
+  if (!h || S < 0 || K < 1 || M < 1) return SP_ERR_INVALID;
+  return (long)make_layout(h, S, K, M, true).total;
+}
+
+int sp_lnlike_ensemble(sp_handle *h, int S, int K, int M, const double *t_dev,
+                       const double *flux_dev, const double *diag_dev,
+                       const sp_star *stars_dev, int conditional, int covpts,
+                       const double *tab_dev, const double *meanvar_dev,
+                       const double *rta1_dev, int temporal, int normalized,
+                       int norm_order, double zmax, void *workspace_dev,
+                       double *lnlike_dev, uint32_t *status_dev, void *stream) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || !t_dev || !flux_dev || !stars_dev || !workspace_dev || !lnlike_dev ||
+      S < 0 || K < 1 || M < 1 || norm_order < 0 || norm_order > SP_NORM_MAXORDER)
+    return SP_ERR_INVALID;
+  if (conditional) {
+    if (!rta1_dev) return SP_ERR_INVALID;
+    if (!h->have_moments) return SP_ERR_STATE;
+  } else {
+    if (!tab_dev || !meanvar_dev || covpts < 1) return SP_ERR_INVALID;
+    if (h->xp_covpts != covpts) return SP_ERR_STATE;
+  }
+  if (S == 0) return SP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  Layout L = make_layout(h, S, K, M, true);
+  void *ws = workspace_dev;
+  double *theta = at<double>(ws, L.theta), *rowsum = at<double>(ws, L.rowsum);
+  double *qv = at<double>(ws, L.qv), *coef = at<double>(ws, L.coef);
+  double *raw = at<double>(ws, L.raw), *cm = at<double>(ws, L.condmean);
+  double *sys = at<double>(ws, L.sys);
+  int32_t *info = at<int32_t>(ws, L.info);
+  uint32_t *status = at<uint32_t>(ws, L.status);
+  int rc;
+  SP_HIP(hipMemsetAsync(info, 0, sizeof(int32_t) * S, st));
+  SP_HIP(hipMemsetAsync(status, 0, sizeof(uint32_t) * S, st));
+  if ((rc = sp_launch_theta(S, K, t_dev, stars_dev, theta, st))) return rc;
+  const double *rawp = nullptr;
+  const double *condmean = nullptr;
+  if (conditional) {
+    if ((rc = build_design(h, L, ws, stars_dev, rta1_dev, at<double>(ws, L.A), st)))
+      return rc;
+    if ((rc = build_conditional_raw(h, L, ws, st))) return rc;
+    rawp = raw;
+    condmean = cm;
+  }
+  const int cp = conditional ? 1 : covpts;
+  if (normalized)
+    if ((rc = sp_launch_rowsum(S, K, theta, t_dev, stars_dev, cp, tab_dev, meanvar_dev,
+                               h->d_xp, temporal, rawp, rowsum, st)))
+      return rc;
+  if ((rc = sp_launch_norm_coef(S, K, stars_dev, meanvar_dev, condmean, normalized,
+                                norm_order, zmax, rowsum, qv, coef, status, st)))
+    return rc;
+  if ((rc = sp_launch_assemble(S, K, M, L.Kp, 1, theta, t_dev, stars_dev, cp, tab_dev,
+                               meanvar_dev, h->d_xp, temporal, rawp, normalized, qv,
+                               coef, diag_dev, 1, flux_dev, sys, L.Kp,
+                               (long)L.Kp * L.Kp, st)))
+    return rc;
+  if ((rc = sp_launch_cholesky_systems(sys, S, K, L.Kp, info, st))) return rc;
+  if ((rc = sp_launch_lnlike_reduce(sys, S, K, M, L.Kp, info, lnlike_dev, status, st)))
+    return rc;
+  if (status_dev)
+    SP_HIP(hipMemcpyAsync(status_dev, status, sizeof(uint32_t) * S,
+                          hipMemcpyDeviceToDevice, st));
+  return SP_OK;
+}
+
+int sp_cholesky_lnlike_batched(sp_handle *h, int S, int K, int M,
+                               const double *cov_dev, const double *resid_dev,
+                               void *workspace_dev, double *lnlike_dev,
+                               uint32_t *status_dev, void *stream) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || !cov_dev || !resid_dev || !workspace_dev || !lnlike_dev || S < 0 ||
+      K < 1 || M < 1)
+    return SP_ERR_INVALID;
+  if (S == 0) return SP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  Layout L = make_layout(h, S, K, M, true);
+  double *sys = at<double>(workspace_dev, L.sys);
+  int32_t *info = at<int32_t>(workspace_dev, L.info);
+  uint32_t *status = at<uint32_t>(workspace_dev, L.status);
+  int rc;
+  SP_HIP(hipMemsetAsync(info, 0, sizeof(int32_t) * S, st));
+  SP_HIP(hipMemsetAsync(status, 0, sizeof(uint32_t) * S, st));
+  if ((rc = sp_launch_pad_in(cov_dev, K, K, (long)K * K, sys, L.Kp, M, resid_dev, S, st)))
+    return rc;
+  if ((rc = sp_launch_cholesky_systems(sys, S, K, L.Kp, info, st))) return rc;
+  if ((rc = sp_launch_lnlike_reduce(sys, S, K, M, L.Kp, info, lnlike_dev, status, st)))
+    return rc;
+  if (status_dev)
+    SP_HIP(hipMemcpyAsync(status_dev, status, sizeof(uint32_t) * S,
+                          hipMemcpyDeviceToDevice, st));
+  return SP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,376 @@
+// Covariance assembly: HBM-bound kernels.
+//
+//   theta_kernel      theta = 2 pi mod(t / p, 1)                  flux.py:262
+//   rowsum_kernel     row sums of the raw covariance (for _normalize)
+//   norm_coef_kernel  m, q, z, alpha(z), beta(z)                  sp.py:705-727
+//   assemble_kernel   final matrix: normalisation fix-up + data variance +
+//                     baseline variance (sp.py:1135-1151), written once.
+//
+// The marginal-path covariance is a function of the phase lag only,
+// cov_ij = spline(|theta_i - theta_j|) [* temporal(|t_i - t_j|)], so it is
+// never stored in raw form: the row sums re-evaluate the spline (pure compute,
+// no HBM traffic) and the assembly writes the normalised matrix exactly once
+// (lower triangle only when it feeds the Cholesky).  The conditional path reads
+// its raw covariance from the GEMM output instead (template parameter).
+//
+// Compiled with -ffp-contract=off: the int64 interpolation index
+// floor(x / dx) must agree bit for bit with the reference (flux.py:262-265).
+#include "sp_internal.h"
+
+namespace {
+
+struct Coef {   // per-star normalisation coefficients, 8 doubles
+  double c1;    // alpha / mu^2          (1 when not normalised)
+  double zab;   // alpha + beta
+  double za;    // alpha
+  double z;     // m / mu^2
+  double gpmean;  // mean of the flux GP (0 when normalised, sp.py:669-670)
+  double m;     // mean(Sigma)
+  double mu;    // 1 + flux mean
+  double pad;
+};
+
+__device__ __forceinline__ double temporal_factor(int kind, double ti, double tj,
+                                                  double tau) {
+  if (kind == SP_TEMPORAL_NONE) return 1.0;
+  const double dt = fabs(ti - tj);
+  if (kind == SP_TEMPORAL_MATERN32) {
+    const double x = 1.7320508075688772 * dt / tau;  // np.sqrt(3) * dt / tau
+    return (1.0 + x) * exp(-x);
+  }
+  return exp(-(dt * dt) / (2.0 * tau));
+}
+
+// spline lookup (flux.py:262-272)
+struct SplineGen {
+  const double *a0, *a1, *a2, *a3, *xp;  // LDS
+  double dx;
+  int covpts;
+  __device__ __forceinline__ double operator()(double thi, double thj) const {
+    const double x = fabs(thi - thj);
+    long idx = (long)floor(x / dx);
+    idx = idx < 0 ? 0 : (idx > covpts ? covpts : idx);
+    const double x0 = (x - xp[idx + 1]) / dx;
+    return a0[idx] + a1[idx] * x0 + a2[idx] * (x0 * x0) + a3[idx] * (x0 * x0 * x0);
+  }
+};
+
+__global__ __launch_bounds__(256) void theta_kernel(
+    int K, const double *__restrict__ t, const sp_star *__restrict__ stars,
+    double *__restrict__ theta) {
+  const int s = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K) return;
+  const double a = t[(size_t)s * K + i] / stars[s].period;
+  double m = fmod(a, 1.0);
+  if (m != 0.0 && m < 0.0) m += 1.0;
+  theta[(size_t)s * K + i] = 6.283185307179586 * m;
+}
+
+// int64 interpolation indices of every (i, j) pair, exposed for parity tests
+__global__ __launch_bounds__(256) void spline_index_kernel(
+    int K, const double *__restrict__ theta, double dx, long long *__restrict__ out) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)K * K) return;
+  const int i = e / K, j = e % K;
+  const double x = fabs(theta[i] - theta[j]);
+  out[e] = (long long)floor(x / dx);
+}
+
+__device__ __forceinline__ void load_tables(const double *__restrict__ tab, int np,
+                                            const double *__restrict__ xp,
+                                            double *s_tab) {
+  // s_tab: a0 | a1 | a2 | a3 | xp   (np each)
+  for (int i = threadIdx.x; i < 4 * np; i += blockDim.x) s_tab[i] = tab[np + i];
+  for (int i = threadIdx.x; i < np; i += blockDim.x) s_tab[4 * np + i] = xp[i];
+}
+
+// Row sums of the raw covariance.  grid (ceil(K/64), S), 256 threads: thread
+// (r = tid & 63, q = tid >> 6) sums columns j = q, q+4, ... of row r.
+template <bool FROM_MATRIX>
+__global__ __launch_bounds__(256) void rowsum_kernel(
+    int K, const double *__restrict__ theta, const double *__restrict__ t,
+    const sp_star *__restrict__ stars, int covpts, const double *__restrict__ tab,
+    const double *__restrict__ meanvar, const double *__restrict__ xp,
+    int temporal, const double *__restrict__ raw, double *__restrict__ rowsum) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int s = blockIdx.y, np = covpts + 4;
+  const sp_star st = stars[s];
+  double *s_tab = lds;            // 5 * np (unused when FROM_MATRIX)
+  double *s_th = lds + (FROM_MATRIX ? 0 : 5 * np);  // K
+  double *s_t = s_th + K;         // K
+  double *s_red = s_t + K;        // 256
+  if (!FROM_MATRIX) {
+    load_tables(tab + (size_t)st.table * 5 * np, np, xp, s_tab);
+    for (int j = threadIdx.x; j < K; j += 256) s_th[j] = theta[(size_t)s * K + j];
+  }
+  if (temporal != SP_TEMPORAL_NONE)
+    for (int j = threadIdx.x; j < K; j += 256) s_t[j] = t[(size_t)s * K + j];
+  __syncthreads();
+  const int r = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + r;
+  double acc = 0.0;
+  if (i < K) {
+    if (FROM_MATRIX) {
+      const double *row = raw + ((size_t)s * K + i) * K;
+      const double ti = temporal != SP_TEMPORAL_NONE ? s_t[i] : 0.0;
+      for (int j = q; j < K; j += 4)
+        acc += row[j] * temporal_factor(temporal, ti, temporal != SP_TEMPORAL_NONE ? s_t[j] : 0.0, st.tau);
+    } else if (K == 1) {
+      acc = q == 0 ? meanvar[2 * st.table + 1] : 0.0;
+    } else {
+      SplineGen g{s_tab, s_tab + np, s_tab + 2 * np, s_tab + 3 * np, s_tab + 4 * np,
+                  6.283185307179586 / covpts, covpts};
+      const double thi = s_th[i];
+      const double ti = temporal != SP_TEMPORAL_NONE ? s_t[i] : 0.0;
+      for (int j = q; j < K; j += 4)
+        acc += g(thi, s_th[j]) *
+               temporal_factor(temporal, ti, temporal != SP_TEMPORAL_NONE ? s_t[j] : 0.0, st.tau);
+    }
+  }
+  s_red[threadIdx.x] = acc;
+  __syncthreads();
+  if (q == 0 && i < K)
+    rowsum[(size_t)s * K + i] = (s_red[r] + s_red[64 + r]) + (s_red[128 + r] + s_red[192 + r]);
+}
+
+// one workgroup per star (sp.py:705-727, ops/norm/norm.py:26-44)
+__global__ __launch_bounds__(256) void norm_coef_kernel(
+    int K, const sp_star *__restrict__ stars, const double *__restrict__ meanvar,
+    const double *__restrict__ condmean, int normalized, int order, double zmax,
+    const double *__restrict__ rowsum, double *__restrict__ qv, Coef *__restrict__ coef,
+    uint32_t *__restrict__ status) {
+  __shared__ double red[4];
+  const int s = blockIdx.x;
+  const double fmean = condmean ? condmean[s] : meanvar[2 * stars[s].table];
+  Coef c;
+  c.c1 = 1.0;
+  c.zab = 0.0;
+  c.za = 0.0;
+  c.z = 0.0;
+  c.gpmean = normalized ? 0.0 : fmean;
+  c.m = 0.0;
+  c.mu = 1.0 + fmean;
+  c.pad = 0.0;
+  if (normalized) {
+    double part = 0.0;
+    for (int i = threadIdx.x; i < K; i += 256) part += rowsum[(size_t)s * K + i];
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    const double total = (red[0] + red[1]) + (red[2] + red[3]);
+    const double m = total / ((double)K * (double)K);
+    const double mu = c.mu;
+    const double z = m / (mu * mu);
+    double fac = 1.0, alpha = 0.0, beta = 0.0;
+    for (int n = 0; n <= order; ++n) {
+      alpha += fac;
+      beta += 2 * n * fac;
+      fac *= z * (2 * n + 3);
+    }
+    c.c1 = alpha / (mu * mu);
+    c.zab = alpha + beta;
+    c.za = alpha;
+    c.z = z;
+    c.m = m;
+    const double km = (double)K * m;
+    for (int i = threadIdx.x; i < K; i += 256)
+      qv[(size_t)s * K + i] = rowsum[(size_t)s * K + i] / km;
+    if (threadIdx.x == 0 && status && z > zmax) atomicOr(&status[s], SP_STAR_ZMAX);
+  }
+  if (threadIdx.x == 0) coef[s] = c;
+}
+
+// Writes 64 x 64 tiles of the final matrix.
+//   SYSTEM = false: plain K x K covariance, every tile (sp.cov()).
+//   SYSTEM = true : the padded (Kp x Kp) Cholesky system: lower-triangle tiles
+//                   only, residual rows K..K+M-1, unit diagonal on the padding.
+template <bool FROM_MATRIX, bool SYSTEM>
+__global__ __launch_bounds__(256) void assemble_kernel(
+    int K, int M, int Kp, const double *__restrict__ theta,
+    const double *__restrict__ t, const sp_star *__restrict__ stars, int covpts,
+    const double *__restrict__ tab, const double *__restrict__ meanvar,
+    const double *__restrict__ xp, int temporal, const double *__restrict__ raw,
+    int normalized, const double *__restrict__ qv, const Coef *__restrict__ coef,
+    const double *__restrict__ diag, int add_noise, const double *__restrict__ flux,
+    double *__restrict__ out, long ldo, long strideo, int ntr) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int s = blockIdx.y, np = covpts + 4;
+  const sp_star st = stars[s];
+  const Coef c = coef[s];
+  int ti, tj;
+  if (SYSTEM) {
+    const int tile = blockIdx.x;
+    ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > tile) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+    tj = tile - ti * (ti + 1) / 2;
+  } else {
+    ti = blockIdx.x / ntr;
+    tj = blockIdx.x % ntr;
+  }
+  const int i0 = ti * 64, j0 = tj * 64;
+  double *s_tab = lds;                                  // 5 np
+  double *s_thi = lds + (FROM_MATRIX ? 0 : 5 * np);     // 64 each below
+  double *s_thj = s_thi + 64, *s_ti = s_thj + 64, *s_tj = s_ti + 64;
+  double *s_qi = s_tj + 64, *s_qj = s_qi + 64;
+  if (!FROM_MATRIX) load_tables(tab + (size_t)st.table * 5 * np, np, xp, s_tab);
+  if (threadIdx.x < 64) {
+    const int i = i0 + threadIdx.x;
+    const bool ok = i < K;
+    s_thi[threadIdx.x] = (ok && !FROM_MATRIX) ? theta[(size_t)s * K + i] : 0.0;
+    s_ti[threadIdx.x] = (ok && temporal != SP_TEMPORAL_NONE) ? t[(size_t)s * K + i] : 0.0;
+    s_qi[threadIdx.x] = (ok && normalized) ? qv[(size_t)s * K + i] : 0.0;
+  } else if (threadIdx.x < 128) {
+    const int l = threadIdx.x - 64, j = j0 + l;
+    const bool ok = j < K;
+    s_thj[l] = (ok && !FROM_MATRIX) ? theta[(size_t)s * K + j] : 0.0;
+    s_tj[l] = (ok && temporal != SP_TEMPORAL_NONE) ? t[(size_t)s * K + j] : 0.0;
+    s_qj[l] = (ok && normalized) ? qv[(size_t)s * K + j] : 0.0;
+  }
+  __syncthreads();
+  SplineGen g{s_tab, s_tab + np, s_tab + 2 * np, s_tab + 3 * np, s_tab + 4 * np,
+              6.283185307179586 / covpts, covpts};
+  const double var1 = (!FROM_MATRIX && K == 1) ? meanvar[2 * st.table + 1] : 0.0;
+  double *ob = out + (size_t)s * strideo;
+  // thread -> 4 consecutive columns, 16 rows per pass
+  const int cj = (threadIdx.x & 15) * 4, ri = threadIdx.x >> 4;
+  const int lim = SYSTEM ? Kp : K;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int li = ri + 16 * pass, i = i0 + li;
+    if (i >= lim) continue;
+    double v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int lj = cj + e, j = j0 + lj;
+      double val = 0.0;
+      if (i < K && j < K) {
+        double rawv;
+        if (FROM_MATRIX)
+          rawv = raw[((size_t)s * K + i) * K + j];
+        else if (K == 1)
+          rawv = var1;
+        else
+          rawv = g(s_thi[li], s_thj[lj]);
+        rawv *= temporal_factor(temporal, s_ti[li], s_tj[lj], st.tau);
+        if (normalized) {
+          const double qi = s_qi[li], qj = s_qj[lj];
+          const double pp = (1.0 - qi) * (1.0 - qj), qq = qi * qj;
+          val = c.c1 * rawv + c.z * (c.zab * pp - c.za * qq);
+        } else {
+          val = rawv;
+        }
+        if (add_noise) {
+          if (i == j) val += diag ? diag[(size_t)s * K + i] : st.data_var;
+          val += st.baseline_var;
+        }
+      } else if (SYSTEM) {
+        if (i >= K && i < K + M && j < K)
+          val = flux[((size_t)s * M + (i - K)) * K + j] - (c.gpmean + st.baseline_mean);
+        else if (i == j)
+          val = 1.0;
+      }
+      v[e] = val;
+    }
+    double *dst = ob + (size_t)i * ldo + j0 + cj;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (j0 + cj + e < lim) dst[e] = v[e];
+  }
+}
+
+}  // namespace
+
+// ---- launchers ---------------------------------------------------------------
+
+static size_t attr_lds_limit = 150 * 1024;
+
+template <typename F>
+static void allow_big_lds(F f) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(f),
+                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)attr_lds_limit);
+}
+
+int sp_launch_theta(int S, int K, const double *t, const sp_star *stars,
+                    double *theta, hipStream_t st) {
+  hipLaunchKernelGGL(theta_kernel, dim3((K + 255) / 256, S), dim3(256), 0, st, K,
+                     t, stars, theta);
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}
+
+int sp_launch_spline_index(int K, const double *theta, double dx, long long *out,
+                           hipStream_t st) {
+  const long n = (long)K * K;
+  hipLaunchKernelGGL(spline_index_kernel, dim3((unsigned)((n + 255) / 256)),
+                     dim3(256), 0, st, K, theta, dx, out);
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}
+
+int sp_launch_rowsum(int S, int K, const double *theta, const double *t,
+                     const sp_star *stars, int covpts, const double *tab,
+                     const double *meanvar, const double *xp, int temporal,
+                     const double *raw, double *rowsum, hipStream_t st) {
+  const int np = covpts + 4;
+  const size_t lds = sizeof(double) * ((raw ? 0 : 5 * (size_t)np) + 2 * (size_t)K + 256);
+  if (lds > attr_lds_limit) return SP_ERR_INVALID;
+  dim3 grid((K + 63) / 64, S);
+  if (raw) {
+    allow_big_lds(rowsum_kernel<true>);
+    hipLaunchKernelGGL(rowsum_kernel<true>, grid, dim3(256), lds, st, K, theta, t,
+                       stars, covpts, tab, meanvar, xp, temporal, raw, rowsum);
+  } else {
+    allow_big_lds(rowsum_kernel<false>);
+    hipLaunchKernelGGL(rowsum_kernel<false>, grid, dim3(256), lds, st, K, theta,
+                       t, stars, covpts, tab, meanvar, xp, temporal, raw, rowsum);
+  }
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}
+
+int sp_launch_norm_coef(int S, int K, const sp_star *stars, const double *meanvar,
+                        const double *condmean, int normalized, int order,
+                        double zmax, const double *rowsum, double *qv, void *coef,
+                        uint32_t *status, hipStream_t st) {
+  hipLaunchKernelGGL(norm_coef_kernel, dim3(S), dim3(256), 0, st, K, stars,
+                     meanvar, condmean, normalized, order, zmax, rowsum, qv,
+                     (Coef *)coef, status);
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}
+
+int sp_launch_assemble(int S, int K, int M, int Kp, int system,
+                       const double *theta, const double *t, const sp_star *stars,
+                       int covpts, const double *tab, const double *meanvar,
+                       const double *xp, int temporal, const double *raw,
+                       int normalized, const double *qv, const void *coef,
+                       const double *diag, int add_noise, const double *flux,
+                       double *out, long ldo, long strideo, hipStream_t st) {
+  const int np = covpts + 4;
+  const size_t lds = sizeof(double) * ((raw ? 0 : 5 * (size_t)np) + 6 * 64);
+  if (lds > attr_lds_limit) return SP_ERR_INVALID;
+  const int ntr = ((system ? Kp : K) + 63) / 64;
+  const int ntiles = system ? ntr * (ntr + 1) / 2 : ntr * ntr;
+  dim3 grid(ntiles, S);
+#define SP_ASM(FM, SY)                                                          \
+  do {                                                                          \
+    allow_big_lds(assemble_kernel<FM, SY>);                                     \
+    hipLaunchKernelGGL((assemble_kernel<FM, SY>), grid, dim3(256), lds, st, K,  \
+                       M, Kp, theta, t, stars, covpts, tab, meanvar, xp,        \
+                       temporal, raw, normalized, qv, (const Coef *)coef, diag, \
+                       add_noise, flux, out, ldo, strideo, ntr);                \
+  } while (0)
+  if (raw && system)
+    SP_ASM(true, true);
+  else if (raw)
+    SP_ASM(true, false);
+  else if (system)
+    SP_ASM(false, true);
+  else
+    SP_ASM(false, false);
+#undef SP_ASM
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}

@@ -1,0 +1,352 @@
+// Host-side constants of the flux operator: index tables,
+// the phase-curve solution vector and change of basis (row a5), the
+// limb-darkening basis, and the AlphaBeta series (row a15).
+//
+// The reference computes these in C++ too (ops/include/flux.h, compile-time
+// SP__LMAX / SP__UMAX); here the degrees are run-time values held by the
+// handle and the polynomial algebra is done on dense coefficient vectors.
+//
+// Polynomial basis: index n(l,m) = l*l + l + m stands for the monomial
+//   x^(mu/2) y^(nu/2)            if nu = l + m is even,
+//   x^((mu-1)/2) y^((nu-1)/2) z  if it is odd,          mu = l - m,
+// with z^2 = 1 - x^2 - y^2 folded back into the basis (flux.h:206-236).
+#include <cmath>
+#include <cstring>
+
+#include "sp_internal.h"
+
+namespace {
+
+inline int nidx(int l, int m) { return l * l + l + m; }
+
+// acc += v * (monomial n(l1,m1) * monomial n(l2,m2))   (flux.h:209-236)
+inline void mono_mul_acc(double *acc, int l1, int m1, int l2, int m2, double v) {
+  const bool z1 = ((l1 + m1) & 1) != 0, z2 = ((l2 + m2) & 1) != 0;
+  const int l = l1 + l2, m = m1 + m2;
+  if (z1 && z2) {
+    acc[nidx(l - 2, m)] += v;
+    acc[nidx(l, m - 2)] += -v;
+    acc[nidx(l, m + 2)] += -v;
+  } else {
+    acc[nidx(l, m)] += v;
+  }
+}
+
+// out = z * p, p of degree <= deg, out of degree deg+1  (flux.h:74-96)
+void times_z(int deg, const double *p, double *out, int nout) {
+  for (int i = 0; i < nout; ++i) out[i] = 0.0;
+  for (int l = 0; l <= deg; ++l)
+    for (int m = -l; m <= l; ++m) {
+      const double v = p[nidx(l, m)];
+      const int lz = l + 1, nz = lz * lz + lz + m;
+      if ((l + m) & 1) {
+        out[nz - 4 * lz + 2] += v;
+        out[nz - 2] -= v;
+        out[nz + 2] -= v;
+      } else {
+        out[nz] += v;
+      }
+    }
+}
+
+// phase-curve solution vector r^T for degree `deg` (flux.h:22-68)
+void solution_vector(int deg, std::vector<double> &rT) {
+  rT.assign((size_t)(deg + 1) * (deg + 1), 0.0);
+  for (int pass = 0; pass < 2; ++pass) {
+    // pass 0: l, m = 0 mod 4;  pass 1: l, m = 2 mod 4
+    double amp0 = pass == 0 ? M_PI : 0.5 * M_PI;
+    double lfac1 = pass == 0 ? 1.0 : 0.5;
+    double lfac2 = pass == 0 ? 2.0 / 3.0 : 4.0 / 15.0;
+    for (int l = 2 * pass; l <= deg; l += 4) {
+      double amp = amp0;
+      for (int m = 2 * pass; m <= l; m += 4) {
+        const int mu = l - m, nu = l + m;
+        rT[nidx(l, m)] = amp * lfac1;
+        rT[nidx(l, -m)] = amp * lfac1;
+        if (l < deg) {
+          rT[nidx(l + 1, m)] = amp * lfac2;
+          rT[nidx(l + 1, -m)] = amp * lfac2;
+        }
+        amp *= (nu + 2.0) / (mu - 2.0);
+      }
+      lfac1 /= (l / 2 + 2) * (l / 2 + 3);
+      lfac2 /= (l / 2 + 2.5) * (l / 2 + 3.5);
+      if (pass == 0)
+        amp0 *= 0.0625 * (l + 2) * (l + 2);
+      else
+        amp0 *= 0.0625 * l * (l + 4);
+    }
+  }
+}
+
+// Dense A1 (Ylm -> polynomial basis), degree `deg`, row-major Nd x Nd
+// (flux.h:98-279).
+void change_of_basis(int deg, std::vector<double> &A1) {
+  const int Nd = (deg + 1) * (deg + 1);
+  A1.assign((size_t)Nd * Nd, 0.0);
+  const double norm = 2.0 / std::sqrt(M_PI);
+
+  // amplitudes per Ylm (flux.h:189-203)
+  std::vector<double> amp(Nd, 0.0);
+  for (int l = 0; l <= deg; ++l) {
+    amp[nidx(l, 0)] = std::sqrt((double)(2 * (2 * l + 1)));
+    for (int m = 1; m <= l; ++m) {
+      amp[nidx(l, m)] =
+          -amp[nidx(l, m - 1)] / std::sqrt((double)((l + m) * (l - m + 1)));
+      amp[nidx(l, -m)] = amp[nidx(l, m)];
+    }
+    amp[nidx(l, 0)] *= std::sqrt(0.5);
+  }
+  for (int i = 0; i < Nd; ++i) amp[i] /= (2 * std::sqrt(M_PI));
+
+  // z-polynomials P[l][m], m >= 0, as dense vectors (flux.h:102-139)
+  std::vector<std::vector<double>> P((size_t)Nd);
+  std::vector<double> zp(Nd);
+  double term = 1.0, fac = 1.0;
+  for (int m = 0; m <= deg; ++m) {
+    std::vector<double> &pmm = P[nidx(m, m)];
+    pmm.assign(Nd, 0.0);
+    pmm[0] = fac;
+    for (int l = m + 1; l <= deg; ++l) {
+      std::vector<double> &cur = P[nidx(l, m)];
+      cur.assign(Nd, 0.0);
+      times_z(deg - 1, P[nidx(l - 1, m)].data(), zp.data(), Nd);
+      for (int i = 0; i < Nd; ++i) cur[i] = (2 * l - 1) * zp[i] / (l - m);
+      if (l > m + 1) {
+        const std::vector<double> &p2 = P[nidx(l - 2, m)];
+        for (int i = 0; i < Nd; ++i) cur[i] -= (l + m - 1) * p2[i] / (l - m);
+      }
+    }
+    fac *= -term;
+    term += 2;
+  }
+
+  // (x, y) terms of each Ylm (flux.h:158-183): lists of (l', m', value)
+  struct Term {
+    int l, m;
+    double v;
+  };
+  std::vector<std::vector<Term>> XY((size_t)Nd);
+  for (int m = 0; m <= deg; ++m) {
+    double t1 = 1.0, t2 = m;
+    for (int j = 0; j <= m; j += 2) {
+      if (j > 0) {
+        t1 *= -(m - j + 1.0) * (m - j + 2.0) / (j * (j - 1.0));
+        t2 *= -(m - j) * (m - j + 1.0) / (j * (j + 1.0));
+      }
+      for (int l = m; l <= deg; ++l) {
+        XY[nidx(l, m)].push_back({m, 2 * j - m, t1});
+        if (j < m) XY[nidx(l, -m)].push_back({m, 2 * (j + 1) - m, t2});
+      }
+    }
+  }
+
+  // column by column: product of the z part and the (x, y) part
+  std::vector<double> col(Nd);
+  for (int l = 0; l <= deg; ++l)
+    for (int m = -l; m <= l; ++m) {
+      const int c = nidx(l, m);
+      const std::vector<double> &pz = P[nidx(l, m < 0 ? -m : m)];
+      for (int i = 0; i < Nd; ++i) col[i] = 0.0;
+      for (int lz = 0; lz <= deg; ++lz)
+        for (int mz = -lz; mz <= lz; ++mz) {
+          const double vz = pz[nidx(lz, mz)];
+          if (vz == 0) continue;
+          for (const Term &t : XY[c])
+            if (lz + t.l <= deg)
+              mono_mul_acc(col.data(), lz, mz, t.l, t.m, vz * t.v * norm * amp[c]);
+        }
+      for (int r = 0; r < Nd; ++r) A1[(size_t)r * Nd + c] = col[r];
+    }
+}
+
+}  // namespace
+
+void sp_build_index_tables(int ydeg, int32_t *l_of, int32_t *m_of,
+                           int32_t *mirror, int32_t *m0, int32_t *blk) {
+  for (int l = 0; l <= ydeg; ++l) {
+    for (int m = -l; m <= l; ++m) {
+      const int n = nidx(l, m);
+      l_of[n] = l;
+      m_of[n] = m;
+      mirror[n] = nidx(l, -m);
+    }
+    m0[l] = nidx(l, 0);
+    blk[l] = l == 0 ? 0 : sp_nwig_of(l - 1);
+  }
+  blk[ydeg + 1] = sp_nwig_of(ydeg);
+}
+
+void sp_build_flux_constants(int ydeg, int udeg, std::vector<double> &rT,
+                             std::vector<double> &A1, std::vector<double> &U1,
+                             std::vector<double> &rta1) {
+  const int LU = ydeg + udeg;
+  const int NLU = (LU + 1) * (LU + 1), N = (ydeg + 1) * (ydeg + 1);
+  solution_vector(LU, rT);
+  change_of_basis(LU, A1);
+
+  // rTA1 at degree ydeg (flux.h:302-309): the leading N x N block of A1 and
+  // the leading N entries of rT do not depend on the total degree
+  rta1.assign(N, 0.0);
+  for (int c = 0; c < N; ++c) {
+    double s = 0.0;
+    for (int r = 0; r < N; ++r) {
+      const double a = A1[(size_t)r * NLU + c];
+      if (a != 0.0) s += rT[r] * a;
+    }
+    rta1[c] = s;
+  }
+
+  // limb-darkening basis U1 (flux.h:332-409)
+  const int nu1 = (udeg + 1) * (udeg + 1);
+  U1.assign((size_t)nu1 * (udeg + 1), 0.0);
+  if (udeg == 0) return;
+  const int W = LU + 1;
+  std::vector<double> LT((size_t)W * W, 0.0), YT((size_t)W * W, 0.0);
+  for (int l = 0; l < W; ++l) {
+    double lck = 1.0;
+    for (int k = 0; k <= l; ++k) {
+      LT[(size_t)k * W + l] = ((k + 1) % 2 == 0) ? lck : -lck;
+      lck *= (l - k) / (k + 1.0);
+    }
+  }
+  for (int par = 0; par < 2; ++par) {
+    double twol = par == 0 ? 1.0 : 2.0, lfac = 1.0, fac0 = par == 0 ? 1.0 : 0.5;
+    for (int l = par; l < W; l += 2) {
+      const double a = twol * std::sqrt((2 * l + 1) / (4 * M_PI)) / lfac;
+      double lck = par == 0 ? 1.0 : (double)l, fac = fac0;
+      for (int k = par; k <= l; k += 2) {
+        YT[(size_t)k * W + l] = a * lck * fac;
+        fac *= (k + l + 1.0) / (k - l + 1.0);
+        lck *= (l - k) * (l - k - 1) / ((k + 1.0) * (k + 2.0));
+      }
+      fac0 *= par == 0 ? -0.25 * (l + 1) * (l + 1) : -0.25 * (l + 2) * l;
+      lfac *= (l + 1.0) * (l + 2.0);
+      twol *= 4.0;
+    }
+  }
+  // YT is upper triangular: U0 = YT^{-1} LT by back substitution, then / norm
+  const double norm = 2.0 / std::sqrt(M_PI);
+  std::vector<double> U0((size_t)W * W, 0.0);
+  for (int c = 0; c < W; ++c)
+    for (int r = W - 1; r >= 0; --r) {
+      double s = LT[(size_t)r * W + c];
+      for (int k = r + 1; k < W; ++k) s -= YT[(size_t)r * W + k] * U0[(size_t)k * W + c];
+      U0[(size_t)r * W + c] = s / YT[(size_t)r * W + r];
+    }
+  for (double &v : U0) v /= norm;
+  // U1 = (A1 . X . U0)[:nu1, :udeg+1], X(l(l+1), l) = 1
+  for (int r = 0; r < nu1; ++r)
+    for (int c = 0; c <= udeg; ++c) {
+      double s = 0.0;
+      for (int l = 0; l < W; ++l)
+        s += A1[(size_t)r * NLU + l * (l + 1)] * U0[(size_t)l * W + c];
+      U1[(size_t)r * (udeg + 1) + c] = s;
+    }
+}
+
+// rTA1L(u) (flux.h:500-523 with computeLp, flux.h:415-441)
+void sp_host_rTA1L(const sp_handle *h, const double *u, double *out) {
+  const int ydeg = h->ydeg, udeg = h->udeg, N = h->N;
+  const int LU = ydeg + udeg, NLU = (LU + 1) * (LU + 1);
+  const int nu1 = (udeg + 1) * (udeg + 1);
+  if (udeg == 0) {
+    for (int i = 0; i < N; ++i) out[i] = h->rta1[i];
+    return;
+  }
+  // limb-darkening polynomial p = U1 . [-1, u], normalised to pi / (rT . p)
+  double p[(SP_MAX_UDEG + 1) * (SP_MAX_UDEG + 1)];
+  double dotp = 0.0;
+  for (int r = 0; r < nu1; ++r) {
+    double s = h->U1[(size_t)r * (udeg + 1)] * -1.0;
+    for (int c = 1; c <= udeg; ++c) s += h->U1[(size_t)r * (udeg + 1) + c] * u[c - 1];
+    p[r] = s;
+    dotp += h->rT[r] * s;
+  }
+  const double scale = (1.0 / dotp) * M_PI;
+  for (int r = 0; r < nu1; ++r) p[r] *= scale;
+
+  // v = rT . Lp, column n1 of Lp being (Ylm-basis monomial n1) x p
+  std::vector<double> v(N, 0.0), col(NLU);
+  for (int l1 = 0; l1 <= ydeg; ++l1)
+    for (int m1 = -l1; m1 <= l1; ++m1) {
+      const int n1 = nidx(l1, m1);
+      for (int i = 0; i < NLU; ++i) col[i] = 0.0;
+      for (int l2 = 0; l2 <= udeg; ++l2)
+        for (int m2 = -l2; m2 <= l2; ++m2)
+          mono_mul_acc(col.data(), l1, m1, l2, m2, p[nidx(l2, m2)]);
+      double s = 0.0;
+      for (int r = 0; r < NLU; ++r) s += h->rT[r] * col[r];
+      v[n1] = s;
+    }
+  for (int c = 0; c < N; ++c) {
+    double s = 0.0;
+    for (int r = 0; r < N; ++r) s += v[r] * h->A1[(size_t)r * NLU + c];
+    out[c] = s;
+  }
+}
+
+extern "C" {
+
+int sp_index_tables(int ydeg, int32_t *l_of, int32_t *m_of, int32_t *mirror,
+                    int32_t *m0, int32_t *blk) {
+  if (ydeg < 0 || ydeg > SP_MAX_YDEG || !l_of || !m_of || !mirror || !m0 || !blk)
+    return SP_ERR_INVALID;
+  sp_build_index_tables(ydeg, l_of, m_of, mirror, m0, blk);
+  return SP_OK;
+}
+
+// cos/sin of -(k pi/2) ("alpha" = -pi/2 per step) and of +(k pi/2) ("gamma"),
+// as exact integers from k mod 4, and the alternating sign (wigner.h:232-270).
+int sp_wigner_int_tables(int ydeg, int32_t *cosmal, int32_t *sinmal,
+                         int32_t *sgn, int32_t *cosmga, int32_t *sinmga) {
+  if (ydeg < 0 || ydeg > SP_MAX_YDEG || !cosmal || !sinmal || !sgn || !cosmga ||
+      !sinmga)
+    return SP_ERR_INVALID;
+  static const int c4[4] = {1, 0, -1, 0}, s4[4] = {0, 1, 0, -1};
+  cosmal[0] = sinmal[0] = sgn[0] = cosmga[0] = sinmga[0] = 0;
+  for (int k = 1; k <= ydeg; ++k) {
+    cosmal[k] = c4[k & 3];
+    sinmal[k] = -s4[k & 3];
+    cosmga[k] = c4[k & 3];
+    sinmga[k] = s4[k & 3];
+    sgn[k] = (k & 1) ? -1 : 1;
+  }
+  return SP_OK;
+}
+
+// ops/norm/norm.py:26-44
+int sp_alpha_beta(double z, int order, double *alpha, double *beta,
+                  double *dalpha_dz, double *dbeta_dz) {
+  if (order < 0) return SP_ERR_INVALID;
+  double fac = 1.0, a = 0.0, b = 0.0, da = 0.0, db = 0.0, df = 0.0;
+  for (int n = 0; n <= order; ++n) {
+    da += df;
+    db += 2 * n * df;
+    df = (2 * n + 3) * (df * z + fac);
+    a += fac;
+    b += 2 * n * fac;
+    fac *= z * (2 * n + 3);
+  }
+  if (alpha) *alpha = a;
+  if (beta) *beta = b;
+  if (dalpha_dz) *dalpha_dz = da;
+  if (dbeta_dz) *dbeta_dz = db;
+  return SP_OK;
+}
+
+int sp_version(void) { return 100; }
+
+const char *sp_strerror(int status) {
+  switch (status) {
+    case SP_OK: return "ok";
+    case SP_ERR_INVALID: return "invalid argument";
+    case SP_ERR_HIP: return "HIP runtime error";
+    case SP_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case SP_ERR_STATE: return "constants or Ylm moments not set";
+    case SP_ERR_ALLOC: return "allocation failed";
+    default: return "unknown status";
+  }
+}
+
+}  // extern "C"

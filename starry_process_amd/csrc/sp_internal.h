@@ -1,0 +1,93 @@
+// Internal declarations shared by the translation units of libsp_hip.so.
+// gfx950 (MI355X, CDNA4) only; wavefront = 64.
+#ifndef SP_INTERNAL_H
+#define SP_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <vector>
+
+#include "../../include/starry_process_amd.h"
+
+#define SP_WAVE 64
+#define SP_MAX_YDEG 30
+#define SP_MAX_UDEG 4
+#define SP_NORM_MAXORDER 64
+
+// Cholesky blocking: panels of SP_NB columns, systems padded to a multiple of
+// SP_NB rows (the right-hand sides ride along as extra rows).
+#define SP_NB 64
+
+struct sp_handle {
+  int ydeg, udeg, N, NWIG, device;
+  // host constants
+  std::vector<int32_t> l_of, m_of, mirror, m0, blk;
+  std::vector<double> rT;       // phase-curve solution vector, degree ydeg+udeg
+  std::vector<double> A1;       // dense change of basis, (NLU x NLU), row-major
+  std::vector<double> U1;       // ((udeg+1)^2 x (udeg+1)) limb-darkening basis
+  std::vector<double> rta1;     // rT . A1 at degree ydeg (N)
+  // device constants
+  int32_t *d_l_of, *d_m_of, *d_mirror, *d_blk;
+  double *d_Rx90;               // packed Rx(pi/2)
+  double *d_wnp, *d_Wnp;        // marginalisation constants (flux.py:121-179)
+  bool have_marginal;
+  double *d_xp;                 // lag grid of the last kernel table
+  int xp_covpts;
+  // device state: Ylm moments
+  double *d_mean_ylm, *d_cov_ylm, *d_ez, *d_Ez, *d_tmpNN;
+  bool have_moments;
+  // small device scratch owned by the handle
+  double *d_scratch;
+  size_t scratch_bytes;
+};
+
+const char *sp_set_hip_error(hipError_t e, const char *what);
+
+#define SP_HIP(call)                                   \
+  do {                                                 \
+    hipError_t e_ = (call);                            \
+    if (e_ != hipSuccess) {                            \
+      sp_set_hip_error(e_, #call);                     \
+      return SP_ERR_HIP;                               \
+    }                                                  \
+  } while (0)
+
+#define SP_LAUNCH_CHECK()                              \
+  do {                                                 \
+    hipError_t e_ = hipGetLastError();                 \
+    if (e_ != hipSuccess) {                            \
+      sp_set_hip_error(e_, "kernel launch");           \
+      return SP_ERR_HIP;                               \
+    }                                                  \
+  } while (0)
+
+static inline int sp_nwig_of(int l) {
+  return ((l + 1) * (2 * l + 1) * (2 * l + 3)) / 3;
+}
+static inline int sp_roundup(int x, int m) { return ((x + m - 1) / m) * m; }
+
+// host-side constant builders (sp_host.cpp)
+void sp_build_index_tables(int ydeg, int32_t *l_of, int32_t *m_of,
+                           int32_t *mirror, int32_t *m0, int32_t *blk);
+void sp_build_flux_constants(int ydeg, int udeg, std::vector<double> &rT,
+                             std::vector<double> &A1, std::vector<double> &U1,
+                             std::vector<double> &rta1);
+void sp_host_rTA1L(const sp_handle *h, const double *u, double *out);
+
+// ---- kernel launchers (one per .hip file) -----------------------------------
+int sp_launch_Rx(sp_handle *h, const double *cs_dev /* [n,2] cos,sin */, int n,
+                 double *R, double *dR, hipStream_t st);
+int sp_launch_dotRx(sp_handle *h, const double *M, long strideM, long rs,
+                    long cs, int rows, const double *R, long strideR,
+                    double *out, int batch, hipStream_t st);
+
+// C[b] (+)= alpha * A[b] . B[b]^T  on 64x64 tiles with fp64 MFMA.
+//   A: Mrows x Kd (lda), B: Nrows x Kd (ldb), C: Mrows x Nrows (ldc)
+//   beta is 0 or 1;  lower_only: only tiles with tile_i >= tile_j are touched
+//   Mrows, Nrows multiples of 64; Kd multiple of 4.
+int sp_launch_gemm_nt(const double *A, long lda, long strideA, const double *B,
+                      long ldb, long strideB, double *C, long ldc, long strideC,
+                      int Mrows, int Nrows, int Kd, double alpha, int beta,
+                      int lower_only, int batch, hipStream_t st);
+
+#endif

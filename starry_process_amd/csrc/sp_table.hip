@@ -1,0 +1,175 @@
+// Inclination-marginalised kernel table.
+//
+// For one flux operator rTA1 (one limb-darkening vector) this produces what
+// FluxIntegral._compute builds before it interpolates (flux.py:181-231,
+// 295-330): the scalar mean and variance, the second moment on the lag grid
+// and the cubic-interpolation coefficients.
+//
+// The reference evaluates the lag-grid second moment as two dense
+// (K' x N)(N x N) products followed by a row sum (wigner.h:409-459, 80 MFLOP).
+// Algebraically the row sum commutes with the products, leaving
+//     f_k = sum_a cos(a x_k) C_a + sin(a x_k) S_a ,  a = 0..ydeg,
+// with C_a, S_a sums of the N row-reductions r1, r2 of W o Ez -- O(N^2 + K' ydeg)
+// work.  One workgroup per table; everything but the N x N reads stays in LDS.
+#include "sp_internal.h"
+
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// sum over the 256 threads of the block; result valid in every thread
+__device__ __forceinline__ double block_sum(double v, double *red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void table_kernel(
+    int ydeg, int N, const int32_t *__restrict__ l_of,
+    const int32_t *__restrict__ mirror, const int32_t *__restrict__ blk,
+    const double *__restrict__ wnp, const double *__restrict__ Wnp,
+    const double *__restrict__ ez, const double *__restrict__ Ez,
+    const double *__restrict__ rta1_all, int covpts,
+    const double *__restrict__ xp, double *__restrict__ tab_all,
+    double *__restrict__ meanvar_all) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double *s_rta1 = lds;             // N
+  double *s_r1 = s_rta1 + N;        // N
+  double *s_r2 = s_r1 + N;          // N
+  double *s_yp = s_r2 + N;          // covpts + 4
+  double *s_ca = s_yp + covpts + 4; // ydeg + 1
+  double *s_sa = s_ca + ydeg + 1;   // ydeg + 1
+  double *s_red = s_sa + ydeg + 1;  // 4
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int np = covpts + 4;
+  const double *rta1 = rta1_all + (size_t)blockIdx.x * N;
+  double *tab = tab_all + (size_t)blockIdx.x * 5 * np;
+
+  for (int n = tid; n < N; n += 256) s_rta1[n] = rta1[n];
+  __syncthreads();
+
+  // first moment: w[l] = rTA1[l-block] . wnp[l];  mean = sum_l w[l] . ez[l-block]
+  double part = 0.0;
+  for (int n = tid; n < N; n += 256) {
+    const int l = l_of[n], w = 2 * l + 1, c = n - l * l;
+    const double *B = wnp + blk[l] + c;
+    double wn = 0.0;
+    for (int r = 0; r < w; ++r) wn += s_rta1[l * l + r] * B[r * w];
+    part += wn * ez[n];
+  }
+  const double mean = block_sum(part, s_red);
+
+  // rows of W o Ez, W[n, j] = Wnp[n, j] * rTA1[m0(l_n)] * rTA1[m0(l_j)]
+  for (int n = wave; n < N; n += 4) {
+    const int ln = l_of[n];
+    const double rn = s_rta1[ln * ln + ln];
+    const double *Wn = Wnp + (size_t)n * N, *En = Ez + (size_t)n * N;
+    double a = 0.0, b = 0.0;
+    for (int j = lane; j < N; j += 64) {
+      const int lj = l_of[j];
+      const double wv = Wn[j] * (rn * s_rta1[lj * lj + lj]);
+      a += wv * En[j];
+      b += wv * En[mirror[j]];
+    }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (lane == 0) {
+      s_r1[n] = a;
+      s_r2[n] = b;
+    }
+  }
+  __syncthreads();
+
+  // variance = <W, Ez> - mean^2 (flux.py:305-308)
+  double pv = 0.0;
+  for (int n = tid; n < N; n += 256) pv += s_r1[n];
+  const double wez = block_sum(pv, s_red);
+  if (tid == 0) {
+    meanvar_all[2 * blockIdx.x] = mean;
+    meanvar_all[2 * blockIdx.x + 1] = wez - mean * mean;
+  }
+
+  // harmonic coefficients
+  if (tid <= ydeg) {
+    const int a = tid;
+    double c = 0.0, s = 0.0;
+    for (int l = a; l <= ydeg; ++l) {
+      const int n0 = l * l + l;
+      if (a == 0) {
+        c += s_r1[n0];
+      } else {
+        c += s_r1[n0 - a] + s_r1[n0 + a];
+        s += s_r2[n0 + a] - s_r2[n0 - a];
+      }
+    }
+    s_ca[a] = c;
+    s_sa[a] = s;
+  }
+  __syncthreads();
+
+  // second moment on the lag grid minus mean^2 (flux.py:317-320)
+  const double mean2 = mean * mean;
+  for (int k = tid; k < np; k += 256) {
+    double s1, c1;
+    sincos(xp[k], &s1, &c1);
+    double cm2 = 1.0, sm2 = 0.0, cm1 = c1, sm1 = s1;
+    double acc = s_ca[0];
+    if (ydeg >= 1) acc += cm1 * s_ca[1] + sm1 * s_sa[1];
+    for (int a = 2; a <= ydeg; ++a) {
+      const double cn = 2.0 * cm1 * c1 - cm2, sn = 2.0 * sm1 * c1 - sm2;
+      acc += cn * s_ca[a] + sn * s_sa[a];
+      cm2 = cm1;
+      sm2 = sm1;
+      cm1 = cn;
+      sm1 = sn;
+    }
+    const double y = acc - mean2;
+    s_yp[k] = y;
+    tab[k] = y;
+  }
+  __syncthreads();
+
+  // cubic interpolant (flux.py:322-330)
+  for (int i = tid; i < np; i += 256) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (i <= covpts) {
+      const double y0 = s_yp[i], y1 = s_yp[i + 1], y2 = s_yp[i + 2],
+                   y3 = s_yp[i + 3];
+      a0 = y1;
+      a1 = -y0 / 3.0 - 0.5 * y1 + y2 - y3 / 6.0;
+      a2 = 0.5 * (y0 + y2) - y1;
+      a3 = 0.5 * ((y1 - y2) + (y3 - y0) / 3.0);
+    }
+    tab[np + i] = a0;
+    tab[2 * np + i] = a1;
+    tab[3 * np + i] = a2;
+    tab[4 * np + i] = a3;
+  }
+}
+
+}  // namespace
+
+int sp_launch_kernel_table(sp_handle *h, const double *rta1_dev, int ntab,
+                           int covpts, const double *xp_dev, double *tab_dev,
+                           double *meanvar_dev, hipStream_t st) {
+  const size_t lds =
+      sizeof(double) * ((size_t)3 * h->N + covpts + 4 + 2 * (h->ydeg + 1) + 4);
+  if (lds > 150 * 1024) return SP_ERR_INVALID;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(table_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(table_kernel, dim3(ntab), dim3(256), lds, st, h->ydeg,
+                     h->N, h->d_l_of, h->d_mirror, h->d_blk, h->d_wnp, h->d_Wnp,
+                     h->d_ez, h->d_Ez, rta1_dev, covpts, xp_dev, tab_dev,
+                     meanvar_dev);
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}

@@ -1,0 +1,310 @@
+"""
+One ``Engine`` per GPU: owns the ``sp_handle`` and turns torch CUDA tensors into
+the raw device pointers the C ABI takes.  PyTorch is plumbing here (HBM
+buffers, streams, torch.distributed); every number is produced by the HIP
+kernels in ``csrc/``.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from . import hostconst
+from ._lib import STAR_DTYPE, TEMPORAL, SPError, c_void_p, check, hptr
+
+__all__ = ["Engine", "get_engine", "make_stars"]
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def make_stars(S, period=1.0, inc_deg=60.0, tau=0.0, baseline_var=0.0,
+               baseline_mean=0.0, data_var=0.0, table=0):
+    """Structured host array of ``sp_star`` (inclination converted to radians,
+    flux.py:236-238)."""
+    st = np.zeros(S, dtype=STAR_DTYPE)
+    st["period"] = period
+    st["inc"] = np.asarray(inc_deg, dtype=float) * (np.pi / 180)
+    st["tau"] = tau
+    st["baseline_var"] = baseline_var
+    st["baseline_mean"] = baseline_mean
+    st["data_var"] = data_var
+    st["table"] = table
+    return st
+
+
+class Engine(object):
+    def __init__(self, ydeg=15, udeg=2, device=0):
+        torch = _torch()
+        L = _lib.lib()
+        if not torch.cuda.is_available():
+            raise SPError("no MI355X visible to PyTorch: the hot path has no CPU fallback")
+        self.ydeg, self.udeg, self.device_index = int(ydeg), int(udeg), int(device)
+        self.device = torch.device("cuda", self.device_index)
+        self.N = (self.ydeg + 1) ** 2
+        self.NWIG = ((self.ydeg + 1) * (2 * self.ydeg + 1) * (2 * self.ydeg + 3)) // 3
+        torch.cuda.set_device(self.device)
+        torch.zeros(1, device=self.device)  # make sure the context exists
+        h = c_void_p()
+        check(L.sp_create(self.ydeg, self.udeg, self.device_index, ctypes.byref(h)))
+        self._h = h
+        self._L = L
+        wnp, Wnp = hostconst.marginal_constants(self.ydeg)
+        wnp = np.ascontiguousarray(wnp)
+        Wnp = np.ascontiguousarray(Wnp)
+        check(L.sp_set_marginal_constants(self._h, hptr(wnp), hptr(Wnp)))
+        self._moments_id = None
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._L.sp_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # -- helpers ------------------------------------------------------------
+    def _stream(self):
+        return c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    def dev(self, a, dtype=None):
+        """Host array / tensor -> contiguous tensor on this GPU."""
+        torch = _torch()
+        if isinstance(a, torch.Tensor):
+            t = a.to(self.device)
+            if dtype is not None:
+                t = t.to(dtype)
+            return t.contiguous()
+        a = np.ascontiguousarray(a)
+        t = torch.from_numpy(a).to(self.device)
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.contiguous()
+
+    def f64(self, a):
+        return self.dev(a, _torch().float64)
+
+    def empty(self, *shape):
+        torch = _torch()
+        return torch.empty(*shape, dtype=torch.float64, device=self.device)
+
+    def stars_to_device(self, stars):
+        torch = _torch()
+        stars = np.ascontiguousarray(stars)
+        assert stars.dtype == STAR_DTYPE
+        raw = torch.from_numpy(stars.view(np.uint8).reshape(-1).copy())
+        return raw.to(self.device)
+
+    @staticmethod
+    def _p(t):
+        return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+    def synchronize(self):
+        check(self._L.sp_stream_synchronize(self._h, self._stream()))
+
+    # -- ops ------------------------------------------------------
+    def Rx(self, thetas, deriv=True):
+        thetas = np.ascontiguousarray(np.atleast_1d(np.asarray(thetas, dtype=np.float64)))
+        n = thetas.shape[0]
+        R = self.empty(n, self.NWIG)
+        dR = self.empty(n, self.NWIG) if deriv else None
+        check(self._L.sp_Rx(self._h, hptr(thetas), n, self._p(R), self._p(dR), self._stream()))
+        return R, dR
+
+    def dotRx(self, M, Rpacked):
+        """M [rows, N] or [B, rows, N]; Rpacked [NWIG] or [B, NWIG]."""
+        M = self.f64(M)
+        Rpacked = self.f64(Rpacked)
+        batched = M.dim() == 3
+        Mb = M if batched else M.unsqueeze(0)
+        B, rows, N = Mb.shape
+        assert N == self.N
+        strideR = self.NWIG if Rpacked.dim() == 2 else 0
+        out = self.empty(B, rows, N)
+        check(self._L.sp_dotRx(self._h, self._p(Mb), rows * N, N, 1, rows,
+                               self._p(Rpacked), strideR, self._p(out), B, self._stream()))
+        return out if batched else out[0]
+
+    def tensordotRz(self, M, theta):
+        M = self.f64(M)
+        theta = self.f64(theta).reshape(-1)
+        K = theta.shape[0]
+        assert M.shape == (K, self.N)
+        f = self.empty(K, self.N)
+        check(self._L.sp_tensordotRz(self._h, self._p(M), self._p(theta), K, self._p(f), self._stream()))
+        return f
+
+    def special_tensordotRz(self, T, M, theta):
+        T = self.f64(T)
+        M = self.f64(M)
+        theta = self.f64(theta).reshape(-1)
+        assert T.shape == (self.N, self.N) and M.shape == (self.N, self.N)
+        K = theta.shape[0]
+        f = self.empty(K)
+        check(self._L.sp_special_tensordotRz(self._h, self._p(T), self._p(M), self._p(theta), K, self._p(f), self._stream()))
+        return f
+
+    def rTA1(self):
+        out = np.empty(self.N)
+        check(self._L.sp_rTA1(self._h, hptr(out)))
+        return out
+
+    def rTA1L(self, u):
+        u = np.ascontiguousarray(np.asarray(u, dtype=np.float64).reshape(-1, max(self.udeg, 1)))[:, : self.udeg]
+        u = np.ascontiguousarray(u)
+        n = u.shape[0]
+        out = np.empty((n, self.N))
+        check(self._L.sp_rTA1L(self._h, hptr(u) if self.udeg else c_void_p(0), n, hptr(out)))
+        return out
+
+    # -- moments / kernel table ------------------------------------------------
+    def set_moments(self, mean_ylm, cov_ylm):
+        mean_ylm = np.ascontiguousarray(np.asarray(mean_ylm, dtype=np.float64).reshape(-1))
+        cov_ylm = np.ascontiguousarray(np.asarray(cov_ylm, dtype=np.float64))
+        assert mean_ylm.shape == (self.N,) and cov_ylm.shape == (self.N, self.N)
+        check(self._L.sp_set_ylm_moments(self._h, hptr(mean_ylm), hptr(cov_ylm)))
+
+    def polar_moments(self):
+        ez = np.empty(self.N)
+        Ez = np.empty((self.N, self.N))
+        check(self._L.sp_get_polar_moments(self._h, hptr(ez), hptr(Ez)))
+        return ez, Ez
+
+    def kernel_table(self, rta1, covpts):
+        """rta1 [ntab, N] (host or device) -> tab [ntab, 5, covpts+4], meanvar [ntab, 2]."""
+        rta1 = self.f64(np.atleast_2d(rta1) if not hasattr(rta1, "dim") else rta1)
+        ntab = rta1.shape[0]
+        _, xp = hostconst.lag_grid(int(covpts))
+        xp = np.ascontiguousarray(xp)
+        assert xp.shape[0] == covpts + 4
+        tab = self.empty(ntab, 5, covpts + 4)
+        mv = self.empty(ntab, 2)
+        check(self._L.sp_kernel_table(self._h, self._p(rta1), ntab, int(covpts), hptr(xp),
+                                      self._p(tab), self._p(mv), self._stream()))
+        return tab, mv
+
+    # -- covariances -----------------------------------------------------------
+    def cov_marginal(self, t, stars, covpts, tab, meanvar, temporal=None,
+                     normalized=True, norm_order=20):
+        t = self.f64(t)
+        S, K = t.shape
+        sd = self.stars_to_device(stars)
+        cov = self.empty(S, K, K)
+        z = self.empty(S)
+        check(self._L.sp_cov_marginal_batched(
+            self._h, S, K, self._p(t), self._p(sd), int(covpts), self._p(tab),
+            self._p(meanvar), TEMPORAL[temporal], int(bool(normalized)), int(norm_order),
+            self._p(cov), K, K * K, self._p(z), self._stream()))
+        return cov, z
+
+    def design_matrix(self, t, stars, rta1):
+        t = self.f64(t)
+        S, K = t.shape
+        sd = self.stars_to_device(stars)
+        rta1 = self.f64(rta1)
+        A = self.empty(S, K, self.N)
+        check(self._L.sp_design_matrix(self._h, S, K, self._p(t), self._p(sd),
+                                       self._p(rta1), self._p(A), self._stream()))
+        return A
+
+    def cov_conditional(self, t, stars, rta1, temporal=None, normalized=True,
+                        norm_order=20):
+        t = self.f64(t)
+        S, K = t.shape
+        sd = self.stars_to_device(stars)
+        rta1 = self.f64(rta1)
+        cov = self.empty(S, K, K)
+        mean = self.empty(S)
+        z = self.empty(S)
+        check(self._L.sp_cov_conditional_batched(
+            self._h, S, K, self._p(t), self._p(sd), self._p(rta1), TEMPORAL[temporal],
+            int(bool(normalized)), int(norm_order), self._p(cov), K, K * K,
+            self._p(mean), self._p(z), self._stream()))
+        return cov, mean, z
+
+    # -- linear algebra ----------------------------------------------------------
+    def cho_factor(self, A):
+        """Lower Cholesky factor(s); A [K, K] or [B, K, K] (not modified)."""
+        torch = _torch()
+        A = self.f64(A).clone()
+        Ab = A if A.dim() == 3 else A.unsqueeze(0)
+        B, K, _ = Ab.shape
+        info = torch.zeros(B, dtype=torch.int32, device=self.device)
+        check(self._L.sp_cho_factor(self._h, self._p(Ab), K, K, K * K, B, self._p(info), self._stream()))
+        return (Ab if A.dim() == 3 else Ab[0]), info
+
+    def cho_solve(self, L, b):
+        """(L L^T)^-1 b; L [K, K] or [B, K, K]; b [K], [K, M] or [B, K, M]."""
+        L = self.f64(L)
+        b = self.f64(b).clone()
+        Lb = L if L.dim() == 3 else L.unsqueeze(0)
+        B, K, _ = Lb.shape
+        shape = b.shape
+        bb = b.reshape(B, K, -1).contiguous()
+        nrhs = bb.shape[2]
+        check(self._L.sp_cho_solve(self._h, self._p(Lb), K, K, K * K, self._p(bb), nrhs, B, self._stream()))
+        return bb.reshape(shape)
+
+    # -- fused likelihood ----------------------------------------------------------
+    def workspace(self, S, K, M):
+        torch = _torch()
+        nbytes = self._L.sp_lnlike_workspace_bytes(self._h, S, K, M)
+        if nbytes < 0:
+            check(int(nbytes))
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def lnlike_ensemble(self, t, flux, stars_dev, diag=None, conditional=False,
+                        covpts=300, tab=None, meanvar=None, rta1=None, temporal=None,
+                        normalized=True, norm_order=20, zmax=0.023, out=None,
+                        status=None, workspace=None):
+        """All arguments already on the device (torch tensors); t [S,K],
+        flux [S,M,K], stars_dev from stars_to_device().  Returns (lnlike, status)."""
+        torch = _torch()
+        S, K = t.shape
+        M = flux.shape[1]
+        ws = workspace if workspace is not None else self.workspace(S, K, M)
+        if out is None:
+            out = self.empty(S)
+        if status is None:
+            status = torch.zeros(S, dtype=torch.int32, device=self.device)
+        check(self._L.sp_lnlike_ensemble(
+            self._h, S, K, M, self._p(t), self._p(flux), self._p(diag), self._p(stars_dev),
+            int(bool(conditional)), int(covpts), self._p(tab), self._p(meanvar),
+            self._p(rta1), TEMPORAL[temporal], int(bool(normalized)), int(norm_order),
+            float(zmax), self._p(ws), self._p(out), self._p(status), self._stream()))
+        return out, status
+
+    def cholesky_lnlike(self, cov, resid):
+        """cov [S,K,K] (noise included), resid [S,M,K] -> (lnlike [S], status [S])."""
+        torch = _torch()
+        cov = self.f64(cov)
+        resid = self.f64(resid)
+        S, K, _ = cov.shape
+        M = resid.shape[1]
+        ws = self.workspace(S, K, M)
+        out = self.empty(S)
+        status = torch.zeros(S, dtype=torch.int32, device=self.device)
+        check(self._L.sp_cholesky_lnlike_batched(self._h, S, K, M, self._p(cov), self._p(resid),
+                                                 self._p(ws), self._p(out), self._p(status), self._stream()))
+        return out, status
+
+
+_engines = {}
+
+
+def get_engine(ydeg=15, udeg=2, device=None):
+    """Process-wide engine cache keyed by (ydeg, udeg, device)."""
+    torch = _torch()
+    if device is None:
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    key = (int(ydeg), int(udeg), int(device))
+    if key not in _engines:
+        _engines[key] = Engine(*key)
+    return _engines[key]

@@ -1,0 +1,170 @@
+"""
+GPU parity of the fused log-likelihood driver (sp_lnlike_ensemble) against the
+golden values from the executed reference and against the oracle.
+
+North-star bar: fp64 log_likelihood within 1e-8 relative of the reference.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden
+from oracle import sp_oracle as orc
+from starry_process_amd.synthetic import synthetic_star
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-8
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from starry_process_amd.engine import get_engine
+
+    cache = {}
+
+    def get(L):
+        if L not in cache:
+            e = get_engine(L, 2)
+            mom = golden("moments_L%d" % L)
+            e.set_moments(mom["default_mean_ylm"], mom["default_cov_ylm"])
+            cache[L] = e
+        return cache[L]
+
+    return get
+
+
+def run_stars(e, K, stars_idx, tspan=4.0, conditional=False, normalized=True,
+              u=(0.0, 0.0), tau=None, temporal=None, covpts=300, baseline_var=0.0,
+              baseline_mean=0.0):
+    from starry_process_amd.engine import make_stars
+
+    sts = [synthetic_star(int(s), K, tspan) for s in stars_idx]
+    S = len(sts)
+    t = np.array([st["t"] for st in sts])
+    flux = np.array([st["flux"] for st in sts])[:, None, :]
+    stars = make_stars(S, period=[st["p"] for st in sts], inc_deg=[st["i"] for st in sts],
+                       tau=tau or 0.0, data_var=[st["data_cov"] for st in sts],
+                       baseline_var=baseline_var, baseline_mean=baseline_mean)
+    rta1 = e.f64(e.rTA1L(u))
+    tab = mv = None
+    if not conditional:
+        tab, mv = e.kernel_table(rta1, covpts)
+    out, status = e.lnlike_ensemble(
+        e.f64(t), e.f64(flux), e.stars_to_device(stars), conditional=conditional,
+        covpts=covpts, tab=tab, meanvar=mv, rta1=rta1, temporal=temporal,
+        normalized=normalized)
+    return out.cpu().numpy(), status.cpu().numpy()
+
+
+def test_cfg1_ydeg5_K100(eng):
+    g = golden("lnlike")
+    v, st = run_stars(eng(5), 100, g["cfg1_L5_K100_stars"])
+    assert not st.any()
+    assert np.max(np.abs(v / g["cfg1_L5_K100"] - 1)) < TOL
+
+
+def test_cfg2_cfg3_ydeg15_K1000(eng):
+    g = golden("lnlike")
+    v, st = run_stars(eng(15), 1000, g["cfg2_L15_K1000_stars"])
+    assert not st.any()
+    assert np.max(np.abs(v / g["cfg2_L15_K1000"] - 1)) < TOL
+    v, _ = run_stars(eng(15), 1000, g["L15_K1000_raw_stars"], normalized=False)
+    assert np.max(np.abs(v / g["L15_K1000_raw"] - 1)) < TOL
+
+
+def test_ydeg15_K200_marginal_and_conditional(eng):
+    g = golden("lnlike")
+    v, _ = run_stars(eng(15), 200, g["L15_K200_stars"])
+    assert np.max(np.abs(v / g["L15_K200"] - 1)) < TOL
+    v, _ = run_stars(eng(15), 200, g["L15_K200_cond_stars"], conditional=True)
+    assert np.max(np.abs(v / g["L15_K200_cond"] - 1)) < TOL
+
+
+def test_ydeg15_K1000_conditional(eng):
+    g = golden("lnlike")
+    v, _ = run_stars(eng(15), 1000, g["L15_K1000_cond_stars"], conditional=True,
+                     normalized=False)
+    assert np.max(np.abs(v / g["L15_K1000_cond"] - 1)) < TOL
+
+
+def test_limb_darkening_baseline_ragged_K(eng):
+    g = golden("lnlike")
+    v, _ = run_stars(eng(15), 257, g["L15_K257_ld_stars"], u=(0.4, 0.2),
+                     baseline_var=1e-4, baseline_mean=1e-3)
+    assert np.max(np.abs(v / g["L15_K257_ld"] - 1)) < TOL
+
+
+def test_cfg5_ydeg20_temporal(eng):
+    g = golden("lnlike")
+    v, _ = run_stars(eng(20), 300, g["L20_K300_mat32_stars"], tspan=30.0, u=(0.4, 0.2),
+                     tau=3.0, temporal="matern32")
+    assert np.max(np.abs(v / g["L20_K300_mat32"] - 1)) < TOL
+    v, _ = run_stars(eng(20), 3000, g["cfg5_L20_K3000_stars"], tspan=30.0, u=(0.4, 0.2),
+                     tau=3.0, temporal="matern32")
+    assert np.max(np.abs(v / g["cfg5_L20_K3000"] - 1)) < TOL
+
+
+def test_multi_lightcurve_and_vector_variance(eng):
+    from starry_process_amd.engine import make_stars
+
+    g = golden("lnlike")
+    e = eng(15)
+    sts = [synthetic_star(s, 200) for s in range(5)]
+    F = np.array([st["flux"] for st in sts])[None, :, :]          # S=1, M=5
+    stars = make_stars(1, period=1.3, data_var=1e-6)
+    rta1 = e.f64(e.rTA1L([0.0, 0.0]))
+    tab, mv = e.kernel_table(rta1, 300)
+    out, _ = e.lnlike_ensemble(e.f64(sts[0]["t"][None, :]), e.f64(F), e.stars_to_device(stars),
+                               tab=tab, meanvar=mv)
+    assert abs(out.cpu().numpy()[0] / float(g["L15_K200_batchM5"]) - 1) < TOL
+    # per-cadence data variance
+    dc = g["L15_K200_vecvar_dc"]
+    stars = make_stars(1, period=sts[1]["p"])
+    out, _ = e.lnlike_ensemble(e.f64(sts[1]["t"][None, :]), e.f64(sts[1]["flux"][None, None, :]),
+                               e.stars_to_device(stars), diag=e.f64(dc[None, :]),
+                               tab=tab, meanvar=mv)
+    assert abs(out.cpu().numpy()[0] / float(g["L15_K200_vecvar"]) - 1) < TOL
+
+
+def test_failure_semantics(eng):
+    """non-PD -> -inf (math.py:82-91, sp.py:1186-1188); z > zmax -> -inf."""
+    from starry_process_amd.engine import get_engine, make_stars
+
+    g = golden("lnlike")
+    e = eng(5)
+    st = synthetic_star(0, 100)
+    stars = make_stars(2, period=1.0, data_var=[-1.0, 1e-6])
+    rta1 = e.f64(e.rTA1L([0.0, 0.0]))
+    tab, mv = e.kernel_table(rta1, 300)
+    t = np.stack([st["t"], st["t"]])
+    f = np.stack([st["flux"], st["flux"]])[:, None, :]
+    out, status = e.lnlike_ensemble(e.f64(t), e.f64(f), e.stars_to_device(stars), tab=tab, meanvar=mv)
+    out, status = out.cpu().numpy(), status.cpu().numpy()
+    assert out[0] == -np.inf and (status[0] & 1)
+    assert np.isfinite(out[1]) and status[1] == 0
+    # zmax guard
+    e15 = get_engine(15, 2)
+    e15.set_moments(g["zmax_guard_mean_ylm"], g["zmax_guard_cov_ylm"])
+    tab, mv = e15.kernel_table(e15.f64(e15.rTA1L([0.0, 0.0])), 300)
+    stars = make_stars(1, period=1.0, data_var=1e-6)
+    out, status = e15.lnlike_ensemble(e15.f64(st["t"][None, :]), e15.f64(st["flux"][None, None, :]),
+                                      e15.stars_to_device(stars), tab=tab, meanvar=mv)
+    assert out.cpu().numpy()[0] == -np.inf and (status.cpu().numpy()[0] & 2)
+    mom = golden("moments_L15")
+    e15.set_moments(mom["default_mean_ylm"], mom["default_cov_ylm"])
+
+
+def test_matches_oracle_on_random_hyper(eng):
+    """HIP vs oracle on inputs that are not in the golden files."""
+    mom = golden("moments_L15")
+    e = eng(15)
+    e.set_moments(mom["hilat_mean_ylm"], mom["hilat_cov_ylm"])
+    try:
+        v, _ = run_stars(e, 150, range(20, 26), u=(0.3, 0.1))
+        op = orc.OracleProcess(mom["hilat_mean_ylm"], mom["hilat_cov_ylm"], ydeg=15)
+        ref = []
+        for s in range(20, 26):
+            st = synthetic_star(s, 150)
+            ref.append(op.log_likelihood(st["t"], st["flux"], st["data_cov"], p=st["p"], u=[0.3, 0.1]))
+        assert np.max(np.abs(v / np.array(ref) - 1)) < TOL
+    finally:
+        e.set_moments(mom["default_mean_ylm"], mom["default_cov_ylm"])
