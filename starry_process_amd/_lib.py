@@ -108,6 +108,14 @@ def lib():
                 "g.build()'` or `make -C starry_process_amd/csrc` (hipcc, gfx950). "
                 "There is no CPU fallback." % LIB_PATH
             )
+        # PyTorch bundles its own HIP runtime (same soname, libamdhip64.so.7).
+        # It must be the first one loaded so that this library binds to the
+        # runtime that owns the tensors' device memory and streams; loading
+        # /opt/rocm's copy first would put two runtimes in one process.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(L, name)  # AttributeError if a declared symbol is missing
