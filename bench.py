@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""
+bench.py -- log_likelihood evaluations per second on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2], the one-GPU share of configs[3]):
+  ydeg = 15, K = 1000 cadences, 64 independent stars per GPU, marginalised over
+  inclination, normalised, covpts = 300, fp64.  Weak scaling: rank r owns stars
+  64 r .. 64 r + 63, so 8 GPUs evaluate the 512-star calibrate ensemble.
+
+One "step" = one hyperparameter sample of an MCMC / nested-sampling loop:
+  polar-frame moments of (mu_y, Sigma_y)   (sp_set_ylm_moments_dev)
+  -> inclination-marginal kernel table      (sp_kernel_table)
+  -> covariance assembly + Cholesky + solve + reduction for every star
+                                            (sp_lnlike_ensemble)
+  -> N > 1: RCCL all-gather of the per-star log-likelihoods (torch.distributed).
+All inputs are resident in HBM when the timed region starts.  (mu_y, Sigma_y) come
+from tests/golden (the upstream integrals are outside the hot path).
+
+Prints ONE JSON line on rank 0 (see DESIGN.md section 6 for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+YDEG, UDEG, K, STARS_PER_GPU, COVPTS = 15, 2, 1000, 64, 300
+FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix = vector peak (AMD CDNA4 datasheet)
+
+
+def cpu_baseline(mu, Sig, nstars):
+    """The oracle (a NumPy/SciPy/C port of the reference's CPU path, LAPACK potrf
+    and trtrs exactly like reference math.py:75-100) timed on the host cores."""
+    from oracle import sp_oracle as orc
+    from starry_process_amd.synthetic import synthetic_star
+
+    try:
+        from threadpoolctl import threadpool_info
+
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    op = orc.OracleProcess(mu, Sig, ydeg=YDEG, udeg=UDEG)
+    st = synthetic_star(0, K)
+    op.log_likelihood(st["t"], st["flux"], st["data_cov"], p=st["p"])  # warm the constants
+    t0 = time.perf_counter()
+    vals = []
+    for s in range(nstars):
+        st = synthetic_star(s, K)
+        vals.append(op.log_likelihood(st["t"], st["flux"], st["data_cov"], p=st["p"]))
+    dt = time.perf_counter() - t0
+    return dict(value=nstars / dt, unit="evals/s", cores=int(cores), kind="port",
+                sample="%d stars (ydeg=15, K=1000, marginal, normalized), sequential, "
+                       "oracle.OracleProcess.log_likelihood with SciPy/LAPACK" % nstars), np.array(vals)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cpu-stars", type=int, default=24)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from starry_process_amd.engine import get_engine, make_stars
+    from starry_process_amd.synthetic import synthetic_star
+
+    mom = np.load(os.path.join(ROOT, "tests", "golden", "moments_L15.npz"))
+    mu, Sig = mom["default_mean_ylm"], mom["default_cov_ylm"]
+
+    e = get_engine(YDEG, UDEG, local_rank)
+    S = STARS_PER_GPU
+    first = rank * S
+    sts = [synthetic_star(s, K) for s in range(first, first + S)]
+    t_d = e.f64(np.array([s["t"] for s in sts]))
+    f_d = e.f64(np.array([s["flux"] for s in sts])[:, None, :])
+    stars_d = e.stars_to_device(make_stars(S, period=[s["p"] for s in sts], data_var=1e-6))
+    mu_d, Sig_d = e.f64(mu), e.f64(Sig)
+    rta1_d = e.f64(e.rTA1L([0.0, 0.0]))          # one flux operator: u = [0, 0]
+    ws = e.workspace(S, K, 1)
+    out = e.empty(S)
+    status = torch.zeros(S, dtype=torch.int32, device=e.device)
+    gathered = e.empty(world * S) if world > 1 else None
+
+    def step():
+        e.set_moments_dev(mu_d, Sig_d)
+        tab, mv = e.kernel_table(rta1_d, COVPTS)
+        e.lnlike_ensemble(t_d, f_d, stars_d, covpts=COVPTS, tab=tab, meanvar=mv,
+                          normalized=True, out=out, status=status, workspace=ws)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, out)
+            return gathered.sum()
+        return out.sum()
+
+    e.set_moments(mu, Sig)  # first call allocates / uploads the lag grid
+    for _ in range(args.warmup):
+        step()
+    nsyrk = (K + 63) // 64
+    e.profile_begin(args.steps * nsyrk)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        total = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    launches, kern_ms, kern_flops = e.profile_end()
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=e.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    lnl = out.cpu().numpy()
+    ok = bool(np.all(np.isfinite(lnl))) and not bool(status.cpu().numpy().any())
+
+    if rank == 0:
+        evals = world * S * args.steps
+        achieved = (kern_flops / (kern_ms * 1e-3)) / 1e12 if kern_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("gemm_nt_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "log_likelihood evals/sec (ydeg=15, K=1000)",
+            "value": evals / elapsed,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "cfg3: ydeg=15, K=1000, 64 stars per GPU batched, marginalize_over_inclination, "
+                            "normalized, covpts=300 (cfg4 = the same at 8 GPUs: 512 stars, RCCL all-gather)",
+                "stars_per_gpu": S, "ydeg": YDEG, "K": K, "parallelism": "stars sharded %d-way" % world,
+            },
+            "parity_ok": ok,
+            "roofline": {
+                "kernel": "gemm_nt_kernel (Cholesky trailing update, v_mfma_f64_16x16x4_f64)",
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": FP64_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / FP64_PEAK_TFLOPS,
+                "traffic": traffic,
+                "launches": launches,
+                "avg_launch_ms": kern_ms / max(launches, 1),
+                "algorithmic_flops_per_launch": kern_flops / max(launches, 1),
+            },
+        }
+        if not args.no_cpu:
+            base, ref_vals = cpu_baseline(mu, Sig, args.cpu_stars)
+            line["cpu_baseline"] = base
+            n = min(len(ref_vals), S)
+            line["max_rel_err_vs_oracle"] = float(np.max(np.abs(lnl[:n] / ref_vals[:n] - 1)))
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -137,6 +137,10 @@ int sp_set_marginal_constants(sp_handle *h, const double *wnp_packed_host,
  * in the handle until the next call.  Synchronous. */
 int sp_set_ylm_moments(sp_handle *h, const double *mean_ylm_host,
                        const double *cov_ylm_host);
+/* Same, with mean_ylm / cov_ylm already resident in HBM; asynchronous on
+ * `stream` (what an MCMC loop with a device-side upstream would call). */
+int sp_set_ylm_moments_dev(sp_handle *h, const double *mean_ylm_dev,
+                           const double *cov_ylm_dev, void *stream);
 /* copies of the resident moments back to the host (any pointer may be NULL) */
 int sp_get_polar_moments(sp_handle *h, double *ez_host, double *Ez_host);
 
@@ -245,6 +249,15 @@ int sp_cholesky_lnlike_batched(sp_handle *h, int S, int K, int M,
                                const double *cov_dev, const double *resid_dev,
                                void *workspace_dev, double *lnlike_dev,
                                uint32_t *status_dev, void *stream);
+
+/* ---- measurement hooks (bench.py) ------------------------------------------ */
+/* Between begin and end every launch of the trailing-update kernel (the
+ * dominant kernel of the factorisation) is bracketed by HIP events on the
+ * stream it is launched on.  end() waits for them and returns the number of
+ * launches, their summed duration and their summed ALGORITHMIC flops
+ * (n (n + 1) / 2 x 64 multiply-adds x 2 per star and launch).                */
+int sp_profile_begin(sp_handle *h, int max_launches);
+int sp_profile_end(sp_handle *h, long *launches, double *total_ms, double *flops);
 
 #ifdef __cplusplus
 }

@@ -75,7 +75,10 @@ PROTOTYPES = {
     "sp_alpha_beta": (_I, [_D, _I, c_double_p, c_double_p, c_double_p, c_double_p]),
     "sp_set_marginal_constants": (_I, [_V, _V, _V]),
     "sp_set_ylm_moments": (_I, [_V, _V, _V]),
+    "sp_set_ylm_moments_dev": (_I, [_V, _V, _V, _V]),
     "sp_get_polar_moments": (_I, [_V, _V, _V]),
+    "sp_profile_begin": (_I, [_V, _I]),
+    "sp_profile_end": (_I, [_V, ctypes.POINTER(ctypes.c_long), c_double_p, c_double_p]),
     "sp_kernel_table": (_I, [_V, _V, _I, _I, _V, _V, _V, _V]),
     "sp_cov_marginal_batched": (
         _I, [_V, _I, _I, _V, _V, _I, _V, _V, _I, _I, _I, _V, _L, _L, _V, _V]),

@@ -31,8 +31,8 @@ int sp_launch_assemble(int S, int K, int M, int Kp, int system,
                        int normalized, const double *qv, const void *coef,
                        const double *diag, int add_noise, const double *flux,
                        double *out, long ldo, long strideo, hipStream_t st);
-int sp_launch_cholesky_systems(double *sys, int S, int K, int Kp, int32_t *info,
-                               hipStream_t st);
+int sp_launch_cholesky_systems(sp_handle *h, double *sys, int S, int K, int Kp,
+                               int32_t *info, hipStream_t st);
 int sp_launch_lnlike_reduce(const double *sys, int S, int K, int M, int Kp,
                             const int32_t *info, double *lnlike, uint32_t *status,
                             hipStream_t st);
@@ -318,6 +318,10 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
   h->d_mean_ylm = h->d_cov_ylm = h->d_ez = h->d_Ez = h->d_tmpNN = nullptr;
   h->d_scratch = nullptr;
   h->scratch_bytes = 0;
+  h->prof_on = false;
+  h->prof_used = 0;
+  h->prof_flops = 0.0;
+  h->prof_launches = 0;
   const int N = h->N;
   h->l_of.resize(N);
   h->m_of.resize(N);
@@ -376,6 +380,7 @@ void sp_destroy(sp_handle *h) {
   void *ptrs[] = {h->d_l_of, h->d_m_of,   h->d_mirror, h->d_blk,   h->d_Rx90,
                   h->d_wnp,  h->d_Wnp,    h->d_mean_ylm, h->d_cov_ylm, h->d_ez,
                   h->d_Ez,   h->d_tmpNN,  h->d_scratch, h->d_xp};
+  for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   delete h;
@@ -466,6 +471,63 @@ int sp_set_ylm_moments(sp_handle *h, const double *mean_ylm, const double *cov_y
   return SP_OK;
 }
 
+int sp_set_ylm_moments_dev(sp_handle *h, const double *mean_ylm_dev,
+                           const double *cov_ylm_dev, void *stream) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || !mean_ylm_dev || !cov_ylm_dev) return SP_ERR_INVALID;
+  const int N = h->N;
+  hipStream_t st = (hipStream_t)stream;
+  SP_HIP(hipMemcpyAsync(h->d_mean_ylm, mean_ylm_dev, sizeof(double) * N,
+                        hipMemcpyDeviceToDevice, st));
+  SP_HIP(hipMemcpyAsync(h->d_cov_ylm, cov_ylm_dev, sizeof(double) * N * N,
+                        hipMemcpyDeviceToDevice, st));
+  int rc = sp_launch_dotRx(h, h->d_mean_ylm, 0, N, 1, 1, h->d_Rx90, 0, h->d_ez, 1, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(second_moment_kernel, dim3((N * N + 255) / 256), dim3(256), 0,
+                     st, N, h->d_mean_ylm, h->d_cov_ylm, h->d_tmpNN);
+  SP_LAUNCH_CHECK();
+  rc = sp_launch_dotRx(h, h->d_tmpNN, 0, N, 1, N, h->d_Rx90, 0, h->d_Ez, 1, st);
+  if (rc) return rc;
+  rc = sp_launch_dotRx(h, h->d_Ez, 0, 1, N, N, h->d_Rx90, 0, h->d_tmpNN, 1, st);
+  if (rc) return rc;
+  SP_HIP(hipMemcpyAsync(h->d_Ez, h->d_tmpNN, sizeof(double) * N * N,
+                        hipMemcpyDeviceToDevice, st));
+  h->have_moments = true;
+  return SP_OK;
+}
+
+int sp_profile_begin(sp_handle *h, int max_launches) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || max_launches < 0) return SP_ERR_INVALID;
+  while (h->prof_ev.size() < 2 * (size_t)max_launches) {
+    hipEvent_t e;
+    SP_HIP(hipEventCreate(&e));
+    h->prof_ev.push_back(e);
+  }
+  h->prof_used = 0;
+  h->prof_flops = 0.0;
+  h->prof_launches = 0;
+  h->prof_on = true;
+  return SP_OK;
+}
+
+int sp_profile_end(sp_handle *h, long *launches, double *total_ms, double *flops) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h) return SP_ERR_INVALID;
+  h->prof_on = false;
+  double ms = 0.0;
+  for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
+    SP_HIP(hipEventSynchronize(h->prof_ev[i + 1]));
+    float dt = 0.f;
+    SP_HIP(hipEventElapsedTime(&dt, h->prof_ev[i], h->prof_ev[i + 1]));
+    ms += dt;
+  }
+  if (launches) *launches = h->prof_launches;
+  if (total_ms) *total_ms = ms;
+  if (flops) *flops = h->prof_flops;
+  return SP_OK;
+}
+
 int sp_get_polar_moments(sp_handle *h, double *ez, double *Ez) {
   if (h && h->device < 0) return SP_ERR_NO_DEVICE;
   if (!h) return SP_ERR_INVALID;
@@ -487,14 +549,20 @@ int sp_kernel_table(sp_handle *h, const double *rta1_dev, int ntab, int covpts,
   if (!h->have_marginal || !h->have_moments) return SP_ERR_STATE;
   if (ntab == 0) return SP_OK;
   const int np = covpts + 4;
-  if (h->xp_covpts != covpts) {
+  const bool same = h->xp_covpts == covpts && (int)h->xp_host.size() == np &&
+                    memcmp(h->xp_host.data(), xp_host, sizeof(double) * np) == 0;
+  if (!same) {
+    // new lag grid: (re)allocate and upload once; later calls with the same
+    // grid are fully asynchronous
     SP_HIP(hipDeviceSynchronize());
     if (h->d_xp) SP_HIP(hipFree(h->d_xp));
     h->d_xp = nullptr;
+    h->xp_covpts = -1;
     SP_HIP(hipMalloc((void **)&h->d_xp, sizeof(double) * np));
+    SP_HIP(hipMemcpy(h->d_xp, xp_host, sizeof(double) * np, hipMemcpyHostToDevice));
+    h->xp_host.assign(xp_host, xp_host + np);
     h->xp_covpts = covpts;
   }
-  SP_HIP(hipMemcpy(h->d_xp, xp_host, sizeof(double) * np, hipMemcpyHostToDevice));
   return sp_launch_kernel_table(h, rta1_dev, ntab, covpts, h->d_xp, tab_dev,
                                 meanvar_dev, (hipStream_t)stream);
 }
@@ -620,7 +688,7 @@ int sp_cho_factor(sp_handle *h, double *A_dev, int K, long lda, long strideA,
   SP_HIP(hipMemsetAsync(info, 0, sizeof(int32_t) * batch, st));
   if ((rc = sp_launch_pad_in(A_dev, K, lda, strideA, sys, Kp, 0, nullptr, batch, st)))
     return rc;
-  if ((rc = sp_launch_cholesky_systems(sys, batch, K, Kp, info, st))) return rc;
+  if ((rc = sp_launch_cholesky_systems(h, sys, batch, K, Kp, info, st))) return rc;
   if ((rc = sp_launch_pad_out(sys, Kp, A_dev, K, lda, strideA, info, batch, st)))
     return rc;
   if (info_dev)
@@ -699,7 +767,7 @@ int sp_lnlike_ensemble(sp_handle *h, int S, int K, int M, const double *t_dev,
                                coef, diag_dev, 1, flux_dev, sys, L.Kp,
                                (long)L.Kp * L.Kp, st)))
     return rc;
-  if ((rc = sp_launch_cholesky_systems(sys, S, K, L.Kp, info, st))) return rc;
+  if ((rc = sp_launch_cholesky_systems(h, sys, S, K, L.Kp, info, st))) return rc;
   if ((rc = sp_launch_lnlike_reduce(sys, S, K, M, L.Kp, info, lnlike_dev, status, st)))
     return rc;
   if (status_dev)
@@ -727,7 +795,7 @@ int sp_cholesky_lnlike_batched(sp_handle *h, int S, int K, int M,
   SP_HIP(hipMemsetAsync(status, 0, sizeof(uint32_t) * S, st));
   if ((rc = sp_launch_pad_in(cov_dev, K, K, (long)K * K, sys, L.Kp, M, resid_dev, S, st)))
     return rc;
-  if ((rc = sp_launch_cholesky_systems(sys, S, K, L.Kp, info, st))) return rc;
+  if ((rc = sp_launch_cholesky_systems(h, sys, S, K, L.Kp, info, st))) return rc;
   if ((rc = sp_launch_lnlike_reduce(sys, S, K, M, L.Kp, info, lnlike_dev, status, st)))
     return rc;
   if (status_dev)

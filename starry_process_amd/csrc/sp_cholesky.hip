@@ -266,8 +266,8 @@ __global__ __launch_bounds__(256) void cho_solve_kernel(
 
 // In-place factorisation of S padded systems (Kp x Kp, ld = Kp): the leading
 // K x K part is factored, rows K..Kp-1 only receive the triangular solve.
-int sp_launch_cholesky_systems(double *sys, int S, int K, int Kp, int32_t *info,
-                               hipStream_t st) {
+int sp_launch_cholesky_systems(sp_handle *h, double *sys, int S, int K, int Kp,
+                               int32_t *info, hipStream_t st) {
   const long ld = Kp, stride = (long)Kp * Kp;
   const int nsteps = (K + SP_NB - 1) / SP_NB;
   for (int j = 0; j < nsteps; ++j) {
@@ -284,9 +284,19 @@ int sp_launch_cholesky_systems(double *sys, int S, int K, int Kp, int32_t *info,
       const int n = Kp - c1;
       double *X = sys + (size_t)c1 * ld + c0;
       double *T = sys + (size_t)c1 * ld + c1;
+      const bool timed = h && h->prof_on && h->prof_used + 2 <= h->prof_ev.size();
+      if (timed) SP_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
       int rc = sp_launch_gemm_nt(X, ld, stride, X, ld, stride, T, ld, stride, n, n,
                                  SP_NB, -1.0, 1, 1, S, st);
       if (rc != SP_OK) return rc;
+      if (timed) {
+        SP_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
+        h->prof_used += 2;
+        // algorithmic work of a symmetric rank-64 update of an n x n block:
+        // n (n + 1) / 2 entries x 64 multiply-adds
+        h->prof_flops += (double)S * (double)n * (n + 1) * SP_NB;
+        h->prof_launches += 1;
+      }
     }
   }
   return SP_OK;

@@ -33,12 +33,19 @@ struct sp_handle {
   bool have_marginal;
   double *d_xp;                 // lag grid of the last kernel table
   int xp_covpts;
+  std::vector<double> xp_host;  // its host copy (re-upload only on change)
   // device state: Ylm moments
   double *d_mean_ylm, *d_cov_ylm, *d_ez, *d_Ez, *d_tmpNN;
   bool have_moments;
   // small device scratch owned by the handle
   double *d_scratch;
   size_t scratch_bytes;
+  // optional per-launch timing of the trailing-update kernel (bench roofline)
+  bool prof_on;
+  std::vector<hipEvent_t> prof_ev;   // pairs (start, stop)
+  size_t prof_used;                  // events handed out so far
+  double prof_flops;                 // algorithmic flops of the timed launches
+  long prof_launches;
 };
 
 const char *sp_set_hip_error(hipError_t e, const char *what);

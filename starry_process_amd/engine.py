@@ -168,6 +168,21 @@ class Engine(object):
         assert mean_ylm.shape == (self.N,) and cov_ylm.shape == (self.N, self.N)
         check(self._L.sp_set_ylm_moments(self._h, hptr(mean_ylm), hptr(cov_ylm)))
 
+    def set_moments_dev(self, mean_ylm, cov_ylm):
+        """Same with the moments already on the device (asynchronous)."""
+        assert mean_ylm.is_cuda and cov_ylm.is_cuda
+        check(self._L.sp_set_ylm_moments_dev(self._h, self._p(mean_ylm), self._p(cov_ylm), self._stream()))
+
+    def profile_begin(self, max_launches):
+        check(self._L.sp_profile_begin(self._h, int(max_launches)))
+
+    def profile_end(self):
+        n = ctypes.c_long()
+        ms = ctypes.c_double()
+        fl = ctypes.c_double()
+        check(self._L.sp_profile_end(self._h, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)))
+        return n.value, ms.value, fl.value
+
     def polar_moments(self):
         ez = np.empty(self.N)
         Ez = np.empty((self.N, self.N))

@@ -1,0 +1,116 @@
+"""
+CPU-only checks of the product's host side: the C-ABI library loads and exports
+every symbol the header declares, the host-only entry points (integer tables,
+AlphaBeta, rTA1 / rTA1L through a host-only handle) agree with the golden
+vectors, and the Python host constants reproduce the reference's.
+No GPU compute is called here.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden
+from oracle import sp_oracle as orc
+from starry_process_amd import _lib, hostconst
+
+LS = [5, 15, 20]
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "starry_process_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(sp_[A-Za-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    L = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), "libsp_hip.so does not export %s" % name
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    assert L.sp_version() >= 100
+    assert L.sp_strerror(0) == b"ok"
+
+
+def test_no_device_is_an_error_not_a_fallback():
+    L = _lib.lib()
+    if L.sp_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    h = ctypes.c_void_p()
+    assert L.sp_create(15, 2, 0, ctypes.byref(h)) == -3  # SP_ERR_NO_DEVICE
+    # host-only handle: host entry points work, device entry points refuse
+    _lib.check(L.sp_create(5, 2, -1, ctypes.byref(h)))
+    x = np.zeros(8)
+    assert L.sp_tensordotRz(h, _lib.hptr(x), _lib.hptr(x), 1, _lib.hptr(x), None) == -3
+    assert L.sp_set_ylm_moments(h, _lib.hptr(x), _lib.hptr(x)) == -3
+    L.sp_destroy(h)
+    with pytest.raises(_lib.SPError):
+        from starry_process_amd.engine import Engine
+
+        Engine(5, 2, 0)
+
+
+@pytest.mark.parametrize("L", LS)
+def test_integer_tables_bit_exact(L):
+    g = golden("ops_L%d" % L)
+    tab = _lib.index_tables(L)
+    ref = orc.index_tables(L)
+    for k in ("l_of", "m_of", "mirror", "m0", "blk"):
+        assert tab[k].dtype == np.int32 and np.array_equal(tab[k], ref[k])
+    assert np.array_equal(tab["m_of"], g["tab_m_of"])
+    assert np.array_equal(tab["mirror"], g["tab_mirror"])
+    assert tab["blk"][-1] == int(g["nwig"])
+    it, ir = _lib.wigner_int_tables(L), orc.wigner_int_tables(L)
+    for k in it:
+        assert np.array_equal(it[k], ir[k])
+
+
+def test_alpha_beta_bit_exact():
+    g = golden("norm")
+    for z, v20, v10 in zip(g["z"], g["abN20"], g["abN10"]):
+        assert np.array_equal(np.array(_lib.alpha_beta(z, 20)), v20)
+        assert np.array_equal(np.array(_lib.alpha_beta(z, 10)), v10)
+
+
+@pytest.mark.parametrize("L", LS)
+def test_flux_operator_host(L):
+    g = golden("ops_L%d" % L)
+    lib = _lib.lib()
+    h = ctypes.c_void_p()
+    _lib.check(lib.sp_create(L, 2, -1, ctypes.byref(h)))
+    N = (L + 1) ** 2
+    out = np.empty(N)
+    _lib.check(lib.sp_rTA1(h, _lib.hptr(out)))
+    assert np.array_equal(out, g["rTA1"])
+    us = np.ascontiguousarray(g["rTA1L_u"])
+    o2 = np.empty((len(us), N))
+    _lib.check(lib.sp_rTA1L(h, _lib.hptr(us), len(us), _lib.hptr(o2)))
+    assert np.max(np.abs(o2 - g["rTA1L"])) < 1e-13
+    lib.sp_destroy(h)
+    # udeg = 0 handle: rTA1L degenerates to rTA1 (flux.py:211-221)
+    _lib.check(lib.sp_create(L, 0, -1, ctypes.byref(h)))
+    o3 = np.empty((1, N))
+    _lib.check(lib.sp_rTA1L(h, None, 1, _lib.hptr(o3)))
+    assert np.array_equal(o3[0], g["rTA1"])
+    lib.sp_destroy(h)
+
+
+@pytest.mark.parametrize("L", LS)
+def test_marginal_constants_match_reference(L):
+    g = golden("consts_L%d" % L)
+    assert np.array_equal(hostconst.G_matrix(L), g["G"])
+    wnp, Wnp = hostconst.marginal_constants(L)
+    gw = np.concatenate([g["wnp_%d" % l].reshape(-1) for l in range(L + 1)])
+    assert np.max(np.abs(wnp - gw)) <= 1e-15 * np.max(np.abs(gw))
+    assert np.max(np.abs(Wnp - g["Wnp"])) <= 1e-14 * np.max(np.abs(g["Wnp"]))
+    dx, xp = hostconst.lag_grid(300)
+    mom = golden("moments_L%d" % L)
+    assert np.array_equal(xp, mom["default_u0_xp"]) and dx == float(mom["default_u0_dx"])
+
+
+def test_bad_arguments_are_rejected():
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    assert L.sp_create(0, 2, -1, ctypes.byref(h)) == -1
+    assert L.sp_create(15, 9, -1, ctypes.byref(h)) == -1
+    assert L.sp_index_tables(-1, None, None, None, None, None) == -1
