@@ -32,7 +32,7 @@ int sp_launch_assemble(int S, int K, int M, int Kp, int system,
                        const double *diag, int add_noise, const double *flux,
                        double *out, long ldo, long strideo, hipStream_t st);
 int sp_launch_cholesky_systems(sp_handle *h, double *sys, int S, int K, int Kp,
-                               int32_t *info, hipStream_t st);
+                               int32_t *info, double *invL, hipStream_t st);
 int sp_launch_lnlike_reduce(const double *sys, int S, int K, int M, int Kp,
                             const int32_t *info, double *lnlike, uint32_t *status,
                             hipStream_t st);
@@ -155,8 +155,8 @@ inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
   int S, K, M, Kp, N, NWIG;
-  size_t theta, rowsum, qv, coef, info, status, condmean, cs, vrow, Rinc, A, B1,
-      raw, sys, total;
+  size_t theta, rowsum, qv, coef, info, status, condmean, cs, vrow, Rinc, invL, A,
+      B1, raw, sys, total;
 };
 
 Layout make_layout(const sp_handle *h, int S, int K, int M, bool with_sys) {
@@ -184,6 +184,7 @@ Layout make_layout(const sp_handle *h, int S, int K, int M, bool with_sys) {
   L.cs = take(d * S * 2);
   L.vrow = take(d * S * L.N);
   L.Rinc = take(d * S * L.NWIG);
+  L.invL = take(d * (size_t)S * SP_NB * SP_NB);
   L.A = take(d * (size_t)S * K * L.N);
   L.B1 = take(d * (size_t)S * K * L.N);
   L.raw = take(d * (size_t)S * K * K);
@@ -680,15 +681,17 @@ int sp_cho_factor(sp_handle *h, double *A_dev, int K, long lda, long strideA,
   hipStream_t st = (hipStream_t)stream;
   const int Kp = sp_roundup(K, SP_NB);
   const size_t sysb = align_up(sizeof(double) * (size_t)batch * Kp * Kp);
+  const size_t invb = align_up(sizeof(double) * (size_t)batch * SP_NB * SP_NB);
   void *ws = nullptr;
-  int rc = ensure_big(h, sysb + align_up(sizeof(int32_t) * batch), &ws);
+  int rc = ensure_big(h, sysb + invb + align_up(sizeof(int32_t) * batch), &ws);
   if (rc) return rc;
   double *sys = at<double>(ws, 0);
-  int32_t *info = at<int32_t>(ws, sysb);
+  double *invL = at<double>(ws, sysb);
+  int32_t *info = at<int32_t>(ws, sysb + invb);
   SP_HIP(hipMemsetAsync(info, 0, sizeof(int32_t) * batch, st));
   if ((rc = sp_launch_pad_in(A_dev, K, lda, strideA, sys, Kp, 0, nullptr, batch, st)))
     return rc;
-  if ((rc = sp_launch_cholesky_systems(h, sys, batch, K, Kp, info, st))) return rc;
+  if ((rc = sp_launch_cholesky_systems(h, sys, batch, K, Kp, info, invL, st))) return rc;
   if ((rc = sp_launch_pad_out(sys, Kp, A_dev, K, lda, strideA, info, batch, st)))
     return rc;
   if (info_dev)
@@ -767,7 +770,7 @@ int sp_lnlike_ensemble(sp_handle *h, int S, int K, int M, const double *t_dev,
                                coef, diag_dev, 1, flux_dev, sys, L.Kp,
                                (long)L.Kp * L.Kp, st)))
     return rc;
-  if ((rc = sp_launch_cholesky_systems(h, sys, S, K, L.Kp, info, st))) return rc;
+  if ((rc = sp_launch_cholesky_systems(h, sys, S, K, L.Kp, info, at<double>(ws, L.invL), st))) return rc;
   if ((rc = sp_launch_lnlike_reduce(sys, S, K, M, L.Kp, info, lnlike_dev, status, st)))
     return rc;
   if (status_dev)
@@ -787,6 +790,7 @@ int sp_cholesky_lnlike_batched(sp_handle *h, int S, int K, int M,
   if (S == 0) return SP_OK;
   hipStream_t st = (hipStream_t)stream;
   Layout L = make_layout(h, S, K, M, true);
+  void *ws = workspace_dev;
   double *sys = at<double>(workspace_dev, L.sys);
   int32_t *info = at<int32_t>(workspace_dev, L.info);
   uint32_t *status = at<uint32_t>(workspace_dev, L.status);
@@ -795,7 +799,7 @@ int sp_cholesky_lnlike_batched(sp_handle *h, int S, int K, int M,
   SP_HIP(hipMemsetAsync(status, 0, sizeof(uint32_t) * S, st));
   if ((rc = sp_launch_pad_in(cov_dev, K, K, (long)K * K, sys, L.Kp, M, resid_dev, S, st)))
     return rc;
-  if ((rc = sp_launch_cholesky_systems(h, sys, S, K, L.Kp, info, st))) return rc;
+  if ((rc = sp_launch_cholesky_systems(h, sys, S, K, L.Kp, info, at<double>(ws, L.invL), st))) return rc;
   if ((rc = sp_launch_lnlike_reduce(sys, S, K, M, L.Kp, info, lnlike_dev, status, st)))
     return rc;
   if (status_dev)

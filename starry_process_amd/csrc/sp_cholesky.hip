@@ -18,52 +18,70 @@
 
 namespace {
 
+typedef double d4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ double read_lane(double v, int l) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
   return __hiloint2double(hi, lo);
 }
 
-// Factor the leading nact columns of the 64-row block held in LDS (rows beyond
-// nact only receive the triangular solve).  Executed by ONE wavefront; lane r
-// keeps row r in registers and the right-looking rank-1 updates fetch L[k][c]
-// from lane k with v_readlane -- no LDS traffic and no barriers inside the
-// 64-column sweep.
-__device__ __forceinline__ void block_potrf_wave(double *sD, int nact, int lane,
-                                                 int *bad) {
-  double x[64];
-#pragma unroll
-  for (int c = 0; c < 64; ++c) x[c] = sD[lane * DLD + c];
-  int notpd = 0;
-#pragma unroll
-  for (int c = 0; c < 64; ++c) {
-    if (c < nact) {
-      const double piv = read_lane(x[c], c);
-      if (!(piv > 0.0)) notpd = 1;
-      const double d = sqrt(piv);
-      x[c] = (lane == c) ? d : x[c] / d;
-#pragma unroll
-      for (int k = c + 1; k < 64; ++k) x[k] -= x[c] * read_lane(x[c], k);
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < 64; ++c)
-    if (c <= lane) sD[lane * DLD + c] = x[c];
-  if (notpd) *bad = 1;
+// 1/sqrt(p) to ~1 ulp: hardware seed (v_rsq_f64) + two Newton steps
+__device__ __forceinline__ double rsqrt_nr(double p) {
+  double r = __builtin_amdgcn_rsq(p);
+  double e = fma(-p * r, r, 1.0);
+  r = fma(0.5 * r, e, r);
+  e = fma(-p * r, r, 1.0);
+  r = fma(0.5 * r, e, r);
+  return r;
 }
 
-// grid (nchunks, S).  Every workgroup factors the diagonal block redundantly
-// (cheap, and it avoids a grid-wide dependency); chunk 0 writes it back.
-__global__ __launch_bounds__(256) void panel_kernel(double *__restrict__ sys,
-                                                    long ld, long stride, int Kp,
-                                                    int c0, int nact,
-                                                    int32_t *__restrict__ info) {
-  __shared__ double sD[64 * DLD];
-  __shared__ int s_bad;
-  double *Mx = sys + (size_t)blockIdx.y * stride;
-  const int tid = threadIdx.x, lane = tid & 63;
-  if (tid == 0) s_bad = 0;
-  // stage the diagonal block (coalesced: 16 lanes x 4 doubles per row)
+// ---- diagonal-block kernel ----------------------------------------------------
+// One workgroup (4 wavefronts) per star factors the 64 x 64 diagonal block
+// A = L L^T and also forms L^-1, so that the panel below it becomes a plain
+// product X = P L^-T on the matrix cores (sp_gemm.hip).  The block is processed
+// as 4 x 4 sub-blocks of 16 x 16:
+//   leaf   : wavefront 0, lane = row, 16-column right-looking sweep with
+//            v_readlane broadcasts (no LDS, no barriers inside), followed by
+//            the 16 x 16 triangular inverse, lane = column;
+//   updates: v_mfma_f64_16x16x4_f64 on LDS-resident operands, sub-blocks
+//            spread over the four wavefronts.
+// LDS rows are padded to 66 doubles (132 dwords = 4 mod 64 banks): the MFMA
+// operand reads (16 rows x 2 k per 32-lane half) are conflict free.
+#define BLD 66
+
+// a-operand / NT b-operand fragment: M[row0 + (lane & 15)][col0 + 4 s + (lane >> 4)]
+__device__ __forceinline__ double frag_rowmajor(const double *M, int row0, int col0,
+                                                int s, int lane) {
+  return M[(row0 + (lane & 15)) * BLD + col0 + 4 * s + (lane >> 4)];
+}
+// NN b-operand fragment: M[row0 + 4 s + (lane >> 4)][col0 + (lane & 15)]
+__device__ __forceinline__ double frag_kmajor(const double *M, int row0, int col0,
+                                              int s, int lane) {
+  return M[(row0 + 4 * s + (lane >> 4)) * BLD + col0 + (lane & 15)];
+}
+// accumulator <-> LDS, C/D map of the fp64 MFMA: col = lane & 15, row = (lane >> 4) + 4 reg
+__device__ __forceinline__ d4 acc_load(const double *M, int row0, int col0, int lane) {
+  d4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = M[(row0 + (lane >> 4) + 4 * r) * BLD + col0 + (lane & 15)];
+  return v;
+}
+__device__ __forceinline__ void acc_store(double *M, int row0, int col0, int lane, d4 v) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) M[(row0 + (lane >> 4) + 4 * r) * BLD + col0 + (lane & 15)] = v[r];
+}
+
+__global__ __launch_bounds__(256) void diag_kernel(double *__restrict__ sys, long ld,
+                                                   long stride, int c0, int nact,
+                                                   double *__restrict__ invL_all,
+                                                   int32_t *__restrict__ info) {
+  __shared__ __attribute__((aligned(16))) double sA[64 * BLD];  // block, becomes L
+  __shared__ __attribute__((aligned(16))) double sI[64 * BLD];  // L^-1
+  double *Mx = sys + (size_t)blockIdx.x * stride;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // stage the block; outside the active nact x nact part use the identity so a
+  // partial last panel factors as diag(L_act, I)
   {
     const int cj = (tid & 15) * 4, ri = tid >> 4;
 #pragma unroll
@@ -71,43 +89,120 @@ __global__ __launch_bounds__(256) void panel_kernel(double *__restrict__ sys,
       const int r = ri + 16 * pass;
       const double *src = Mx + (size_t)(c0 + r) * ld + c0 + cj;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) sD[r * DLD + cj + e] = src[e];
+      for (int e = 0; e < 4; ++e) {
+        const int c = cj + e;
+        double v = (r < nact && c < nact) ? src[e] : (r == c ? 1.0 : 0.0);
+        if (c > r) v = 0.0;
+        sA[r * BLD + c] = v;
+        sI[r * BLD + c] = 0.0;
+      }
     }
   }
   __syncthreads();
-  if (tid < 64) block_potrf_wave(sD, nact, lane, &s_bad);
-  __syncthreads();
-  if (blockIdx.x == 0) {
-    if (tid == 0 && s_bad && info) info[blockIdx.y] = 1;
+  int notpd = 0;
+#pragma unroll 1
+  for (int kb = 0; kb < 4; ++kb) {
+    const int o = 16 * kb;
+    if (wave == 0) {
+      // leaf Cholesky, lane (< 16) = row of the 16 x 16 block
+      double x[16], rinv = 1.0;
+      const int row = lane & 15;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) x[c] = sA[(o + row) * BLD + o + c];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const double piv = read_lane(x[c], c);
+        if (!(piv > 0.0)) notpd = 1;
+        const double r = rsqrt_nr(piv);
+        if (row == c) rinv = r;
+        x[c] = (row == c) ? piv * r : x[c] * r;
+#pragma unroll
+        for (int k = c + 1; k < 16; ++k) x[k] -= x[c] * read_lane(x[c], k);
+      }
+      // leaf inverse, lane (< 16) = column j: solve L y = e_j
+      double y[16];
+      const int j = lane & 15;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        double sacc = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) sacc -= read_lane(x[k], i) * y[k];
+        y[i] = sacc * read_lane(rinv, i);
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          if (c <= row) sA[(o + row) * BLD + o + c] = x[c];
+          sI[(o + c) * BLD + o + j] = y[c];  // y[c] = (L^-1)[c][j], zero above the diagonal
+        }
+      }
+    }
+    __syncthreads();
+    // sub-diagonal blocks of this block column: L_ik = A_ik . (L_kk^-1)^T
+    if (wave > kb) {
+      const int ib = wave;
+      d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(frag_rowmajor(sA, 16 * ib, o, s, lane),
+                                                   frag_rowmajor(sI, o, o, s, lane), acc, 0, 0, 0);
+      acc_store(sA, 16 * ib, o, lane, acc);
+    }
+    __syncthreads();
+    // trailing sub-blocks: A_ij -= L_ik L_jk^T, kb < jb <= ib
+    {
+      int q = 0;
+      for (int ib = kb + 1; ib < 4; ++ib)
+        for (int jb = kb + 1; jb <= ib; ++jb, ++q) {
+          if ((q & 3) != wave) continue;
+          d4 acc = acc_load(sA, 16 * ib, 16 * jb, lane);
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-frag_rowmajor(sA, 16 * ib, o, s, lane),
+                                                       frag_rowmajor(sA, 16 * jb, o, s, lane), acc, 0, 0, 0);
+          acc_store(sA, 16 * ib, 16 * jb, lane, acc);
+        }
+    }
+    __syncthreads();
+  }
+  // off-diagonal blocks of L^-1: X_ij = -(L_ii^-1) sum_{k=j}^{i-1} L_ik X_kj,
+  // block column j on wavefront j, rows i in sequence
+#pragma unroll 1
+  for (int i = 1; i < 4; ++i) {
+    if (wave < i) {
+      const int j = wave;
+      d4 t = {0.0, 0.0, 0.0, 0.0};
+      for (int k = j; k < i; ++k)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          t = __builtin_amdgcn_mfma_f64_16x16x4f64(frag_rowmajor(sA, 16 * i, 16 * k, s, lane),
+                                                   frag_kmajor(sI, 16 * k, 16 * j, s, lane), t, 0, 0, 0);
+      // t[s] = T[4 s + (lane >> 4)][lane & 15] is exactly the k-major operand of step s
+      d4 xacc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        xacc = __builtin_amdgcn_mfma_f64_16x16x4f64(-frag_rowmajor(sI, 16 * i, 16 * i, s, lane),
+                                                    t[s], xacc, 0, 0, 0);
+      acc_store(sI, 16 * i, 16 * j, lane, xacc);
+    }
+    __syncthreads();
+  }
+  // write back L (active lower part) and the full L^-1 tile
+  {
+    if (tid == 0 && notpd && info) info[blockIdx.x] = 1;
+    double *inv = invL_all + (size_t)blockIdx.x * 4096;
     const int cj = (tid & 15) * 4, ri = tid >> 4;
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       const int r = ri + 16 * pass;
       double *dst = Mx + (size_t)(c0 + r) * ld + c0 + cj;
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (cj + e <= r && cj + e < nact) dst[e] = sD[r * DLD + cj + e];
-    }
-  }
-  // rows below the block: x L_d^T = p, one row per thread
-  const int row = c0 + 64 + blockIdx.x * 256 + tid;
-  if (row < Kp) {
-    double *p = Mx + (size_t)row * ld + c0;
-    double x[64];
-#pragma unroll
-    for (int c = 0; c < 64; ++c) x[c] = p[c];
-#pragma unroll
-    for (int c = 0; c < 64; ++c) {
-      if (c < nact) {
-        double v = x[c];
-#pragma unroll
-        for (int k = 0; k < c; ++k) v -= x[k] * sD[c * DLD + k];
-        x[c] = v / sD[c * DLD + c];
+      for (int e = 0; e < 4; ++e) {
+        const int c = cj + e;
+        if (c <= r && r < nact) dst[e] = sA[r * BLD + c];
+        inv[r * 64 + c] = sI[r * BLD + c];
       }
     }
-#pragma unroll
-    for (int c = 0; c < 64; ++c)
-      if (c < nact) p[c] = x[c];
   }
 }
 
@@ -267,18 +362,25 @@ __global__ __launch_bounds__(256) void cho_solve_kernel(
 // In-place factorisation of S padded systems (Kp x Kp, ld = Kp): the leading
 // K x K part is factored, rows K..Kp-1 only receive the triangular solve.
 int sp_launch_cholesky_systems(sp_handle *h, double *sys, int S, int K, int Kp,
-                               int32_t *info, hipStream_t st) {
+                               int32_t *info, double *invL, hipStream_t st) {
   const long ld = Kp, stride = (long)Kp * Kp;
   const int nsteps = (K + SP_NB - 1) / SP_NB;
   for (int j = 0; j < nsteps; ++j) {
     const int c0 = j * SP_NB;
     const int nact = K - c0 < SP_NB ? K - c0 : SP_NB;
-    const int below = Kp - (c0 + SP_NB);
-    int nchunks = (below + 255) / 256;
-    if (nchunks < 1) nchunks = 1;
-    hipLaunchKernelGGL(panel_kernel, dim3(nchunks, S), dim3(256), 0, st, sys, ld,
-                       stride, Kp, c0, nact, info);
+    // (1) diagonal block: L_d and L_d^-1
+    hipLaunchKernelGGL(diag_kernel, dim3(S), dim3(256), 0, st, sys, ld, stride, c0,
+                       nact, invL, info);
     SP_LAUNCH_CHECK();
+    // (2) rows below the active block: X = P L_d^-T, in place, on the matrix cores
+    const int r1 = c0 + nact;
+    if (r1 < Kp) {
+      double *P = sys + (size_t)r1 * ld + c0;
+      int rc = sp_launch_gemm_nt(P, ld, stride, invL, SP_NB, (long)SP_NB * SP_NB, P, ld,
+                                 stride, Kp - r1, SP_NB, SP_NB, 1.0, 0, 0, S, st);
+      if (rc != SP_OK) return rc;
+    }
+    // (3) trailing update C -= X X^T, lower-triangle tiles
     const int c1 = c0 + SP_NB;
     if (c1 < K) {
       const int n = Kp - c1;

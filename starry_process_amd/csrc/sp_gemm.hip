@@ -27,7 +27,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-__device__ __forceinline__ void stage_panel(const double *__restrict__ P,
+__device__ __forceinline__ void stage_panel(const double *P,
                                             long ld, int row0, int nrows,
                                             int k0, int Kd, double scale,
                                             bool vec_ok, double *__restrict__ s) {
@@ -54,9 +54,11 @@ __device__ __forceinline__ void stage_panel(const double *__restrict__ P,
   }
 }
 
+// (A and C may alias: the triangular solve X = P L^-T runs in place, each
+//  workgroup reads its whole A row-tile before it stores the same C tile.)
 __global__ __launch_bounds__(256) void gemm_nt_kernel(
-    const double *__restrict__ A, long lda, long strideA,
-    const double *__restrict__ B, long ldb, long strideB, double *__restrict__ C,
+    const double *A, long lda, long strideA,
+    const double *__restrict__ B, long ldb, long strideB, double *C,
     long ldc, long strideC, int Mrows, int Nrows, int Kd, double alpha,
     int beta, int lower_only, int batch, int ntm, int ntn, int ntiles) {
   __shared__ __attribute__((aligned(16))) double sA[GT * GLD];
