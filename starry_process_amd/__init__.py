@@ -1,2 +1,18 @@
 """MI355X-native log-likelihood hot path of starry_process."""
 __version__ = "0.1.0"
+
+from .defaults import defaults  # noqa: E402,F401
+from .temporal import ExpSquaredKernel, Matern32Kernel  # noqa: E402,F401
+
+
+def __getattr__(name):
+    # heavy modules (torch, the HIP library) load on first use
+    if name == "StarryProcess":
+        from .sp import StarryProcess
+
+        return StarryProcess
+    if name in ("ops", "flux", "sp", "engine", "ensemble", "upstream", "hostconst"):
+        import importlib
+
+        return importlib.import_module("." + name, __name__)
+    raise AttributeError(name)

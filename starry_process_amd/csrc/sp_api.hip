@@ -319,6 +319,8 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
   h->d_mean_ylm = h->d_cov_ylm = h->d_ez = h->d_Ez = h->d_tmpNN = nullptr;
   h->d_scratch = nullptr;
   h->scratch_bytes = 0;
+  h->d_tab_scratch = nullptr;
+  h->tab_scratch_bytes = 0;
   h->prof_on = false;
   h->prof_used = 0;
   h->prof_flops = 0.0;
@@ -380,7 +382,7 @@ void sp_destroy(sp_handle *h) {
   (void)hipDeviceSynchronize();
   void *ptrs[] = {h->d_l_of, h->d_m_of,   h->d_mirror, h->d_blk,   h->d_Rx90,
                   h->d_wnp,  h->d_Wnp,    h->d_mean_ylm, h->d_cov_ylm, h->d_ez,
-                  h->d_Ez,   h->d_tmpNN,  h->d_scratch, h->d_xp};
+                  h->d_Ez,   h->d_tmpNN,  h->d_scratch, h->d_xp, h->d_tab_scratch};
   for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
   for (void *p : ptrs)
     if (p) (void)hipFree(p);

@@ -42,15 +42,23 @@ __device__ __forceinline__ double temporal_factor(int kind, double ti, double tj
 }
 
 // spline lookup (flux.py:262-272)
+//
+// The segment index is integer work and must equal floor(fl(x / dx)) bit for
+// bit.  An IEEE fp64 division costs ~12 dependent instructions, so the index is
+// first taken from the product q = x * (1/dx) (within 2 ulp of the quotient)
+// and the exact division is only evaluated when q lies within 1e-9 of an
+// integer, the only case in which the two floors can differ.
 struct SplineGen {
   const double *a0, *a1, *a2, *a3, *xp;  // LDS
-  double dx;
+  double dx, inv_dx;
   int covpts;
   __device__ __forceinline__ double operator()(double thi, double thj) const {
     const double x = fabs(thi - thj);
-    long idx = (long)floor(x / dx);
+    const double q = x * inv_dx;
+    long idx = (long)q;
+    if (fabs(q - rint(q)) < 1.0e-9) idx = (long)floor(x / dx);
     idx = idx < 0 ? 0 : (idx > covpts ? covpts : idx);
-    const double x0 = (x - xp[idx + 1]) / dx;
+    const double x0 = (x - xp[idx + 1]) * inv_dx;
     return a0[idx] + a1[idx] * x0 + a2[idx] * (x0 * x0) + a3[idx] * (x0 * x0 * x0);
   }
 };
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(256) void rowsum_kernel(
       acc = q == 0 ? meanvar[2 * st.table + 1] : 0.0;
     } else {
       SplineGen g{s_tab, s_tab + np, s_tab + 2 * np, s_tab + 3 * np, s_tab + 4 * np,
-                  6.283185307179586 / covpts, covpts};
+                  6.283185307179586 / covpts, 1.0 / (6.283185307179586 / covpts), covpts};
       const double thi = s_th[i];
       const double ti = temporal != SP_TEMPORAL_NONE ? s_t[i] : 0.0;
       for (int j = q; j < K; j += 4)
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(
   }
   __syncthreads();
   SplineGen g{s_tab, s_tab + np, s_tab + 2 * np, s_tab + 3 * np, s_tab + 4 * np,
-              6.283185307179586 / covpts, covpts};
+              6.283185307179586 / covpts, 1.0 / (6.283185307179586 / covpts), covpts};
   const double var1 = (!FROM_MATRIX && K == 1) ? meanvar[2 * st.table + 1] : 0.0;
   double *ob = out + (size_t)s * strideo;
   // thread -> 4 consecutive columns, 16 rows per pass

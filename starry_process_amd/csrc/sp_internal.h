@@ -40,6 +40,8 @@ struct sp_handle {
   // small device scratch owned by the handle
   double *d_scratch;
   size_t scratch_bytes;
+  double *d_tab_scratch;        // [ntab][2][N] row reductions of the kernel table
+  size_t tab_scratch_bytes;
   // optional per-launch timing of the trailing-update kernel (bench roofline)
   bool prof_on;
   std::vector<hipEvent_t> prof_ev;   // pairs (start, stop)

@@ -29,13 +29,42 @@ __device__ __forceinline__ double block_sum(double v, double *red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ __launch_bounds__(256) void table_kernel(
-    int ydeg, int N, const int32_t *__restrict__ l_of,
-    const int32_t *__restrict__ mirror, const int32_t *__restrict__ blk,
-    const double *__restrict__ wnp, const double *__restrict__ Wnp,
-    const double *__restrict__ ez, const double *__restrict__ Ez,
-    const double *__restrict__ rta1_all, int covpts,
-    const double *__restrict__ xp, double *__restrict__ tab_all,
+// rows of W o Ez: grid (ceil(N/4), ntab), one wavefront per row n
+//   r1[n] = sum_j W[n,j] Ez[n,j],  r2[n] = sum_j W[n,j] Ez[n,mirror(j)],
+//   W[n,j] = Wnp[n,j] * rTA1[m0(l_n)] * rTA1[m0(l_j)]          (flux.py:199-209)
+__global__ __launch_bounds__(256) void table_rows_kernel(
+    int N, const int32_t *__restrict__ l_of, const int32_t *__restrict__ mirror,
+    const double *__restrict__ Wnp, const double *__restrict__ Ez,
+    const double *__restrict__ rta1_all, double *__restrict__ rows_all) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 4 + wave;
+  if (n >= N) return;
+  const double *rta1 = rta1_all + (size_t)blockIdx.y * N;
+  const int ln = l_of[n];
+  const double rn = rta1[ln * ln + ln];
+  const double *Wn = Wnp + (size_t)n * N, *En = Ez + (size_t)n * N;
+  double a = 0.0, b = 0.0;
+  for (int j = lane; j < N; j += 64) {
+    const int lj = l_of[j];
+    const double wv = Wn[j] * (rn * rta1[lj * lj + lj]);
+    a += wv * En[j];
+    b += wv * En[mirror[j]];
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if (lane == 0) {
+    double *rows = rows_all + (size_t)blockIdx.y * 2 * N;
+    rows[n] = a;
+    rows[N + n] = b;
+  }
+}
+
+// one workgroup per table: mean, variance, harmonics, lag grid, spline
+__global__ __launch_bounds__(256) void table_finish_kernel(
+    int ydeg, int N, const int32_t *__restrict__ l_of, const int32_t *__restrict__ blk,
+    const double *__restrict__ wnp, const double *__restrict__ ez,
+    const double *__restrict__ rta1_all, const double *__restrict__ rows_all,
+    int covpts, const double *__restrict__ xp, double *__restrict__ tab_all,
     double *__restrict__ meanvar_all) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double *s_rta1 = lds;             // N
@@ -45,12 +74,17 @@ __global__ __launch_bounds__(256) void table_kernel(
   double *s_ca = s_yp + covpts + 4; // ydeg + 1
   double *s_sa = s_ca + ydeg + 1;   // ydeg + 1
   double *s_red = s_sa + ydeg + 1;  // 4
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const int np = covpts + 4;
   const double *rta1 = rta1_all + (size_t)blockIdx.x * N;
+  const double *rows = rows_all + (size_t)blockIdx.x * 2 * N;
   double *tab = tab_all + (size_t)blockIdx.x * 5 * np;
 
-  for (int n = tid; n < N; n += 256) s_rta1[n] = rta1[n];
+  for (int n = tid; n < N; n += 256) {
+    s_rta1[n] = rta1[n];
+    s_r1[n] = rows[n];
+    s_r2[n] = rows[N + n];
+  }
   __syncthreads();
 
   // first moment: w[l] = rTA1[l-block] . wnp[l];  mean = sum_l w[l] . ez[l-block]
@@ -63,27 +97,6 @@ __global__ __launch_bounds__(256) void table_kernel(
     part += wn * ez[n];
   }
   const double mean = block_sum(part, s_red);
-
-  // rows of W o Ez, W[n, j] = Wnp[n, j] * rTA1[m0(l_n)] * rTA1[m0(l_j)]
-  for (int n = wave; n < N; n += 4) {
-    const int ln = l_of[n];
-    const double rn = s_rta1[ln * ln + ln];
-    const double *Wn = Wnp + (size_t)n * N, *En = Ez + (size_t)n * N;
-    double a = 0.0, b = 0.0;
-    for (int j = lane; j < N; j += 64) {
-      const int lj = l_of[j];
-      const double wv = Wn[j] * (rn * s_rta1[lj * lj + lj]);
-      a += wv * En[j];
-      b += wv * En[mirror[j]];
-    }
-    a = wave_sum(a);
-    b = wave_sum(b);
-    if (lane == 0) {
-      s_r1[n] = a;
-      s_r2[n] = b;
-    }
-  }
-  __syncthreads();
 
   // variance = <W, Ez> - mean^2 (flux.py:305-308)
   double pv = 0.0;
@@ -160,16 +173,29 @@ int sp_launch_kernel_table(sp_handle *h, const double *rta1_dev, int ntab,
   const size_t lds =
       sizeof(double) * ((size_t)3 * h->N + covpts + 4 + 2 * (h->ydeg + 1) + 4);
   if (lds > 150 * 1024) return SP_ERR_INVALID;
+  // row-reduction scratch [ntab][2][N], grown on demand (rare: new ntab)
+  const size_t need = sizeof(double) * (size_t)ntab * 2 * h->N;
+  if (h->tab_scratch_bytes < need) {
+    SP_HIP(hipDeviceSynchronize());
+    if (h->d_tab_scratch) SP_HIP(hipFree(h->d_tab_scratch));
+    h->d_tab_scratch = nullptr;
+    h->tab_scratch_bytes = 0;
+    SP_HIP(hipMalloc((void **)&h->d_tab_scratch, need));
+    h->tab_scratch_bytes = need;
+  }
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(table_kernel),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(table_finish_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL(table_kernel, dim3(ntab), dim3(256), lds, st, h->ydeg,
-                     h->N, h->d_l_of, h->d_mirror, h->d_blk, h->d_wnp, h->d_Wnp,
-                     h->d_ez, h->d_Ez, rta1_dev, covpts, xp_dev, tab_dev,
-                     meanvar_dev);
+  hipLaunchKernelGGL(table_rows_kernel, dim3((h->N + 3) / 4, ntab), dim3(256), 0, st,
+                     h->N, h->d_l_of, h->d_mirror, h->d_Wnp, h->d_Ez, rta1_dev,
+                     h->d_tab_scratch);
+  SP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(table_finish_kernel, dim3(ntab), dim3(256), lds, st, h->ydeg, h->N,
+                     h->d_l_of, h->d_blk, h->d_wnp, h->d_ez, rta1_dev, h->d_tab_scratch,
+                     covpts, xp_dev, tab_dev, meanvar_dev);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }

@@ -154,11 +154,16 @@ class Engine(object):
         return out
 
     def rTA1L(self, u):
-        u = np.ascontiguousarray(np.asarray(u, dtype=np.float64).reshape(-1, max(self.udeg, 1)))[:, : self.udeg]
-        u = np.ascontiguousarray(u)
+        """u: (udeg,) or (nsets, udeg) -> (nsets, N); udeg = 0 gives rTA1."""
+        if self.udeg == 0:
+            return self.rTA1()[None, :].copy()
+        u = np.asarray(u, dtype=np.float64)
+        u = np.ascontiguousarray(u.reshape(-1, u.shape[-1])[:, : self.udeg])
+        if u.shape[1] != self.udeg:
+            raise ValueError("Vector `u` has the wrong size.")
         n = u.shape[0]
         out = np.empty((n, self.N))
-        check(self._L.sp_rTA1L(self._h, hptr(u) if self.udeg else c_void_p(0), n, hptr(out)))
+        check(self._L.sp_rTA1L(self._h, hptr(u), n, hptr(out)))
         return out
 
     # -- moments / kernel table ------------------------------------------------

@@ -1,0 +1,262 @@
+"""
+``StarryProcess``: source-compatible front end of the reference class
+(reference ``sp.py:38-1396``) restricted to the log-likelihood hot path:
+
+    sp = StarryProcess(r=..., a=..., b=..., c=..., n=..., ydeg=15, ...)
+    sp.mean(t, i, p, u); sp.cov(t, i, p, u)
+    sp.log_likelihood(t, flux, data_cov, i, p, u, baseline_mean, baseline_var)
+
+Keyword names, defaults, argument meaning and error behaviour follow the
+reference (``sp.py:39-51, 643-703, 1052-1188``).  Results are eager NumPy values
+with a no-op ``.eval()`` so scripts written for the lazy Theano graph run
+unchanged.  Every number on the path mean / cov / log_likelihood is produced on
+the GPU by ``libsp_hip.so``.
+
+The Ylm moments (mu_y, Sigma_y) come from the hyperparameters through the host
+module ``upstream`` (reference sp.py:257-266); they can also be injected with
+``mean_ylm= / cov_ylm=`` (what the tests and ``bench.py`` do with the golden
+moments).
+
+Addition over the reference: ``log_likelihood_ensemble`` evaluates many stars,
+each with its own period / inclination / limb darkening / noise, in one batched
+device call -- the calibrate-style use case the reference describes but leaves
+unimplemented (joss/paper.md:160-172).
+"""
+import numpy as np
+
+from .defaults import defaults
+from .engine import get_engine, make_stars
+from .flux import FluxIntegral
+from .ops import AlphaBetaOp, CheckBoundsOp, Eager
+from .temporal import kernel_id
+
+__all__ = ["StarryProcess"]
+
+
+def _neg_inf_if_nan(x):
+    x = np.asarray(x, dtype=np.float64)
+    return np.where(np.isnan(x), -np.inf, x)
+
+
+class StarryProcess(object):
+    def __init__(
+        self,
+        r=defaults["r"],
+        dr=defaults["dr"],
+        c=defaults["c"],
+        n=defaults["n"],
+        tau=defaults["tau"],
+        temporal_kernel=defaults["temporal_kernel"],
+        marginalize_over_inclination=defaults["marginalize_over_inclination"],
+        normalized=defaults["normalized"],
+        covpts=defaults["covpts"],
+        **kwargs
+    ):
+        mu = kwargs.pop("mu", None)
+        sigma = kwargs.pop("sigma", None)
+        mean_ylm = kwargs.pop("mean_ylm", None)
+        cov_ylm = kwargs.pop("cov_ylm", None)
+        if mu is None and sigma is None:
+            a = kwargs.pop("a", defaults["a"])
+            b = kwargs.pop("b", defaults["b"])
+        elif (kwargs.get("a", None) is None and kwargs.get("b", None) is None) and (
+            mu is not None and sigma is not None
+        ):
+            from .upstream import gauss2beta
+
+            a, b = gauss2beta(mu, sigma)
+        else:
+            raise ValueError("Must provide either `a` and `b` *or* `mu` and `sigma`.")
+
+        if tau is None:
+            self._tau = 0.0
+            self._time_variable = False
+            self._temporal = None
+        else:
+            self._tau = float(CheckBoundsOp(name="tau", lower=0, upper=np.inf)(tau))
+            self._time_variable = True
+            self._temporal = kernel_id(temporal_kernel)
+
+        self._ydeg = int(kwargs.get("ydeg", defaults["ydeg"]))
+        assert self._ydeg >= 5, "Degree of map must be >= 5."
+        self._udeg = int(kwargs.get("udeg", defaults["udeg"]))
+        assert self._udeg >= 0, "Degree of limb darkening must be >= 0."
+        self._nylm = (self._ydeg + 1) ** 2
+        self._covpts = int(covpts)
+        self._kwargs = kwargs
+        self._normalized = bool(normalized)
+        self._normN = int(kwargs.get("normalization_order", defaults["normalization_order"]))
+        self._normzmax = float(kwargs.get("normalization_zmax", defaults["normalization_zmax"]))
+        self._get_alpha_beta = AlphaBetaOp(self._normN)
+        self._marginalize_over_inclination = bool(marginalize_over_inclination)
+        self._r, self._dr, self._a, self._b, self._c, self._n = r, dr, a, b, c, n
+
+        if mean_ylm is None or cov_ylm is None:
+            from .upstream import ylm_moments
+
+            mean_ylm, cov_ylm = ylm_moments(r=r, dr=dr, a=a, b=b, c=c, n=n, ydeg=self._ydeg, **kwargs)
+        self._mean_ylm = np.asarray(mean_ylm, dtype=np.float64).reshape(-1)
+        self._cov_ylm = np.asarray(cov_ylm, dtype=np.float64)
+        if self._mean_ylm.shape != (self._nylm,) or self._cov_ylm.shape != (self._nylm, self._nylm):
+            raise ValueError("mean_ylm / cov_ylm have the wrong shape for ydeg=%d" % self._ydeg)
+
+        self._engine = get_engine(self._ydeg, self._udeg, kwargs.get("device"))
+        self._flux = FluxIntegral(
+            self._mean_ylm,
+            self._cov_ylm,
+            udeg=self._udeg,
+            marginalize_over_inclination=self._marginalize_over_inclination,
+            covpts=self._covpts,
+            ydeg=self._ydeg,
+            device=kwargs.get("device"),
+        )
+        self._z = None
+
+    # -- hyperparameters (read-only views, sp.py:286-367) -------------------------
+    a = property(lambda self: self._a)
+    b = property(lambda self: self._b)
+    r = property(lambda self: self._r)
+    dr = property(lambda self: self._dr)
+    c = property(lambda self: self._c)
+    n = property(lambda self: self._n)
+    tau = property(lambda self: self._tau)
+    ydeg = property(lambda self: self._ydeg)
+    udeg = property(lambda self: self._udeg)
+    normalized = property(lambda self: self._normalized)
+    covpts = property(lambda self: self._covpts)
+    marginalize_over_inclination = property(lambda self: self._marginalize_over_inclination)
+    mean_ylm = property(lambda self: Eager(self._mean_ylm))
+    cov_ylm = property(lambda self: Eager(self._cov_ylm))
+
+    # -- mean / cov (sp.py:643-703) --------------------------------------------------
+    def mean(self, t, i=defaults["i"], p=defaults["p"], u=defaults["u"][: defaults["udeg"]]):
+        if self._normalized:
+            return Eager(np.zeros_like(np.asarray(t, dtype=np.float64).reshape(-1)))
+        return self._flux.mean(t, i, p, u)
+
+    def _device_cov(self, t, i, p, u):
+        f = self._flux
+        t, i, p, u = f._ingest(t, i, p, u)
+        f._bind()
+        e = self._engine
+        stars = make_stars(1, period=p, inc_deg=i, tau=self._tau)
+        if self._marginalize_over_inclination:
+            tab, mv = f._table(u)
+            cov, z = e.cov_marginal(t[None, :], stars, self._covpts, tab, mv, temporal=self._temporal,
+                                    normalized=self._normalized, norm_order=self._normN)
+            fmean = mv[0, 0]
+        else:
+            cov, mean, z = e.cov_conditional(t[None, :], stars, f._rta1(u), temporal=self._temporal,
+                                             normalized=self._normalized, norm_order=self._normN)
+            fmean = mean[0]
+        if self._normalized:
+            self._z = float(z[0].item())
+        return t, cov[0], fmean
+
+    def cov(self, t, i=defaults["i"], p=defaults["p"], u=defaults["u"][: defaults["udeg"]]):
+        _, cov, _ = self._device_cov(t, i, p, u)
+        return Eager(cov.cpu().numpy())
+
+    # -- log likelihood (sp.py:1052-1188) ------------------------------------------------
+    def log_likelihood(
+        self,
+        t,
+        flux,
+        data_cov,
+        i=defaults["i"],
+        p=defaults["p"],
+        u=defaults["u"][: defaults["udeg"]],
+        baseline_mean=defaults["baseline_mean"],
+        baseline_var=defaults["baseline_var"],
+    ):
+        f = self._flux
+        t, i, p, u = f._ingest(t, i, p, u)
+        K = t.shape[0]
+        flux = np.asarray(flux, dtype=np.float64)
+        F = flux.reshape(1, K) if flux.ndim == 1 else flux.reshape(-1, K)
+        data_cov = np.asarray(data_cov, dtype=np.float64)
+        bmean = np.asarray(baseline_mean, dtype=np.float64)
+        bvar = np.asarray(baseline_var, dtype=np.float64)
+        simple = data_cov.ndim <= 1 and bmean.ndim == 0 and bvar.ndim == 0
+        e = self._engine
+        f._bind()
+        if simple:
+            stars = make_stars(1, period=p, inc_deg=i, tau=self._tau, baseline_var=float(bvar),
+                               baseline_mean=float(bmean),
+                               data_var=float(data_cov) if data_cov.ndim == 0 else 0.0)
+            diag = e.f64(data_cov.reshape(1, K)) if data_cov.ndim == 1 else None
+            rta1 = f._rta1(u)
+            tab = mv = None
+            if self._marginalize_over_inclination:
+                tab, mv = f._table(u)
+            out, status = e.lnlike_ensemble(
+                e.f64(t[None, :]), e.f64(F[None, :, :]), e.stars_to_device(stars), diag=diag,
+                conditional=not self._marginalize_over_inclination, covpts=self._covpts, tab=tab,
+                meanvar=mv, rta1=rta1, temporal=self._temporal, normalized=self._normalized,
+                norm_order=self._normN, zmax=self._normzmax)
+            return Eager(_neg_inf_if_nan(out.cpu().numpy())[0])
+        # general data / baseline covariances: assemble on the device, add the
+        # extra terms with tensor ops, then the batched factorisation
+        tt, cov, fmean = self._device_cov(t, i, p, u)
+        C = cov.clone()
+        if data_cov.ndim == 0:
+            C.diagonal().add_(float(data_cov))
+        elif data_cov.ndim == 1:
+            C.diagonal().add_(e.f64(data_cov))
+        else:
+            C += e.f64(data_cov)
+        C += e.f64(bvar) if bvar.ndim else float(bvar)
+        gp_mean = 0.0 if self._normalized else fmean
+        resid = e.f64(F) - (gp_mean + (e.f64(bmean) if bmean.ndim else float(bmean)))
+        out, status = e.cholesky_lnlike(C[None, :, :], resid[None, :, :])
+        val = _neg_inf_if_nan(out.cpu().numpy())[0]
+        if self._normalized and self._z is not None and self._z > self._normzmax:
+            val = -np.inf
+        return Eager(val)
+
+    def log_likelihood_ensemble(self, t, flux, data_cov, i=None, p=None, u=None,
+                                baseline_mean=0.0, baseline_var=0.0):
+        """Per-star log-likelihoods of S independent stars in one device call.
+
+        t: (K,) or (S, K); flux: (S, K); data_cov: scalar, (S,) or (S, K);
+        i, p: scalars or (S,); u: (udeg,) shared or (S, udeg)."""
+        e = self._engine
+        f = self._flux
+        flux = np.asarray(flux, dtype=np.float64)
+        S, K = flux.shape
+        t = np.asarray(t, dtype=np.float64)
+        t = np.broadcast_to(t, (S, K)) if t.ndim == 1 else t
+        p = np.broadcast_to(np.asarray(defaults["p"] if p is None else p, dtype=np.float64), (S,))
+        i = np.broadcast_to(np.asarray(defaults["i"] if i is None else i, dtype=np.float64), (S,))
+        if np.any(p < -1e-6):
+            raise ValueError("p out of bounds")
+        if np.any(i * np.pi / 180 < -1e-6) or np.any(i * np.pi / 180 > 0.5 * np.pi + 1e-6):
+            raise ValueError("i out of bounds")
+        u = np.asarray(defaults["u"][: self._udeg] if u is None else u, dtype=np.float64)
+        if u.ndim == 1:
+            utab, table = u[None, : self._udeg], np.zeros(S, dtype=np.int32)
+        else:
+            utab, table = np.unique(u[:, : self._udeg], axis=0, return_inverse=True)
+            table = table.astype(np.int32).reshape(-1)
+        data_cov = np.asarray(data_cov, dtype=np.float64)
+        diag = None
+        dvar = 0.0
+        if data_cov.ndim == 2:
+            diag = e.f64(np.ascontiguousarray(data_cov))
+        else:
+            dvar = np.broadcast_to(data_cov, (S,))
+        stars = make_stars(S, period=p, inc_deg=i, tau=self._tau,
+                           baseline_var=np.broadcast_to(np.asarray(baseline_var, float), (S,)),
+                           baseline_mean=np.broadcast_to(np.asarray(baseline_mean, float), (S,)),
+                           data_var=dvar, table=table)
+        f._bind()
+        rta1 = e.f64(e.rTA1L(utab))
+        tab = mv = None
+        if self._marginalize_over_inclination:
+            tab, mv = e.kernel_table(rta1, self._covpts)
+        out, status = e.lnlike_ensemble(
+            e.f64(np.ascontiguousarray(t)), e.f64(flux[:, None, :]), e.stars_to_device(stars), diag=diag,
+            conditional=not self._marginalize_over_inclination, covpts=self._covpts, tab=tab,
+            meanvar=mv, rta1=rta1, temporal=self._temporal, normalized=self._normalized,
+            norm_order=self._normN, zmax=self._normzmax)
+        return Eager(_neg_inf_if_nan(out.cpu().numpy()))

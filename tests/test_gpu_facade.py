@@ -1,0 +1,162 @@
+"""
+GPU tests of the source-compatible front end (StarryProcess / FluxIntegral /
+ops), written the way the reference's own tests read
+(tests/test_lnlike.py, test_variance.py, test_ld.py, test_sum.py).
+"""
+import numpy as np
+import pytest
+
+from conftest import golden
+from oracle import sp_oracle as orc
+from starry_process_amd.synthetic import synthetic_star
+
+pytestmark = pytest.mark.gpu
+
+
+def SP(L=15, **kw):
+    from starry_process_amd import StarryProcess
+
+    mom = golden("moments_L%d" % L)
+    return StarryProcess(ydeg=L, mean_ylm=mom["default_mean_ylm"], cov_ylm=mom["default_cov_ylm"], **kw)
+
+
+def test_log_likelihood_matches_reference():
+    g = golden("lnlike")
+    sp = SP(15)
+    st = synthetic_star(0, 1000)
+    v = sp.log_likelihood(st["t"], st["flux"], st["data_cov"], p=st["p"])
+    assert abs(float(v.eval()) / g["cfg2_L15_K1000"][0] - 1) < 1e-8
+    # Appendix-B anchor of the survey
+    t = np.linspace(0, 4, 1000)
+    fl = 1e-2 * np.sin(2 * np.pi * t) + 1e-3 * np.random.RandomState(0).randn(1000)
+    assert abs(float(sp.log_likelihood(t, fl, 1e-6)) - 5455.083646979640) < 5e-5
+    # conditional, not normalised
+    spc = SP(15, marginalize_over_inclination=False, normalized=False)
+    st1 = synthetic_star(1, 1000)
+    v = spc.log_likelihood(st1["t"], st1["flux"], st1["data_cov"], p=st1["p"], i=st1["i"])
+    assert abs(float(v) / g["L15_K1000_cond"][1] - 1) < 1e-8
+
+
+def test_data_cov_forms_agree():
+    """scalar == vector == matrix data covariance; matrix baseline (sp.py:1135-1151)."""
+    sp = SP(15)
+    st = synthetic_star(3, 150)
+    K = 150
+    a = float(sp.log_likelihood(st["t"], st["flux"], 1e-6, p=st["p"]))
+    b = float(sp.log_likelihood(st["t"], st["flux"], 1e-6 * np.ones(K), p=st["p"]))
+    c = float(sp.log_likelihood(st["t"], st["flux"], 1e-6 * np.eye(K), p=st["p"]))
+    assert abs(b / a - 1) < 1e-12 and abs(c / a - 1) < 1e-10
+    d = float(sp.log_likelihood(st["t"], st["flux"], 1e-6, p=st["p"], baseline_var=1e-4, baseline_mean=1e-3))
+    e = float(sp.log_likelihood(st["t"], st["flux"], 1e-6, p=st["p"], baseline_var=1e-4 * np.ones((K, K)),
+                                baseline_mean=1e-3 * np.ones(K)))
+    assert abs(e / d - 1) < 1e-10
+    mom = golden("moments_L15")
+    op = orc.OracleProcess(mom["default_mean_ylm"], mom["default_cov_ylm"], ydeg=15)
+    ref = op.log_likelihood(st["t"], st["flux"], 1e-6, p=st["p"], baseline_var=1e-4, baseline_mean=1e-3)
+    assert abs(d / ref - 1) < 1e-8
+
+
+def test_multi_lightcurve_batch():
+    g = golden("lnlike")
+    sp = SP(15)
+    sts = [synthetic_star(s, 200) for s in range(5)]
+    F = np.array([st["flux"] for st in sts])
+    v = float(sp.log_likelihood(sts[0]["t"], F, 1e-6, p=1.3))
+    assert abs(v / float(g["L15_K200_batchM5"]) - 1) < 1e-8
+
+
+def test_ensemble_equals_per_star_calls():
+    sp = SP(15)
+    S, K = 6, 200
+    sts = [synthetic_star(s, K) for s in range(10, 10 + S)]
+    F = np.array([st["flux"] for st in sts])
+    p = np.array([st["p"] for st in sts])
+    us = np.array([[0.0, 0.0], [0.4, 0.2], [0.0, 0.0], [0.1, 0.3], [0.4, 0.2], [0.0, 0.0]])
+    ens = np.asarray(sp.log_likelihood_ensemble(sts[0]["t"], F, 1e-6, p=p, u=us))
+    one = np.array([float(sp.log_likelihood(st["t"], st["flux"], 1e-6, p=st["p"], u=uu)) for st, uu in zip(sts, us)])
+    assert np.max(np.abs(ens / one - 1)) < 1e-12
+    g = golden("lnlike")
+    ens2 = np.asarray(sp.log_likelihood_ensemble(
+        sts[0]["t"], np.array([synthetic_star(s, K)["flux"] for s in range(6)]), 1e-6,
+        p=np.array([synthetic_star(s, K)["p"] for s in range(6)])))
+    assert np.max(np.abs(ens2 / g["L15_K200"][:6] - 1)) < 1e-8
+
+
+def test_mean_cov_and_variance_special_case():
+    g = golden("cov_L15")
+    sp = SP(15, normalized=False)
+    k1 = np.asarray(sp.cov(np.array([0.3])))
+    k2 = np.asarray(sp.cov(np.array([0.0, 0.1])))
+    assert np.max(np.abs(k1 - g["k1_cov"])) < 1e-11 * np.abs(g["k1_cov"]).max()
+    assert np.max(np.abs(k2 - g["k2_cov"])) < 1e-11 * np.abs(g["k2_cov"]).max()
+    assert abs(k2[0, 0] - k1[0, 0]) < 1e-12 * abs(k1[0, 0])     # reference tests/test_variance.py:5-11
+    t = g["t"]
+    spn = SP(15, normalized=True, tau=2.5)
+    cov = np.asarray(spn.cov(t, p=float(g["marg_mat32_p"])))
+    assert np.max(np.abs(cov - g["marg_mat32_cov"])) < 5e-11 * np.abs(g["marg_mat32_cov"]).max()
+    assert np.all(np.asarray(spn.mean(t)) == 0)
+    m = np.asarray(sp.mean(t, p=1.37))
+    assert np.allclose(m, g["marg_raw_mean"], rtol=1e-12)
+
+
+def test_null_limb_darkening_and_bounds():
+    """reference tests/test_ld.py:44-49; ops/exceptions.py:30-48."""
+    from starry_process_amd import StarryProcess
+
+    mom = golden("moments_L15")
+    st = synthetic_star(2, 120)
+    a = StarryProcess(ydeg=15, udeg=2, mean_ylm=mom["default_mean_ylm"], cov_ylm=mom["default_cov_ylm"])
+    b = StarryProcess(ydeg=15, udeg=0, mean_ylm=mom["default_mean_ylm"], cov_ylm=mom["default_cov_ylm"])
+    va = float(a.log_likelihood(st["t"], st["flux"], 1e-6, p=st["p"], u=[0.0, 0.0]))
+    vb = float(b.log_likelihood(st["t"], st["flux"], 1e-6, p=st["p"], u=[]))
+    assert abs(va / vb - 1) < 1e-9
+    with pytest.raises(ValueError):
+        a.log_likelihood(st["t"], st["flux"], 1e-6, i=95.0)
+    with pytest.raises(ValueError):
+        a.log_likelihood(st["t"], st["flux"], 1e-6, p=-1.0)
+    with pytest.raises(ValueError):
+        StarryProcess(ydeg=15, tau=-1.0, mean_ylm=mom["default_mean_ylm"], cov_ylm=mom["default_cov_ylm"])
+    assert float(a.log_likelihood(st["t"], st["flux"], -1.0)) == -np.inf
+
+
+def test_ops_module_signatures():
+    from starry_process_amd import ops
+
+    g = golden("ops_L5")
+    R, dR = ops.RxOp(5)(g["Rx_theta"][1])
+    assert np.array_equal(R.eval(), g["Rx_R"][1]) and np.array_equal(dR.eval(), g["Rx_dR"][1])
+    with pytest.raises(ValueError):
+        ops.RxOp(5)(np.zeros(3))
+    rng = np.random.RandomState(int(g["tdRz_seed"]))
+    M = rng.randn(50, 36)
+    th = rng.uniform(-7, 7, 50)
+    f = ops.tensordotRzOp(5)(M, th)
+    assert np.max(np.abs(f.eval() - g["tdRz_f"])) < 1e-13 * np.abs(g["tdRz_f"]).max()
+    assert np.array_equal(ops.rTA1Op(5)().eval(), g["rTA1"])
+    assert np.max(np.abs(ops.rTA1LOp(5, 2)(g["rTA1L_u"][1]).eval() - g["rTA1L"][1])) < 1e-13
+    al, be, _, _ = ops.AlphaBetaOp(20)(4.2904487674796314e-4)
+    assert abs(float(al) - 1.00128990414774) < 1e-14
+    A = np.array([[4.0, 2.0], [2.0, 3.0]])
+    L = ops.cho_factor(A).eval()
+    assert np.allclose(L @ L.T, A, atol=1e-14) and L[0, 1] == 0
+    x = ops.cho_solve(L, np.array([1.0, 2.0])).eval()
+    assert np.allclose(A @ x, [1.0, 2.0], atol=1e-13)
+    with pytest.raises(ValueError):
+        ops.CheckBoundsOp(name="p", lower=0, upper=np.inf)(-1.0)
+
+
+def test_flux_integral_mirror():
+    from starry_process_amd.flux import FluxIntegral
+
+    g = golden("cov_L15")
+    mom = golden("moments_L15")
+    fi = FluxIntegral(mom["default_mean_ylm"], mom["default_cov_ylm"], ydeg=15,
+                      marginalize_over_inclination=False)
+    A = np.asarray(fi.design_matrix(g["t"], float(g["cond_raw_i"]), float(g["cond_raw_p"]), g["cond_raw_u"]))
+    assert np.max(np.abs(A - g["cond_raw_A"])) < 4e-12 * np.abs(g["cond_raw_A"]).max()
+    cov = np.asarray(fi.cov(g["t"], float(g["cond_raw_i"]), float(g["cond_raw_p"]), g["cond_raw_u"]))
+    assert np.max(np.abs(cov - g["cond_raw_cov"])) < 5e-11 * np.abs(g["cond_raw_cov"]).max()
+    fm = FluxIntegral(mom["default_mean_ylm"], mom["default_cov_ylm"], ydeg=15)
+    k = np.asarray(fm.kernel(np.array([0.0, 0.1, 0.7]), 60.0, 1.0, [0.0, 0.0]))
+    tab = mom["default_u0_yp"]
+    assert abs(k[0] - tab[1]) < 1e-12 * abs(tab[1])   # zero lag = yp at x = 0
