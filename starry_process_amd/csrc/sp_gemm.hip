@@ -16,28 +16,34 @@
 // Workgroup -> tile mapping is XCD-aware: blockIdx.x % 8 selects the XCD
 // (round-robin dispatch), and all tiles of one matrix are given to one XCD so
 // that the row panels every tile re-reads stay in that XCD's 4 MiB L2.
+#include <cstdlib>
+
 #include "sp_internal.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 #define GT 64   // tile edge
-#define GK 32   // k slice
-#define GLD 34  // padded LDS row length (doubles)
 
 namespace {
 
-__device__ __forceinline__ void stage_panel(const double *P,
-                                            long ld, int row0, int nrows,
-                                            int k0, int Kd, double scale,
-                                            bool vec_ok, double *__restrict__ s) {
-  // 64 rows x 32 k  ->  s[row][k], 4 passes of 16 rows, 16 lanes x 16 B per row
+// Global -> registers -> LDS staging of a 64-row x BK panel slice, split in two
+// so that the loads of slice k+1 are in flight while slice k feeds the MFMAs.
+//   BK/2 lanes x 16 B per row, 256/(BK/2) rows per pass, 64/that passes.
+template <int BK>
+struct PanelRegs {
+  d2 v[GT / (256 / (BK / 2))];
+};
+
+template <int BK>
+__device__ __forceinline__ void stage_load(const double *P, long ld, int row0, int nrows,
+                                           int k0, int Kd, bool vec_ok, PanelRegs<BK> &R) {
+  constexpr int LPR = BK / 2, RPP = 256 / LPR;
   const int t = threadIdx.x;
-  const int cpair = (t & 15) * 2;
+  const int cpair = (t % LPR) * 2;
 #pragma unroll
-  for (int pass = 0; pass < 4; ++pass) {
-    const int r = (t >> 4) + 16 * pass;
-    const int gr = row0 + r;
+  for (int pass = 0; pass < GT / RPP; ++pass) {
+    const int gr = row0 + (t / LPR) + RPP * pass;
     d2 v = {0.0, 0.0};
     if (gr < nrows) {
       const double *src = P + (size_t)gr * ld + k0 + cpair;
@@ -48,21 +54,44 @@ __device__ __forceinline__ void stage_panel(const double *P,
         if (k0 + cpair + 1 < Kd) v.y = src[1];
       }
     }
-    v.x *= scale;
-    v.y *= scale;
-    *reinterpret_cast<d2 *>(s + r * GLD + cpair) = v;
+    R.v[pass] = v;
+  }
+}
+
+template <int BK>
+__device__ __forceinline__ void stage_store(const PanelRegs<BK> &R, double scale,
+                                            double *__restrict__ s) {
+  constexpr int LDW = BK + 1, LPR = BK / 2, RPP = 256 / LPR;
+  const int t = threadIdx.x;
+  const int cpair = (t % LPR) * 2;
+#pragma unroll
+  for (int pass = 0; pass < GT / RPP; ++pass) {
+    const int r = (t / LPR) + RPP * pass;
+    s[r * LDW + cpair] = R.v[pass].x * scale;
+    s[r * LDW + cpair + 1] = R.v[pass].y * scale;
   }
 }
 
 // (A and C may alias: the triangular solve X = P L^-T runs in place, each
 //  workgroup reads its whole A row-tile before it stores the same C tile.)
+//
+// Template parameters: BK = depth of one LDS stage (32 or 64); DEFER_C = issue
+// the C-tile loads before staging but consume them only after the MFMA loop, so
+// their HBM latency hides behind the panel staging and the matrix work.
+template <int BK, bool DEFER_C>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(
     const double *A, long lda, long strideA,
     const double *__restrict__ B, long ldb, long strideB, double *C,
     long ldc, long strideC, int Mrows, int Nrows, int Kd, double alpha,
     int beta, int lower_only, int batch, int ntm, int ntn, int ntiles) {
-  __shared__ __attribute__((aligned(16))) double sA[GT * GLD];
-  __shared__ __attribute__((aligned(16))) double sB[GT * GLD];
+  // Padded LDS row of BK + 1 doubles.  hipcc fuses the per-k-step fragment reads
+  // into ds_read2_b64, which is banked mod 32 dwords in 16-lane groups: an ODD
+  // row length puts the 16 rows of a group on 16 distinct bank pairs.  (An even
+  // row length of BK + 2 is conflict-free only for plain ds_read_b64 and cost
+  // 42% extra LDS cycles here: SQ_LDS_BANK_CONFLICT, profiles/r01_v3_pmc.txt.)
+  constexpr int LDW = BK + 1;
+  __shared__ __attribute__((aligned(16))) double sA[GT * LDW];
+  __shared__ __attribute__((aligned(16))) double sB[GT * LDW];
 
   // XCD-aware decode: blocks b and b+8 share an XCD
   const int b = blockIdx.x;
@@ -88,35 +117,50 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fk = lane >> 4;
 
-  d4 acc[4];
+  d4 acc[4], cin[4];
 #pragma unroll
-  for (int n = 0; n < 4; ++n) acc[n] = d4{0.0, 0.0, 0.0, 0.0};
+  for (int n = 0; n < 4; ++n) {
+    acc[n] = d4{0.0, 0.0, 0.0, 0.0};
+    cin[n] = d4{0.0, 0.0, 0.0, 0.0};
+  }
+  const bool full = row0 + GT <= Mrows && col0 + GT <= Nrows;
   if (beta) {
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int gi = row0 + 16 * wave + fk + 4 * r, gj = col0 + 16 * n + fr;
-        if (gi < Mrows && gj < Nrows) acc[n][r] = Cb[(size_t)gi * ldc + gj];
+        if (full || (gi < Mrows && gj < Nrows)) cin[n][r] = Cb[(size_t)gi * ldc + gj];
       }
+    if (!DEFER_C) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[n] = cin[n];
+    }
   }
 
   const bool vecA = ((lda & 1) == 0) && ((reinterpret_cast<uintptr_t>(Ab) & 15) == 0);
   const bool vecB = ((ldb & 1) == 0) && ((reinterpret_cast<uintptr_t>(Bb) & 15) == 0);
 
-  for (int k0 = 0; k0 < Kd; k0 += GK) {
-    stage_panel(Ab, lda, row0, Mrows, k0, Kd, alpha, vecA, sA);
-    stage_panel(Bb, ldb, col0, Nrows, k0, Kd, 1.0, vecB, sB);
+  PanelRegs<BK> ra, rb;
+  stage_load<BK>(Ab, lda, row0, Mrows, 0, Kd, vecA, ra);
+  stage_load<BK>(Bb, ldb, col0, Nrows, 0, Kd, vecB, rb);
+  for (int k0 = 0; k0 < Kd; k0 += BK) {
+    stage_store<BK>(ra, alpha, sA);
+    stage_store<BK>(rb, 1.0, sB);
     __syncthreads();
-    const double *pa = sA + (16 * wave + fr) * GLD + fk;
-    const double *pb = sB + fr * GLD + fk;
+    if (k0 + BK < Kd) {  // next slice: loads fly while this slice is multiplied
+      stage_load<BK>(Ab, lda, row0, Mrows, k0 + BK, Kd, vecA, ra);
+      stage_load<BK>(Bb, ldb, col0, Nrows, k0 + BK, Kd, vecB, rb);
+    }
+    const double *pa = sA + (16 * wave + fr) * LDW + fk;
+    const double *pb = sB + fr * LDW + fk;
 #pragma unroll
-    for (int kk = 0; kk < GK; kk += 4) {
+    for (int kk = 0; kk < BK; kk += 4) {
       const double a = pa[kk];
       const double b0 = pb[kk];
-      const double b1 = pb[16 * GLD + kk];
-      const double b2 = pb[32 * GLD + kk];
-      const double b3 = pb[48 * GLD + kk];
+      const double b1 = pb[16 * LDW + kk];
+      const double b2 = pb[32 * LDW + kk];
+      const double b3 = pb[48 * LDW + kk];
       acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc[1], 0, 0, 0);
       acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b2, acc[2], 0, 0, 0);
@@ -124,13 +168,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
     }
     __syncthreads();
   }
+  if (DEFER_C && beta) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] += cin[n];
+  }
 
 #pragma unroll
   for (int n = 0; n < 4; ++n)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int gi = row0 + 16 * wave + fk + 4 * r, gj = col0 + 16 * n + fr;
-      if (gi < Mrows && gj < Nrows) Cb[(size_t)gi * ldc + gj] = acc[n][r];
+      if (full || (gi < Mrows && gj < Nrows)) Cb[(size_t)gi * ldc + gj] = acc[n][r];
     }
 }
 
@@ -147,9 +195,22 @@ int sp_launch_gemm_nt(const double *A, long lda, long strideA, const double *B,
   const int ntiles = lower_only ? ntm * (ntm + 1) / 2 : ntm * ntn;
   const long nblk = 8L * ((batch + 7) / 8) * ntiles;
   if (nblk > 0x7fffffffL) return SP_ERR_INVALID;
-  hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)nblk), dim3(256), 0, st, A,
-                     lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows,
-                     Nrows, Kd, alpha, beta, lower_only, batch, ntm, ntn, ntiles);
+  static int variant = -1;
+  if (variant < 0) {
+    const char *e = getenv("SP_GEMM_VARIANT");
+    variant = e ? atoi(e) : 1;
+  }
+#define SP_GO(BK, DC)                                                              \
+  hipLaunchKernelGGL((gemm_nt_kernel<BK, DC>), dim3((unsigned)nblk), dim3(256), 0, \
+                     st, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, \
+                     Nrows, Kd, alpha, beta, lower_only, batch, ntm, ntn, ntiles)
+  switch (variant) {
+    case 0: SP_GO(32, false); break;
+    case 2: SP_GO(64, false); break;
+    case 3: SP_GO(64, true); break;
+    default: SP_GO(32, true); break;
+  }
+#undef SP_GO
   SP_LAUNCH_CHECK();
   return SP_OK;
 }
