@@ -118,7 +118,7 @@ def main():
     e.set_moments(mu, Sig)  # first call allocates / uploads the lag grid
     for _ in range(args.warmup):
         step()
-    nsyrk = (K + 63) // 64
+    nsyrk = (K + 63) // 64  # upper bound on timed launches per step
     e.profile_begin(args.steps * nsyrk)
     if world > 1:
         dist.barrier()

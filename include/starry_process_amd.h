@@ -258,6 +258,11 @@ int sp_cholesky_lnlike_batched(sp_handle *h, int S, int K, int M,
  * (n (n + 1) / 2 x 64 multiply-adds x 2 per star and launch).                */
 int sp_profile_begin(sp_handle *h, int max_launches);
 int sp_profile_end(sp_handle *h, long *launches, double *total_ms, double *flops);
+/* launch ONE phase (0 diagonal block, 1 panel solve, 2 trailing update) of panel
+ * step j on the systems left in `workspace_dev` by sp_lnlike_ensemble; used by
+ * tools/microbench.py to time the kernels in isolation.                        */
+int sp_debug_cholesky_phase(sp_handle *h, int S, int K, int M, void *workspace_dev,
+                            int phase, int j, void *stream);
 
 #ifdef __cplusplus
 }

@@ -3,6 +3,7 @@
 // kernel sequencing on the caller's stream.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -33,6 +34,8 @@ int sp_launch_assemble(int S, int K, int M, int Kp, int system,
                        double *out, long ldo, long strideo, hipStream_t st);
 int sp_launch_cholesky_systems(sp_handle *h, double *sys, int S, int K, int Kp,
                                int32_t *info, double *invL, hipStream_t st);
+int sp_debug_phase(sp_handle *h, double *sys, int S, int K, int Kp, int32_t *info,
+                   double *invL, int phase, int j, hipStream_t st);
 int sp_launch_lnlike_reduce(const double *sys, int S, int K, int M, int Kp,
                             const int32_t *info, double *lnlike, uint32_t *status,
                             hipStream_t st);
@@ -321,6 +324,7 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
   h->scratch_bytes = 0;
   h->d_tab_scratch = nullptr;
   h->tab_scratch_bytes = 0;
+  h->superpanel = 4;
   h->prof_on = false;
   h->prof_used = 0;
   h->prof_flops = 0.0;
@@ -360,6 +364,11 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
   SP_HIP(hipMemcpy(h->d_mirror, h->mirror.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice));
   SP_HIP(hipMemcpy(h->d_blk, h->blk.data(), sizeof(int32_t) * (ydeg + 2), hipMemcpyHostToDevice));
 
+  {
+    const char *e2 = getenv("SP_SUPER");
+    h->superpanel = e2 ? atoi(e2) : 4;
+    if (h->superpanel < 1) h->superpanel = 1;
+  }
   // Rx(pi/2): the polar-frame rotation every path uses (flux.py:56,61,62,103)
   const double th = 0.5 * M_PI;
   int rc = sp_Rx(h, &th, 1, h->d_Rx90, nullptr, nullptr);
@@ -779,6 +788,19 @@ int sp_lnlike_ensemble(sp_handle *h, int S, int K, int M, const double *t_dev,
     SP_HIP(hipMemcpyAsync(status_dev, status, sizeof(uint32_t) * S,
                           hipMemcpyDeviceToDevice, st));
   return SP_OK;
+}
+
+// micro-benchmark hook (not part of the reference-facing API): one phase of one
+// panel step on the workspace systems of a previous sp_lnlike_ensemble call
+int sp_debug_cholesky_phase(sp_handle *h, int S, int K, int M, void *workspace_dev,
+                            int phase, int j, void *stream) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || !workspace_dev || S < 1 || K < 1 || M < 1 || j < 0 || j * SP_NB >= K)
+    return SP_ERR_INVALID;
+  Layout L = make_layout(h, S, K, M, true);
+  return sp_debug_phase(h, at<double>(workspace_dev, L.sys), S, K, L.Kp,
+                        at<int32_t>(workspace_dev, L.info), at<double>(workspace_dev, L.invL),
+                        phase, j, (hipStream_t)stream);
 }
 
 int sp_cholesky_lnlike_batched(sp_handle *h, int S, int K, int M,

@@ -359,49 +359,105 @@ __global__ __launch_bounds__(256) void cho_solve_kernel(
 
 // ---- launchers ---------------------------------------------------------------
 
+// C[cfrom:, cfrom:] -= X[cfrom:, :] X[cfrom:, :]^T with X = columns c0..c0+kd-1 of the
+// same rows; lower-triangle tiles only.  Timed for bench.py when profiling is on.
+static int bulk_update(sp_handle *h, double *sys, long ld, long stride, int S, int c0,
+                       int cfrom, int Kp, int kd, hipStream_t st) {
+  const int n = Kp - cfrom;
+  double *X = sys + (size_t)cfrom * ld + c0;
+  double *T = sys + (size_t)cfrom * ld + cfrom;
+  const bool timed = h && h->prof_on && h->prof_used + 2 <= h->prof_ev.size();
+  if (timed) SP_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
+  int rc = sp_launch_gemm_nt(X, ld, stride, X, ld, stride, T, ld, stride, n, n, kd, -1.0, 1,
+                             1, S, st);
+  if (rc != SP_OK) return rc;
+  if (timed) {
+    SP_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
+    h->prof_used += 2;
+    // algorithmic work of a symmetric rank-kd update of an n x n block:
+    // n (n + 1) / 2 entries x kd multiply-adds
+    h->prof_flops += (double)S * (double)n * (n + 1) * kd;
+    h->prof_launches += 1;
+  }
+  return SP_OK;
+}
+
+static int diag_and_solve(double *sys, long ld, long stride, int S, int K, int Kp, int j,
+                          int32_t *info, double *invL, hipStream_t st) {
+  const int c0 = j * SP_NB;
+  const int nact = K - c0 < SP_NB ? K - c0 : SP_NB;
+  // diagonal block: L_d and L_d^-1
+  hipLaunchKernelGGL(diag_kernel, dim3(S), dim3(256), 0, st, sys, ld, stride, c0, nact,
+                     invL, info);
+  SP_LAUNCH_CHECK();
+  // rows below the active block: X = P L_d^-T, in place, on the matrix cores
+  const int r1 = c0 + nact;
+  if (r1 < Kp) {
+    double *P = sys + (size_t)r1 * ld + c0;
+    return sp_launch_gemm_nt(P, ld, stride, invL, SP_NB, (long)SP_NB * SP_NB, P, ld, stride,
+                             Kp - r1, SP_NB, SP_NB, 1.0, 0, 0, S, st);
+  }
+  return SP_OK;
+}
+
 // In-place factorisation of S padded systems (Kp x Kp, ld = Kp): the leading
 // K x K part is factored, rows K..Kp-1 only receive the triangular solve.
+//
+// Two-level blocking.  Panels (64 columns) are grouped in super-panels of w
+// panels.  Inside a super-panel a block column is brought up to date
+// left-looking (ONE narrow product over the q previous panels of the group,
+// k = 64 q) just before it is factored; the big trailing matrix is touched once
+// per super-panel with a rank-64w update instead of w rank-64 updates.  The
+// trailing update is HBM-bound at k = 64 (8 flop per byte of C traffic,
+// measured 4.0 TB/s, profiles/r01_*); k = 64 w divides that traffic by w.
 int sp_launch_cholesky_systems(sp_handle *h, double *sys, int S, int K, int Kp,
                                int32_t *info, double *invL, hipStream_t st) {
   const long ld = Kp, stride = (long)Kp * Kp;
   const int nsteps = (K + SP_NB - 1) / SP_NB;
-  for (int j = 0; j < nsteps; ++j) {
-    const int c0 = j * SP_NB;
-    const int nact = K - c0 < SP_NB ? K - c0 : SP_NB;
-    // (1) diagonal block: L_d and L_d^-1
-    hipLaunchKernelGGL(diag_kernel, dim3(S), dim3(256), 0, st, sys, ld, stride, c0,
-                       nact, invL, info);
-    SP_LAUNCH_CHECK();
-    // (2) rows below the active block: X = P L_d^-T, in place, on the matrix cores
-    const int r1 = c0 + nact;
-    if (r1 < Kp) {
-      double *P = sys + (size_t)r1 * ld + c0;
-      int rc = sp_launch_gemm_nt(P, ld, stride, invL, SP_NB, (long)SP_NB * SP_NB, P, ld,
-                                 stride, Kp - r1, SP_NB, SP_NB, 1.0, 0, 0, S, st);
+  const int w = (h && h->superpanel > 0) ? h->superpanel : 1;
+  for (int s0 = 0; s0 < nsteps; s0 += w) {
+    const int cS = s0 * SP_NB;
+    for (int q = 0; q < w && s0 + q < nsteps; ++q) {
+      const int j = s0 + q, c0 = j * SP_NB;
+      if (q > 0) {  // left-looking update of block column j by panels s0..j-1
+        double *A = sys + (size_t)c0 * ld + cS;
+        double *T = sys + (size_t)c0 * ld + c0;
+        int rc = sp_launch_gemm_nt(A, ld, stride, A, ld, stride, T, ld, stride, Kp - c0,
+                                   SP_NB, q * SP_NB, -1.0, 1, 0, S, st);
+        if (rc != SP_OK) return rc;
+      }
+      int rc = diag_and_solve(sys, ld, stride, S, K, Kp, j, info, invL, st);
       if (rc != SP_OK) return rc;
     }
-    // (3) trailing update C -= X X^T, lower-triangle tiles
-    const int c1 = c0 + SP_NB;
-    if (c1 < K) {
-      const int n = Kp - c1;
-      double *X = sys + (size_t)c1 * ld + c0;
-      double *T = sys + (size_t)c1 * ld + c1;
-      const bool timed = h && h->prof_on && h->prof_used + 2 <= h->prof_ev.size();
-      if (timed) SP_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
-      int rc = sp_launch_gemm_nt(X, ld, stride, X, ld, stride, T, ld, stride, n, n,
-                                 SP_NB, -1.0, 1, 1, S, st);
+    const int cE = (s0 + w) * SP_NB;
+    if (cE < K) {
+      int rc = bulk_update(h, sys, ld, stride, S, cS, cE, Kp, w * SP_NB, st);
       if (rc != SP_OK) return rc;
-      if (timed) {
-        SP_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
-        h->prof_used += 2;
-        // algorithmic work of a symmetric rank-64 update of an n x n block:
-        // n (n + 1) / 2 entries x 64 multiply-adds
-        h->prof_flops += (double)S * (double)n * (n + 1) * SP_NB;
-        h->prof_launches += 1;
-      }
     }
   }
   return SP_OK;
+}
+
+// Micro-benchmark hook: launch ONE phase of panel step j on `st`.
+// phase 0 = diagonal block, 1 = panel solve, 2 = rank-64 trailing update.
+int sp_debug_phase(sp_handle *h, double *sys, int S, int K, int Kp, int32_t *info,
+                   double *invL, int phase, int j, hipStream_t st) {
+  const long ld = Kp, stride = (long)Kp * Kp;
+  const int c0 = j * SP_NB;
+  const int nact = K - c0 < SP_NB ? K - c0 : SP_NB;
+  if (phase == 0) {
+    hipLaunchKernelGGL(diag_kernel, dim3(S), dim3(256), 0, st, sys, ld, stride, c0, nact,
+                       invL, info);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+  }
+  if (phase == 1) {
+    const int r1 = c0 + nact;
+    double *P = sys + (size_t)r1 * ld + c0;
+    return sp_launch_gemm_nt(P, ld, stride, invL, SP_NB, (long)SP_NB * SP_NB, P, ld, stride,
+                             Kp - r1, SP_NB, SP_NB, 1.0, 0, 0, S, st);
+  }
+  return bulk_update(nullptr, sys, ld, stride, S, c0, c0 + SP_NB, Kp, SP_NB, st);
 }
 
 int sp_launch_lnlike_reduce(const double *sys, int S, int K, int M, int Kp,

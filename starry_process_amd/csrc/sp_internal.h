@@ -42,6 +42,7 @@ struct sp_handle {
   size_t scratch_bytes;
   double *d_tab_scratch;        // [ntab][2][N] row reductions of the kernel table
   size_t tab_scratch_bytes;
+  int superpanel;               // panels per super-panel (SP_SUPER, default 4)
   // optional per-launch timing of the trailing-update kernel (bench roofline)
   bool prof_on;
   std::vector<hipEvent_t> prof_ev;   // pairs (start, stop)
