@@ -126,6 +126,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         total = step()
+    host_enqueue = time.perf_counter() - t0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -168,6 +169,7 @@ def main():
                 "stars_per_gpu": S, "ydeg": YDEG, "K": K, "parallelism": "stars sharded %d-way" % world,
             },
             "parity_ok": ok,
+            "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
             "roofline": {
                 "kernel": "gemm_nt_kernel (Cholesky trailing update, v_mfma_f64_16x16x4_f64)",
                 "bound": "mfma",

@@ -34,6 +34,8 @@ int sp_launch_assemble(int S, int K, int M, int Kp, int system,
                        double *out, long ldo, long strideo, hipStream_t st);
 int sp_launch_cholesky_systems(sp_handle *h, double *sys, int S, int K, int Kp,
                                int32_t *info, double *invL, hipStream_t st);
+int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *grp, int K,
+                              int Kp);
 int sp_debug_phase(sp_handle *h, double *sys, int S, int K, int Kp, int32_t *info,
                    double *invL, int phase, int j, hipStream_t st);
 int sp_launch_lnlike_reduce(const double *sys, int S, int K, int M, int Kp,
@@ -282,6 +284,87 @@ int build_conditional_raw(sp_handle *h, const Layout &L, void *ws, hipStream_t s
 
 }  // namespace
 
+namespace {
+
+// the same layout seen by the stars s0 .. s0+Sg-1 only
+Layout sub_layout(const Layout &L, int s0, int Sg) {
+  Layout G = L;
+  const size_t d = sizeof(double), z = (size_t)s0;
+  G.S = Sg;
+  G.theta += z * L.K * d;
+  G.rowsum += z * L.K * d;
+  G.qv += z * L.K * d;
+  G.coef += z * 8 * d;
+  G.info += z * sizeof(int32_t);
+  G.status += z * sizeof(uint32_t);
+  G.condmean += z * d;
+  G.cs += z * 2 * d;
+  G.vrow += z * L.N * d;
+  G.Rinc += z * L.NWIG * d;
+  G.invL += z * SP_NB * SP_NB * d;
+  G.A += z * L.K * L.N * d;
+  G.B1 += z * L.K * L.N * d;
+  G.raw += z * (size_t)L.K * L.K * d;
+  G.sys += z * (size_t)L.Kp * L.Kp * d;
+  return G;
+}
+
+// stage A: everything up to the assembled systems, for one group on its stream
+int lnlike_assemble(sp_handle *h, const Layout &L, void *ws, int K, int M, const double *t_dev,
+                    const double *flux_dev, const double *diag_dev, const sp_star *stars_dev,
+                    int conditional, int covpts, const double *tab_dev,
+                    const double *meanvar_dev, const double *rta1_dev, int temporal,
+                    int normalized, int norm_order, double zmax, hipStream_t st) {
+  const int S = L.S;
+  double *theta = at<double>(ws, L.theta), *rowsum = at<double>(ws, L.rowsum);
+  double *qv = at<double>(ws, L.qv), *coef = at<double>(ws, L.coef);
+  double *raw = at<double>(ws, L.raw), *cm = at<double>(ws, L.condmean);
+  double *sys = at<double>(ws, L.sys);
+  int32_t *info = at<int32_t>(ws, L.info);
+  uint32_t *status = at<uint32_t>(ws, L.status);
+  int rc;
+  SP_HIP(hipMemsetAsync(info, 0, sizeof(int32_t) * S, st));
+  SP_HIP(hipMemsetAsync(status, 0, sizeof(uint32_t) * S, st));
+  if ((rc = sp_launch_theta(S, K, t_dev, stars_dev, theta, st))) return rc;
+  const double *rawp = nullptr;
+  const double *condmean = nullptr;
+  if (conditional) {
+    if ((rc = build_design(h, L, ws, stars_dev, rta1_dev, at<double>(ws, L.A), st)))
+      return rc;
+    if ((rc = build_conditional_raw(h, L, ws, st))) return rc;
+    rawp = raw;
+    condmean = cm;
+  }
+  const int cp = conditional ? 1 : covpts;
+  if (normalized)
+    if ((rc = sp_launch_rowsum(S, K, theta, t_dev, stars_dev, cp, tab_dev, meanvar_dev,
+                               h->d_xp, temporal, rawp, rowsum, st)))
+      return rc;
+  if ((rc = sp_launch_norm_coef(S, K, stars_dev, meanvar_dev, condmean, normalized,
+                                norm_order, zmax, rowsum, qv, coef, status, st)))
+    return rc;
+  return sp_launch_assemble(S, K, M, L.Kp, 1, theta, t_dev, stars_dev, cp, tab_dev,
+                            meanvar_dev, h->d_xp, temporal, rawp, normalized, qv, coef,
+                            diag_dev, 1, flux_dev, sys, L.Kp, (long)L.Kp * L.Kp, st);
+}
+
+// stage C: reduction of one group's factored systems
+int lnlike_finish(const Layout &L, void *ws, int K, int M, double *lnlike_dev,
+                  uint32_t *status_dev, hipStream_t st) {
+  const int S = L.S;
+  int rc;
+  uint32_t *status = at<uint32_t>(ws, L.status);
+  if ((rc = sp_launch_lnlike_reduce(at<double>(ws, L.sys), S, K, M, L.Kp,
+                                    at<int32_t>(ws, L.info), lnlike_dev, status, st)))
+    return rc;
+  if (status_dev)
+    SP_HIP(hipMemcpyAsync(status_dev, status, sizeof(uint32_t) * S, hipMemcpyDeviceToDevice,
+                          st));
+  return SP_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 const char *sp_last_hip_error(void) { return g_hip_err; }
@@ -325,6 +408,8 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
   h->d_tab_scratch = nullptr;
   h->tab_scratch_bytes = 0;
   h->superpanel = 4;
+  h->groups = 2;
+  h->gfork = nullptr;
   h->prof_on = false;
   h->prof_used = 0;
   h->prof_flops = 0.0;
@@ -365,6 +450,8 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
   SP_HIP(hipMemcpy(h->d_blk, h->blk.data(), sizeof(int32_t) * (ydeg + 2), hipMemcpyHostToDevice));
 
   {
+    const char *e3 = getenv("SP_GROUPS");
+    h->groups = e3 ? atoi(e3) : 2;
     const char *e2 = getenv("SP_SUPER");
     h->superpanel = e2 ? atoi(e2) : 4;
     if (h->superpanel < 1) h->superpanel = 1;
@@ -393,6 +480,9 @@ void sp_destroy(sp_handle *h) {
                   h->d_wnp,  h->d_Wnp,    h->d_mean_ylm, h->d_cov_ylm, h->d_ez,
                   h->d_Ez,   h->d_tmpNN,  h->d_scratch, h->d_xp, h->d_tab_scratch};
   for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->gdone) (void)hipEventDestroy(e);
+  for (hipStream_t s2 : h->gstream) (void)hipStreamDestroy(s2);
+  if (h->gfork) (void)hipEventDestroy(h->gfork);
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   delete h;
@@ -749,44 +839,61 @@ int sp_lnlike_ensemble(sp_handle *h, int S, int K, int M, const double *t_dev,
   hipStream_t st = (hipStream_t)stream;
   Layout L = make_layout(h, S, K, M, true);
   void *ws = workspace_dev;
-  double *theta = at<double>(ws, L.theta), *rowsum = at<double>(ws, L.rowsum);
-  double *qv = at<double>(ws, L.qv), *coef = at<double>(ws, L.coef);
-  double *raw = at<double>(ws, L.raw), *cm = at<double>(ws, L.condmean);
-  double *sys = at<double>(ws, L.sys);
-  int32_t *info = at<int32_t>(ws, L.info);
-  uint32_t *status = at<uint32_t>(ws, L.status);
-  int rc;
-  SP_HIP(hipMemsetAsync(info, 0, sizeof(int32_t) * S, st));
-  SP_HIP(hipMemsetAsync(status, 0, sizeof(uint32_t) * S, st));
-  if ((rc = sp_launch_theta(S, K, t_dev, stars_dev, theta, st))) return rc;
-  const double *rawp = nullptr;
-  const double *condmean = nullptr;
-  if (conditional) {
-    if ((rc = build_design(h, L, ws, stars_dev, rta1_dev, at<double>(ws, L.A), st)))
-      return rc;
-    if ((rc = build_conditional_raw(h, L, ws, st))) return rc;
-    rawp = raw;
-    condmean = cm;
+  // Star groups on concurrent streams: the diagonal-block kernel
+  // is a latency-bound chain that occupies 1/4 of the CUs with one wavefront
+  // each; with G groups in flight one group's GEMMs fill the machine while
+  // another group sits in its chain.  No event traffic inside the loop: one fork
+  // and one join per call.
+  int G = h->groups;
+  if (G > S / 8) G = S / 8;  // keep groups large enough to fill the matrix cores
+  if (G < 1) G = 1;
+  if (G > 1) {
+    while ((int)h->gstream.size() < G - 1) {
+      hipStream_t s2;
+      hipEvent_t e2;
+      SP_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+      SP_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+      h->gstream.push_back(s2);
+      h->gdone.push_back(e2);
+    }
+    if (!h->gfork) SP_HIP(hipEventCreateWithFlags(&h->gfork, hipEventDisableTiming));
+    SP_HIP(hipEventRecord(h->gfork, st));
   }
-  const int cp = conditional ? 1 : covpts;
-  if (normalized)
-    if ((rc = sp_launch_rowsum(S, K, theta, t_dev, stars_dev, cp, tab_dev, meanvar_dev,
-                               h->d_xp, temporal, rawp, rowsum, st)))
-      return rc;
-  if ((rc = sp_launch_norm_coef(S, K, stars_dev, meanvar_dev, condmean, normalized,
-                                norm_order, zmax, rowsum, qv, coef, status, st)))
-    return rc;
-  if ((rc = sp_launch_assemble(S, K, M, L.Kp, 1, theta, t_dev, stars_dev, cp, tab_dev,
-                               meanvar_dev, h->d_xp, temporal, rawp, normalized, qv,
-                               coef, diag_dev, 1, flux_dev, sys, L.Kp,
-                               (long)L.Kp * L.Kp, st)))
-    return rc;
-  if ((rc = sp_launch_cholesky_systems(h, sys, S, K, L.Kp, info, at<double>(ws, L.invL), st))) return rc;
-  if ((rc = sp_launch_lnlike_reduce(sys, S, K, M, L.Kp, info, lnlike_dev, status, st)))
-    return rc;
-  if (status_dev)
-    SP_HIP(hipMemcpyAsync(status_dev, status, sizeof(uint32_t) * S,
-                          hipMemcpyDeviceToDevice, st));
+  std::vector<Layout> LG(G, L);
+  std::vector<sp_chol_group> CG(G);
+  std::vector<int> first(G);
+  for (int g = 0; g < G; ++g) {
+    const int s0 = (int)((long)S * g / G), s1 = (int)((long)S * (g + 1) / G);
+    first[g] = s0;
+    LG[g] = sub_layout(L, s0, s1 - s0);
+    hipStream_t sg = g == 0 ? st : h->gstream[g - 1];
+    if (g > 0) SP_HIP(hipStreamWaitEvent(sg, h->gfork, 0));
+    CG[g] = sp_chol_group{at<double>(ws, LG[g].sys), at<int32_t>(ws, LG[g].info),
+                          at<double>(ws, LG[g].invL), s1 - s0, sg};
+  }
+  for (int g = 0; g < G; ++g) {
+    const int s0 = first[g];
+    int rc = lnlike_assemble(h, LG[g], ws, K, M, t_dev + (size_t)s0 * K,
+                             flux_dev + (size_t)s0 * M * K,
+                             diag_dev ? diag_dev + (size_t)s0 * K : nullptr, stars_dev + s0,
+                             conditional, covpts, tab_dev, meanvar_dev, rta1_dev, temporal,
+                             normalized, norm_order, zmax, CG[g].st);
+    if (rc) return rc;
+  }
+  {
+    int rc = sp_launch_cholesky_groups(h, G, CG.data(), K, L.Kp);
+    if (rc) return rc;
+  }
+  for (int g = 0; g < G; ++g) {
+    const int s0 = first[g];
+    int rc = lnlike_finish(LG[g], ws, K, M, lnlike_dev + s0,
+                           status_dev ? status_dev + s0 : nullptr, CG[g].st);
+    if (rc) return rc;
+    if (g > 0) {
+      SP_HIP(hipEventRecord(h->gdone[g - 1], CG[g].st));
+      SP_HIP(hipStreamWaitEvent(st, h->gdone[g - 1], 0));
+    }
+  }
   return SP_OK;
 }
 

@@ -104,38 +104,39 @@ __global__ __launch_bounds__(256) void diag_kernel(double *__restrict__ sys, lon
   for (int kb = 0; kb < 4; ++kb) {
     const int o = 16 * kb;
     if (wave == 0) {
-      // leaf Cholesky, lane (< 16) = row of the 16 x 16 block
-      double x[16], rinv = 1.0;
-      const int row = lane & 15;
+      // Leaf Cholesky AND leaf inverse on the matrix core, one column at a time.
+      // The (symmetric, fully stored) 16 x 16 leaf sits in ONE accumulator tile:
+      // lane (fk, fr) holds rows fk + 4 q, column fr.  By symmetry row c = column
+      // c, and row c is held by the 16 lanes of group fk = c & 3 in register
+      // q = c >> 2 -- exactly the operand slot k = fk of v_mfma_f64_16x16x4, so
+      //   A <- A - l l^T         (l = column c of L)          needs no lane traffic:
+      // lanes of that group pass l, every other lane passes 0.  The inverse rides
+      // along: L = L_0 L_1 .. L_15 with L_c = I + (l_c - e_c) e_c^T, hence
+      //   Y <- Y - u_c (e_c^T Y),  u_c = (l_c - e_c) / l_cc,   Y_0 = I
+      // ends at Y = L^-1; e_c^T Y is again "row c", same operand slot.
+      const int fr = lane & 15, fk = lane >> 4;
+      d4 Am, Ym;
 #pragma unroll
-      for (int c = 0; c < 16; ++c) x[c] = sA[(o + row) * BLD + o + c];
+      for (int q = 0; q < 4; ++q) {
+        const int row = fk + 4 * q;
+        Am[q] = fr <= row ? sA[(o + row) * BLD + o + fr] : sA[(o + fr) * BLD + o + row];
+        Ym[q] = row == fr ? 1.0 : 0.0;
+      }
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        const double piv = read_lane(x[c], c);
+        const int g = c & 3, q = c >> 2;
+        const double piv = read_lane(Am[q], 16 * g + c);
         if (!(piv > 0.0)) notpd = 1;
         const double r = rsqrt_nr(piv);
-        if (row == c) rinv = r;
-        x[c] = (row == c) ? piv * r : x[c] * r;
-#pragma unroll
-        for (int k = c + 1; k < 16; ++k) x[k] -= x[c] * read_lane(x[c], k);
+        const bool act = (fk == g) && (fr >= c);
+        const double l = act ? Am[q] * r : 0.0;           // l_{fr,c}; fr == c: sqrt(piv)
+        const double u = act ? (fr == c ? 1.0 - r : l * r) : 0.0;
+        const double yrow = (fk == g) ? Ym[q] : 0.0;      // row c of Y
+        if (act) sA[(o + fr) * BLD + o + c] = l;
+        Am = __builtin_amdgcn_mfma_f64_16x16x4f64(-l, l, Am, 0, 0, 0);
+        Ym = __builtin_amdgcn_mfma_f64_16x16x4f64(-u, yrow, Ym, 0, 0, 0);
       }
-      // leaf inverse, lane (< 16) = column j: solve L y = e_j
-      double y[16];
-      const int j = lane & 15;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        double sacc = (i == j) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < i; ++k) sacc -= read_lane(x[k], i) * y[k];
-        y[i] = sacc * read_lane(rinv, i);
-      }
-      if (lane < 16) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          if (c <= row) sA[(o + row) * BLD + o + c] = x[c];
-          sI[(o + c) * BLD + o + j] = y[c];  // y[c] = (L^-1)[c][j], zero above the diagonal
-        }
-      }
+      acc_store(sI, o, o, lane, Ym);
     }
     __syncthreads();
     // sub-diagonal blocks of this block column: L_ik = A_ik . (L_kk^-1)^T
@@ -410,32 +411,45 @@ static int diag_and_solve(double *sys, long ld, long stride, int S, int K, int K
 // per super-panel with a rank-64w update instead of w rank-64 updates.  The
 // trailing update is HBM-bound at k = 64 (8 flop per byte of C traffic,
 // measured 4.0 TB/s, profiles/r01_*); k = 64 w divides that traffic by w.
-int sp_launch_cholesky_systems(sp_handle *h, double *sys, int S, int K, int Kp,
-                               int32_t *info, double *invL, hipStream_t st) {
+int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *grp, int K,
+                              int Kp) {
   const long ld = Kp, stride = (long)Kp * Kp;
   const int nsteps = (K + SP_NB - 1) / SP_NB;
   const int w = (h && h->superpanel > 0) ? h->superpanel : 1;
+  // launches are issued breadth-first over the groups so that the groups'
+  // streams advance together (the host enqueues ~3-8 us per launch)
   for (int s0 = 0; s0 < nsteps; s0 += w) {
     const int cS = s0 * SP_NB;
     for (int q = 0; q < w && s0 + q < nsteps; ++q) {
       const int j = s0 + q, c0 = j * SP_NB;
-      if (q > 0) {  // left-looking update of block column j by panels s0..j-1
-        double *A = sys + (size_t)c0 * ld + cS;
-        double *T = sys + (size_t)c0 * ld + c0;
-        int rc = sp_launch_gemm_nt(A, ld, stride, A, ld, stride, T, ld, stride, Kp - c0,
-                                   SP_NB, q * SP_NB, -1.0, 1, 0, S, st);
+      for (int g = 0; g < ngroups; ++g) {
+        const sp_chol_group &G = grp[g];
+        if (q > 0) {  // left-looking update of block column j by panels s0..j-1
+          double *A = G.sys + (size_t)c0 * ld + cS;
+          double *T = G.sys + (size_t)c0 * ld + c0;
+          int rc = sp_launch_gemm_nt(A, ld, stride, A, ld, stride, T, ld, stride, Kp - c0,
+                                     SP_NB, q * SP_NB, -1.0, 1, 0, G.S, G.st);
+          if (rc != SP_OK) return rc;
+        }
+        int rc = diag_and_solve(G.sys, ld, stride, G.S, K, Kp, j, G.info, G.invL, G.st);
         if (rc != SP_OK) return rc;
       }
-      int rc = diag_and_solve(sys, ld, stride, S, K, Kp, j, info, invL, st);
-      if (rc != SP_OK) return rc;
     }
     const int cE = (s0 + w) * SP_NB;
-    if (cE < K) {
-      int rc = bulk_update(h, sys, ld, stride, S, cS, cE, Kp, w * SP_NB, st);
-      if (rc != SP_OK) return rc;
-    }
+    if (cE < K)
+      for (int g = 0; g < ngroups; ++g) {
+        int rc = bulk_update(h, grp[g].sys, ld, stride, grp[g].S, cS, cE, Kp, w * SP_NB,
+                             grp[g].st);
+        if (rc != SP_OK) return rc;
+      }
   }
   return SP_OK;
+}
+
+int sp_launch_cholesky_systems(sp_handle *h, double *sys, int S, int K, int Kp,
+                               int32_t *info, double *invL, hipStream_t st) {
+  sp_chol_group g{sys, info, invL, S, st};
+  return sp_launch_cholesky_groups(h, 1, &g, K, Kp);
 }
 
 // Micro-benchmark hook: launch ONE phase of panel step j on `st`.

@@ -43,6 +43,10 @@ struct sp_handle {
   double *d_tab_scratch;        // [ntab][2][N] row reductions of the kernel table
   size_t tab_scratch_bytes;
   int superpanel;               // panels per super-panel (SP_SUPER, default 4)
+  int groups;                   // concurrent star groups (SP_GROUPS, default 2)
+  std::vector<hipStream_t> gstream;
+  std::vector<hipEvent_t> gdone;
+  hipEvent_t gfork;
   // optional per-launch timing of the trailing-update kernel (bench roofline)
   bool prof_on;
   std::vector<hipEvent_t> prof_ev;   // pairs (start, stop)
@@ -75,6 +79,15 @@ static inline int sp_nwig_of(int l) {
   return ((l + 1) * (2 * l + 1) * (2 * l + 3)) / 3;
 }
 static inline int sp_roundup(int x, int m) { return ((x + m - 1) / m) * m; }
+
+// one group of stars factored on its own stream
+struct sp_chol_group {
+  double *sys;
+  int32_t *info;
+  double *invL;
+  int S;
+  hipStream_t st;
+};
 
 // host-side constant builders (sp_host.cpp)
 void sp_build_index_tables(int ydeg, int32_t *l_of, int32_t *m_of,
