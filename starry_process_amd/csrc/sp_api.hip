@@ -409,6 +409,7 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
   h->tab_scratch_bytes = 0;
   h->superpanel = 4;
   h->groups = 2;
+  h->fuse_diag = 2;
   h->gfork = nullptr;
   h->prof_on = false;
   h->prof_used = 0;
@@ -450,6 +451,8 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
   SP_HIP(hipMemcpy(h->d_blk, h->blk.data(), sizeof(int32_t) * (ydeg + 2), hipMemcpyHostToDevice));
 
   {
+    const char *e4 = getenv("SP_FUSE_DIAG");
+    h->fuse_diag = e4 ? atoi(e4) : 2;  // 0 off, 1 block-column updates, 2 + bulk updates
     const char *e3 = getenv("SP_GROUPS");
     h->groups = e3 ? atoi(e3) : 2;
     const char *e2 = getenv("SP_SUPER");

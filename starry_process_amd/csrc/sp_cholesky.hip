@@ -1,11 +1,12 @@
 // Batched fp64 Cholesky, triangular solves and the likelihood reduction
 //  for gfx950.
 //
-// Right-looking blocked factorisation, panels of SP_NB = 64 columns:
-//   panel_kernel   factors the 64x64 diagonal block in LDS and solves the rows
-//                  below it (X L_d^T = P), 256 rows per workgroup;
-//   sp_launch_gemm_nt (sp_gemm.hip) applies the trailing update C -= X X^T on
-//                  the matrix cores, lower-triangle tiles only.
+// Blocked factorisation, panels of SP_NB = 64 columns (driver:
+// sp_launch_cholesky_groups below):
+//   diag_block (sp_diag.h)  factors the 64x64 diagonal block and forms L_d^-1;
+//   sp_launch_gemm_nt (sp_gemm.hip) does everything else on the matrix cores:
+//                  the panel solve X = P L_d^-T, the left-looking block-column
+//                  updates and the rank-64w trailing updates.
 // The systems are padded to a multiple of 64 rows and carry the residual
 // vectors as EXTRA ROWS below the matrix: factoring
 //     [ C   . ]          gives          [ L   . ]
@@ -14,72 +15,23 @@
 // triangular solve is needed for the likelihood.
 #include "sp_internal.h"
 
-#define DLD 65  // padded row length of the diagonal block in LDS
+#include "sp_diag.h"
+
+#define DLD 65  // padded row length of a diagonal block in cho_solve_kernel
 
 namespace {
 
-typedef double d4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ double read_lane(double v, int l) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-  return __hiloint2double(hi, lo);
-}
-
-// 1/sqrt(p) to ~1 ulp: hardware seed (v_rsq_f64) + two Newton steps
-__device__ __forceinline__ double rsqrt_nr(double p) {
-  double r = __builtin_amdgcn_rsq(p);
-  double e = fma(-p * r, r, 1.0);
-  r = fma(0.5 * r, e, r);
-  e = fma(-p * r, r, 1.0);
-  r = fma(0.5 * r, e, r);
-  return r;
-}
-
-// ---- diagonal-block kernel ----------------------------------------------------
-// One workgroup (4 wavefronts) per star factors the 64 x 64 diagonal block
-// A = L L^T and also forms L^-1, so that the panel below it becomes a plain
-// product X = P L^-T on the matrix cores (sp_gemm.hip).  The block is processed
-// as 4 x 4 sub-blocks of 16 x 16:
-//   leaf   : wavefront 0, lane = row, 16-column right-looking sweep with
-//            v_readlane broadcasts (no LDS, no barriers inside), followed by
-//            the 16 x 16 triangular inverse, lane = column;
-//   updates: v_mfma_f64_16x16x4_f64 on LDS-resident operands, sub-blocks
-//            spread over the four wavefronts.
-// LDS rows are padded to 66 doubles (132 dwords = 4 mod 64 banks): the MFMA
-// operand reads (16 rows x 2 k per 32-lane half) are conflict free.
-#define BLD 66
-
-// a-operand / NT b-operand fragment: M[row0 + (lane & 15)][col0 + 4 s + (lane >> 4)]
-__device__ __forceinline__ double frag_rowmajor(const double *M, int row0, int col0,
-                                                int s, int lane) {
-  return M[(row0 + (lane & 15)) * BLD + col0 + 4 * s + (lane >> 4)];
-}
-// NN b-operand fragment: M[row0 + 4 s + (lane >> 4)][col0 + (lane & 15)]
-__device__ __forceinline__ double frag_kmajor(const double *M, int row0, int col0,
-                                              int s, int lane) {
-  return M[(row0 + 4 * s + (lane >> 4)) * BLD + col0 + (lane & 15)];
-}
-// accumulator <-> LDS, C/D map of the fp64 MFMA: col = lane & 15, row = (lane >> 4) + 4 reg
-__device__ __forceinline__ d4 acc_load(const double *M, int row0, int col0, int lane) {
-  d4 v;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] = M[(row0 + (lane >> 4) + 4 * r) * BLD + col0 + (lane & 15)];
-  return v;
-}
-__device__ __forceinline__ void acc_store(double *M, int row0, int col0, int lane, d4 v) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r) M[(row0 + (lane >> 4) + 4 * r) * BLD + col0 + (lane & 15)] = v[r];
-}
-
+// Stand-alone diagonal-block kernel: one workgroup per star (used for the first
+// panel of every super-panel; the other panels get their diagonal block from the
+// fused tile-(0,0) workgroup of the block-column update, sp_gemm.hip).
 __global__ __launch_bounds__(256) void diag_kernel(double *__restrict__ sys, long ld,
                                                    long stride, int c0, int nact,
                                                    double *__restrict__ invL_all,
                                                    int32_t *__restrict__ info) {
-  __shared__ __attribute__((aligned(16))) double sA[64 * BLD];  // block, becomes L
-  __shared__ __attribute__((aligned(16))) double sI[64 * BLD];  // L^-1
+  __shared__ __attribute__((aligned(16))) double lds[SP_DIAG_LDS_DOUBLES];
+  double *sD = lds, *sY = lds + 64 * BLD;
   double *Mx = sys + (size_t)blockIdx.x * stride;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   // stage the block; outside the active nact x nact part use the identity so a
   // partial last panel factors as diag(L_act, I)
   {
@@ -93,105 +45,14 @@ __global__ __launch_bounds__(256) void diag_kernel(double *__restrict__ sys, lon
         const int c = cj + e;
         double v = (r < nact && c < nact) ? src[e] : (r == c ? 1.0 : 0.0);
         if (c > r) v = 0.0;
-        sA[r * BLD + c] = v;
-        sI[r * BLD + c] = 0.0;
+        sD[r * BLD + c] = v;
       }
     }
   }
   __syncthreads();
-  int notpd = 0;
-#pragma unroll 1
-  for (int kb = 0; kb < 4; ++kb) {
-    const int o = 16 * kb;
-    if (wave == 0) {
-      // Leaf Cholesky AND leaf inverse on the matrix core, one column at a time.
-      // The (symmetric, fully stored) 16 x 16 leaf sits in ONE accumulator tile:
-      // lane (fk, fr) holds rows fk + 4 q, column fr.  By symmetry row c = column
-      // c, and row c is held by the 16 lanes of group fk = c & 3 in register
-      // q = c >> 2 -- exactly the operand slot k = fk of v_mfma_f64_16x16x4, so
-      //   A <- A - l l^T         (l = column c of L)          needs no lane traffic:
-      // lanes of that group pass l, every other lane passes 0.  The inverse rides
-      // along: L = L_0 L_1 .. L_15 with L_c = I + (l_c - e_c) e_c^T, hence
-      //   Y <- Y - u_c (e_c^T Y),  u_c = (l_c - e_c) / l_cc,   Y_0 = I
-      // ends at Y = L^-1; e_c^T Y is again "row c", same operand slot.
-      const int fr = lane & 15, fk = lane >> 4;
-      d4 Am, Ym;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int row = fk + 4 * q;
-        Am[q] = fr <= row ? sA[(o + row) * BLD + o + fr] : sA[(o + fr) * BLD + o + row];
-        Ym[q] = row == fr ? 1.0 : 0.0;
-      }
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const int g = c & 3, q = c >> 2;
-        const double piv = read_lane(Am[q], 16 * g + c);
-        if (!(piv > 0.0)) notpd = 1;
-        const double r = rsqrt_nr(piv);
-        const bool act = (fk == g) && (fr >= c);
-        const double l = act ? Am[q] * r : 0.0;           // l_{fr,c}; fr == c: sqrt(piv)
-        const double u = act ? (fr == c ? 1.0 - r : l * r) : 0.0;
-        const double yrow = (fk == g) ? Ym[q] : 0.0;      // row c of Y
-        if (act) sA[(o + fr) * BLD + o + c] = l;
-        Am = __builtin_amdgcn_mfma_f64_16x16x4f64(-l, l, Am, 0, 0, 0);
-        Ym = __builtin_amdgcn_mfma_f64_16x16x4f64(-u, yrow, Ym, 0, 0, 0);
-      }
-      acc_store(sI, o, o, lane, Ym);
-    }
-    __syncthreads();
-    // sub-diagonal blocks of this block column: L_ik = A_ik . (L_kk^-1)^T
-    if (wave > kb) {
-      const int ib = wave;
-      d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(frag_rowmajor(sA, 16 * ib, o, s, lane),
-                                                   frag_rowmajor(sI, o, o, s, lane), acc, 0, 0, 0);
-      acc_store(sA, 16 * ib, o, lane, acc);
-    }
-    __syncthreads();
-    // trailing sub-blocks: A_ij -= L_ik L_jk^T, kb < jb <= ib
-    {
-      int q = 0;
-      for (int ib = kb + 1; ib < 4; ++ib)
-        for (int jb = kb + 1; jb <= ib; ++jb, ++q) {
-          if ((q & 3) != wave) continue;
-          d4 acc = acc_load(sA, 16 * ib, 16 * jb, lane);
-#pragma unroll
-          for (int s = 0; s < 4; ++s)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-frag_rowmajor(sA, 16 * ib, o, s, lane),
-                                                       frag_rowmajor(sA, 16 * jb, o, s, lane), acc, 0, 0, 0);
-          acc_store(sA, 16 * ib, 16 * jb, lane, acc);
-        }
-    }
-    __syncthreads();
-  }
-  // off-diagonal blocks of L^-1: X_ij = -(L_ii^-1) sum_{k=j}^{i-1} L_ik X_kj,
-  // block column j on wavefront j, rows i in sequence
-#pragma unroll 1
-  for (int i = 1; i < 4; ++i) {
-    if (wave < i) {
-      const int j = wave;
-      d4 t = {0.0, 0.0, 0.0, 0.0};
-      for (int k = j; k < i; ++k)
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-          t = __builtin_amdgcn_mfma_f64_16x16x4f64(frag_rowmajor(sA, 16 * i, 16 * k, s, lane),
-                                                   frag_kmajor(sI, 16 * k, 16 * j, s, lane), t, 0, 0, 0);
-      // t[s] = T[4 s + (lane >> 4)][lane & 15] is exactly the k-major operand of step s
-      d4 xacc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-        xacc = __builtin_amdgcn_mfma_f64_16x16x4f64(-frag_rowmajor(sI, 16 * i, 16 * i, s, lane),
-                                                    t[s], xacc, 0, 0, 0);
-      acc_store(sI, 16 * i, 16 * j, lane, xacc);
-    }
-    __syncthreads();
-  }
-  // write back L (active lower part) and the full L^-1 tile
+  const int notpd = diag_block(sD, sY, invL_all + (size_t)blockIdx.x * 4096);
+  if (notpd && info) info[blockIdx.x] = 1;
   {
-    if (tid == 0 && notpd && info) info[blockIdx.x] = 1;
-    double *inv = invL_all + (size_t)blockIdx.x * 4096;
     const int cj = (tid & 15) * 4, ri = tid >> 4;
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
@@ -200,8 +61,7 @@ __global__ __launch_bounds__(256) void diag_kernel(double *__restrict__ sys, lon
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int c = cj + e;
-        if (c <= r && r < nact) dst[e] = sA[r * BLD + c];
-        inv[r * 64 + c] = sI[r * BLD + c];
+        if (c <= r && r < nact) dst[e] = sD[r * BLD + c];
       }
     }
   }
@@ -363,14 +223,20 @@ __global__ __launch_bounds__(256) void cho_solve_kernel(
 // C[cfrom:, cfrom:] -= X[cfrom:, :] X[cfrom:, :]^T with X = columns c0..c0+kd-1 of the
 // same rows; lower-triangle tiles only.  Timed for bench.py when profiling is on.
 static int bulk_update(sp_handle *h, double *sys, long ld, long stride, int S, int c0,
-                       int cfrom, int Kp, int kd, hipStream_t st) {
+                       int cfrom, int Kp, int kd, hipStream_t st, int fuse_nact = 0,
+                       double *invL = nullptr, int32_t *info = nullptr) {
+  // fuse_nact > 0: tile (0, 0) is the diagonal block of the next panel and its
+  // workgroup factors it on the spot (hidden behind the other tiles)
   const int n = Kp - cfrom;
   double *X = sys + (size_t)cfrom * ld + c0;
   double *T = sys + (size_t)cfrom * ld + cfrom;
   const bool timed = h && h->prof_on && h->prof_used + 2 <= h->prof_ev.size();
   if (timed) SP_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
-  int rc = sp_launch_gemm_nt(X, ld, stride, X, ld, stride, T, ld, stride, n, n, kd, -1.0, 1,
-                             1, S, st);
+  int rc = fuse_nact > 0
+               ? sp_launch_gemm_nt_diag(X, ld, stride, X, ld, stride, T, ld, stride, n, n, kd,
+                                        -1.0, 1, S, fuse_nact, invL, info, st)
+               : sp_launch_gemm_nt(X, ld, stride, X, ld, stride, T, ld, stride, n, n, kd, -1.0,
+                                   1, 1, S, st);
   if (rc != SP_OK) return rc;
   if (timed) {
     SP_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
@@ -384,13 +250,15 @@ static int bulk_update(sp_handle *h, double *sys, long ld, long stride, int S, i
 }
 
 static int diag_and_solve(double *sys, long ld, long stride, int S, int K, int Kp, int j,
-                          int32_t *info, double *invL, hipStream_t st) {
+                          int32_t *info, double *invL, hipStream_t st, bool have_diag = false) {
   const int c0 = j * SP_NB;
   const int nact = K - c0 < SP_NB ? K - c0 : SP_NB;
   // diagonal block: L_d and L_d^-1
-  hipLaunchKernelGGL(diag_kernel, dim3(S), dim3(256), 0, st, sys, ld, stride, c0, nact,
-                     invL, info);
-  SP_LAUNCH_CHECK();
+  if (!have_diag) {
+    hipLaunchKernelGGL(diag_kernel, dim3(S), dim3(256), 0, st, sys, ld, stride, c0, nact,
+                       invL, info);
+    SP_LAUNCH_CHECK();
+  }
   // rows below the active block: X = P L_d^-T, in place, on the matrix cores
   const int r1 = c0 + nact;
   if (r1 < Kp) {
@@ -424,6 +292,26 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
       const int j = s0 + q, c0 = j * SP_NB;
       for (int g = 0; g < ngroups; ++g) {
         const sp_chol_group &G = grp[g];
+        const int nact = K - c0 < SP_NB ? K - c0 : SP_NB;
+        if (q > 0 && h && h->fuse_diag) {
+          // left-looking update of block column j by panels s0..j-1; the tile-(0,0)
+          // workgroup goes on to factor the diagonal block (fused), so only the
+          // panel solve remains as a separate launch
+          double *A = G.sys + (size_t)c0 * ld + cS;
+          double *T = G.sys + (size_t)c0 * ld + c0;
+          int rc = sp_launch_gemm_nt_diag(A, ld, stride, A, ld, stride, T, ld, stride, Kp - c0,
+                                          SP_NB, q * SP_NB, -1.0, 0, G.S, nact, G.invL, G.info,
+                                          G.st);
+          if (rc != SP_OK) return rc;
+          const int r1 = c0 + nact;
+          if (r1 < Kp) {
+            double *P = G.sys + (size_t)r1 * ld + c0;
+            rc = sp_launch_gemm_nt(P, ld, stride, G.invL, SP_NB, (long)SP_NB * SP_NB, P, ld,
+                                   stride, Kp - r1, SP_NB, SP_NB, 1.0, 0, 0, G.S, G.st);
+            if (rc != SP_OK) return rc;
+          }
+          continue;
+        }
         if (q > 0) {  // left-looking update of block column j by panels s0..j-1
           double *A = G.sys + (size_t)c0 * ld + cS;
           double *T = G.sys + (size_t)c0 * ld + c0;
@@ -431,17 +319,24 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
                                      SP_NB, q * SP_NB, -1.0, 1, 0, G.S, G.st);
           if (rc != SP_OK) return rc;
         }
-        int rc = diag_and_solve(G.sys, ld, stride, G.S, K, Kp, j, G.info, G.invL, G.st);
+        // first panel of a super-panel: its diagonal block was factored by the
+        // fused bulk update of the previous super-panel (if fusing is on)
+        const bool have_diag = q == 0 && s0 > 0 && h && h->fuse_diag > 1;
+        int rc = diag_and_solve(G.sys, ld, stride, G.S, K, Kp, j, G.info, G.invL, G.st,
+                                have_diag);
         if (rc != SP_OK) return rc;
       }
     }
     const int cE = (s0 + w) * SP_NB;
-    if (cE < K)
+    if (cE < K) {
+      const int nactE = K - cE < SP_NB ? K - cE : SP_NB;
       for (int g = 0; g < ngroups; ++g) {
         int rc = bulk_update(h, grp[g].sys, ld, stride, grp[g].S, cS, cE, Kp, w * SP_NB,
-                             grp[g].st);
+                             grp[g].st, (h && h->fuse_diag > 1) ? nactE : 0, grp[g].invL,
+                             grp[g].info);
         if (rc != SP_OK) return rc;
       }
+    }
   }
   return SP_OK;
 }

@@ -19,8 +19,8 @@
 #include <cstdlib>
 
 #include "sp_internal.h"
+#include "sp_diag.h"
 
-typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 #define GT 64   // tile edge
@@ -78,20 +78,30 @@ __device__ __forceinline__ void stage_store(const PanelRegs<BK> &R, double scale
 // Template parameters: BK = depth of one LDS stage (32 or 64); DEFER_C = issue
 // the C-tile loads before staging but consume them only after the MFMA loop, so
 // their HBM latency hides behind the panel staging and the matrix work.
-template <int BK, bool DEFER_C>
+//
+// FUSE_DIAG: tile (0, 0) of the launch is the diagonal block of the next panel.
+// The workgroup that owns it does not stop after its tile: it keeps the updated
+// block in LDS and factors it (diag_block, sp_diag.h), writing L_d and L_d^-1.
+// The ~15 us latency-bound factorisation then runs concurrently with the other
+// tiles of the same launch instead of as a kernel of its own between launches.
+template <int BK, bool DEFER_C, bool FUSE_DIAG>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(
     const double *A, long lda, long strideA,
     const double *__restrict__ B, long ldb, long strideB, double *C,
     long ldc, long strideC, int Mrows, int Nrows, int Kd, double alpha,
-    int beta, int lower_only, int batch, int ntm, int ntn, int ntiles) {
+    int beta, int lower_only, int batch, int ntm, int ntn, int ntiles, int nact,
+    double *invL_all, int32_t *info) {
   // Padded LDS row of BK + 1 doubles.  hipcc fuses the per-k-step fragment reads
   // into ds_read2_b64, which is banked mod 32 dwords in 16-lane groups: an ODD
   // row length puts the 16 rows of a group on 16 distinct bank pairs.  (An even
   // row length of BK + 2 is conflict-free only for plain ds_read_b64 and cost
   // 42% extra LDS cycles here: SQ_LDS_BANK_CONFLICT, profiles/r01_v3_pmc.txt.)
   constexpr int LDW = BK + 1;
-  __shared__ __attribute__((aligned(16))) double sA[GT * LDW];
-  __shared__ __attribute__((aligned(16))) double sB[GT * LDW];
+  constexpr int NLDS = FUSE_DIAG ? (2 * GT * LDW > SP_DIAG_LDS_DOUBLES ? 2 * GT * LDW
+                                                                       : SP_DIAG_LDS_DOUBLES)
+                                 : 2 * GT * LDW;
+  __shared__ __attribute__((aligned(16))) double smem[NLDS];
+  double *sA = smem, *sB = smem + GT * LDW;
 
   // XCD-aware decode: blocks b and b+8 share an XCD
   const int b = blockIdx.x;
@@ -180,14 +190,40 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
       const int gi = row0 + 16 * wave + fk + 4 * r, gj = col0 + 16 * n + fr;
       if (full || (gi < Mrows && gj < Nrows)) Cb[(size_t)gi * ldc + gj] = acc[n][r];
     }
+
+  if (FUSE_DIAG && ti == 0 && tj == 0) {
+    // the updated tile is the next diagonal block: factor it right here
+    double *sD = smem, *sY = smem + 64 * BLD;
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int li = 16 * wave + fk + 4 * r, lj = 16 * n + fr;
+        double v = (li < nact && lj < nact) ? acc[n][r] : (li == lj ? 1.0 : 0.0);
+        if (lj > li) v = 0.0;
+        sD[li * BLD + lj] = v;
+      }
+    __syncthreads();
+    const int notpd = diag_block(sD, sY, invL_all + (size_t)mtx * 4096);
+    if (notpd && info) info[mtx] = 1;
+    const int cj = (threadIdx.x & 15) * 4, ri = threadIdx.x >> 4;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int r = ri + 16 * pass;
+      double *dst = Cb + (size_t)r * ldc + cj;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (cj + e <= r && r < nact) dst[e] = sD[r * BLD + cj + e];
+    }
+  }
 }
 
 }  // namespace
 
-int sp_launch_gemm_nt(const double *A, long lda, long strideA, const double *B,
-                      long ldb, long strideB, double *C, long ldc, long strideC,
-                      int Mrows, int Nrows, int Kd, double alpha, int beta,
-                      int lower_only, int batch, hipStream_t st) {
+static int launch_gemm(const double *A, long lda, long strideA, const double *B, long ldb,
+                       long strideB, double *C, long ldc, long strideC, int Mrows, int Nrows,
+                       int Kd, double alpha, int beta, int lower_only, int batch, int fuse,
+                       int nact, double *invL, int32_t *info, hipStream_t st) {
   if (Mrows <= 0 || Nrows <= 0 || batch <= 0) return SP_OK;
   if (Kd < 0) return SP_ERR_INVALID;
   const int ntm = (Mrows + GT - 1) / GT, ntn = (Nrows + GT - 1) / GT;
@@ -198,19 +234,41 @@ int sp_launch_gemm_nt(const double *A, long lda, long strideA, const double *B,
   static int variant = -1;
   if (variant < 0) {
     const char *e = getenv("SP_GEMM_VARIANT");
-    variant = e ? atoi(e) : 1;
+    variant = e ? atoi(e) : 0;
   }
-#define SP_GO(BK, DC)                                                              \
-  hipLaunchKernelGGL((gemm_nt_kernel<BK, DC>), dim3((unsigned)nblk), dim3(256), 0, \
-                     st, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, \
-                     Nrows, Kd, alpha, beta, lower_only, batch, ntm, ntn, ntiles)
-  switch (variant) {
-    case 0: SP_GO(32, false); break;
-    case 2: SP_GO(64, false); break;
-    case 3: SP_GO(64, true); break;
-    default: SP_GO(32, true); break;
+#define SP_GO(BK, DC, FD)                                                              \
+  hipLaunchKernelGGL((gemm_nt_kernel<BK, DC, FD>), dim3((unsigned)nblk), dim3(256), 0, st, \
+                     A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd, \
+                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info)
+  if (fuse) {
+    SP_GO(32, false, true);
+  } else {
+    switch (variant) {
+      case 1: SP_GO(32, true, false); break;
+      case 2: SP_GO(64, false, false); break;
+      case 3: SP_GO(64, true, false); break;
+      default: SP_GO(32, false, false); break;
+    }
   }
 #undef SP_GO
   SP_LAUNCH_CHECK();
   return SP_OK;
+}
+
+int sp_launch_gemm_nt(const double *A, long lda, long strideA, const double *B, long ldb,
+                      long strideB, double *C, long ldc, long strideC, int Mrows, int Nrows,
+                      int Kd, double alpha, int beta, int lower_only, int batch,
+                      hipStream_t st) {
+  return launch_gemm(A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd,
+                     alpha, beta, lower_only, batch, 0, 0, nullptr, nullptr, st);
+}
+
+// Update (beta = 1) whose tile (0, 0) is the next diagonal block: that tile's
+// workgroup also factors it (nact active columns) and writes L_d^-1 / info.
+int sp_launch_gemm_nt_diag(const double *A, long lda, long strideA, const double *B, long ldb,
+                           long strideB, double *C, long ldc, long strideC, int Mrows,
+                           int Nrows, int Kd, double alpha, int lower_only, int batch,
+                           int nact, double *invL, int32_t *info, hipStream_t st) {
+  return launch_gemm(A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd,
+                     alpha, 1, lower_only, batch, 1, nact, invL, info, st);
 }

@@ -44,6 +44,7 @@ struct sp_handle {
   size_t tab_scratch_bytes;
   int superpanel;               // panels per super-panel (SP_SUPER, default 4)
   int groups;                   // concurrent star groups (SP_GROUPS, default 2)
+  int fuse_diag;                // fuse the diagonal-block factorisation into the block-column update
   std::vector<hipStream_t> gstream;
   std::vector<hipEvent_t> gdone;
   hipEvent_t gfork;
@@ -112,5 +113,10 @@ int sp_launch_gemm_nt(const double *A, long lda, long strideA, const double *B,
                       long ldb, long strideB, double *C, long ldc, long strideC,
                       int Mrows, int Nrows, int Kd, double alpha, int beta,
                       int lower_only, int batch, hipStream_t st);
+
+int sp_launch_gemm_nt_diag(const double *A, long lda, long strideA, const double *B, long ldb,
+                           long strideB, double *C, long ldc, long strideC, int Mrows,
+                           int Nrows, int Kd, double alpha, int lower_only, int batch,
+                           int nact, double *invL, int32_t *info, hipStream_t st);
 
 #endif
