@@ -48,8 +48,11 @@ __device__ __forceinline__ double temporal_factor(int kind, double ti, double tj
 // first taken from the product q = x * (1/dx) (within 2 ulp of the quotient)
 // and the exact division is only evaluated when q lies within 1e-9 of an
 // integer, the only case in which the two floors can differ.
+typedef double dd2 __attribute__((ext_vector_type(2)));
+
 struct SplineGen {
-  const double *a0, *a1, *a2, *a3, *xp;  // LDS
+  const double *tab;   // LDS: {a0, a1, a2, a3} interleaved per segment (32 B, 16-B aligned)
+  const double *xp;    // LDS: lag grid
   double dx, inv_dx;
   int covpts;
   __device__ __forceinline__ double operator()(double thi, double thj) const {
@@ -59,7 +62,11 @@ struct SplineGen {
     if (fabs(q - rint(q)) < 1.0e-9) idx = (long)floor(x / dx);
     idx = idx < 0 ? 0 : (idx > covpts ? covpts : idx);
     const double x0 = (x - xp[idx + 1]) * inv_dx;
-    return a0[idx] + a1[idx] * x0 + a2[idx] * (x0 * x0) + a3[idx] * (x0 * x0 * x0);
+    // two 16-byte LDS reads fetch the four coefficients of the segment
+    const dd2 c01 = *reinterpret_cast<const dd2 *>(tab + 4 * idx);
+    const dd2 c23 = *reinterpret_cast<const dd2 *>(tab + 4 * idx + 2);
+    // a0 + a1 x0 + a2 x0^2 + a3 x0^3 in Horner form
+    return c01.x + x0 * (c01.y + x0 * (c23.x + x0 * c23.y));
   }
 };
 
@@ -88,8 +95,11 @@ __global__ __launch_bounds__(256) void spline_index_kernel(
 __device__ __forceinline__ void load_tables(const double *__restrict__ tab, int np,
                                             const double *__restrict__ xp,
                                             double *s_tab) {
-  // s_tab: a0 | a1 | a2 | a3 | xp   (np each)
-  for (int i = threadIdx.x; i < 4 * np; i += blockDim.x) s_tab[i] = tab[np + i];
+  // s_tab: [np][4] = {a0, a1, a2, a3} per segment, then xp[np]
+  for (int i = threadIdx.x; i < 4 * np; i += blockDim.x) {
+    const int seg = i >> 2, k = i & 3;
+    s_tab[i] = tab[(1 + k) * np + seg];
+  }
   for (int i = threadIdx.x; i < np; i += blockDim.x) s_tab[4 * np + i] = xp[i];
 }
 
@@ -127,8 +137,8 @@ __global__ __launch_bounds__(256) void rowsum_kernel(
     } else if (K == 1) {
       acc = q == 0 ? meanvar[2 * st.table + 1] : 0.0;
     } else {
-      SplineGen g{s_tab, s_tab + np, s_tab + 2 * np, s_tab + 3 * np, s_tab + 4 * np,
-                  6.283185307179586 / covpts, 1.0 / (6.283185307179586 / covpts), covpts};
+      SplineGen g{s_tab, s_tab + 4 * np, 6.283185307179586 / covpts,
+                  1.0 / (6.283185307179586 / covpts), covpts};
       const double thi = s_th[i];
       const double ti = temporal != SP_TEMPORAL_NONE ? s_t[i] : 0.0;
       for (int j = q; j < K; j += 4)
@@ -237,8 +247,8 @@ __global__ __launch_bounds__(256) void assemble_kernel(
     s_qj[l] = (ok && normalized) ? qv[(size_t)s * K + j] : 0.0;
   }
   __syncthreads();
-  SplineGen g{s_tab, s_tab + np, s_tab + 2 * np, s_tab + 3 * np, s_tab + 4 * np,
-              6.283185307179586 / covpts, 1.0 / (6.283185307179586 / covpts), covpts};
+  SplineGen g{s_tab, s_tab + 4 * np, 6.283185307179586 / covpts,
+              1.0 / (6.283185307179586 / covpts), covpts};
   const double var1 = (!FROM_MATRIX && K == 1) ? meanvar[2 * st.table + 1] : 0.0;
   double *ob = out + (size_t)s * strideo;
   // thread -> 4 consecutive columns, 16 rows per pass
@@ -282,9 +292,14 @@ __global__ __launch_bounds__(256) void assemble_kernel(
       v[e] = val;
     }
     double *dst = ob + (size_t)i * ldo + j0 + cj;
+    if (j0 + cj + 3 < lim && (((size_t)dst) & 15) == 0) {
+      *reinterpret_cast<dd2 *>(dst) = dd2{v[0], v[1]};
+      *reinterpret_cast<dd2 *>(dst + 2) = dd2{v[2], v[3]};
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (j0 + cj + e < lim) dst[e] = v[e];
+      for (int e = 0; e < 4; ++e)
+        if (j0 + cj + e < lim) dst[e] = v[e];
+    }
   }
 }
 
