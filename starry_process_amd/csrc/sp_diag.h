@@ -95,19 +95,50 @@ __device__ __forceinline__ int diag_block(double *sD, double *sY, double *__rest
         Am[q] = fr <= row ? sD[(o + row) * BLD + o + fr] : sD[(o + fr) * BLD + o + row];
         Ym[q] = row == fr ? 1.0 : 0.0;
       }
+      // Pivots run one column ahead of the MFMA chain: r_c = 1/sqrt(p_c) is
+      // ready before column c is applied, so the critical path per column is
+      // MFMA -> one multiply -> MFMA instead of MFMA -> readlane -> rsqrt -> MFMA.
+      // p_{c+1} = a_{c+1,c+1} - (a_{c+1,c} r_c)^2 with both a's read from the
+      // tile as it stands BEFORE update c (i.e. after update c-1).
+      double r_cur, r_nxt;
+      {
+        const double p0 = read_lane(Am[0], 0);
+        if (!(p0 > 0.0)) notpd = 1;
+        r_cur = rsqrt_nr(p0);
+        const double a10 = read_lane(Am[0], 16 * 1 + 0);   // row 1: group 1, reg 0
+        const double a11 = read_lane(Am[0], 16 * 1 + 1);
+        const double l10 = a10 * r_cur;
+        const double p1 = fma(-l10, l10, a11);
+        if (!(p1 > 0.0)) notpd = 1;
+        r_nxt = rsqrt_nr(p1);
+      }
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
         const int g = c & 3, q = c >> 2;
-        const double piv = read_lane(Am[q], 16 * g + c);
-        if (!(piv > 0.0)) notpd = 1;
-        const double r = rsqrt_nr(piv);
+        const double r = r_cur;
         const bool act = (fk == g) && (fr >= c);
-        const double l = act ? Am[q] * r : 0.0;       // l_{fr,c}; fr == c: sqrt(piv)
-        const double u = act ? (fr == c ? 1.0 - r : l * r) : 0.0;
-        const double yrow = (fk == g) ? Ym[q] : 0.0;  // row c of Y
+        const double arow = Am[q];
+        const double t0 = arow * r;
+        const double l = act ? t0 : 0.0;              // l_{fr,c}; fr == c: sqrt(piv)
+        const double lr = l * r;                       // 0 outside the active lanes
+        const double u = (act && fr == c) ? 1.0 - r : lr;
+        const double yq = Ym[q];
+        const double yrow = (fk == g) ? yq : 0.0;      // row c of Y
         if (act) sD[(o + fr) * BLD + o + c] = l;
         Am = __builtin_amdgcn_mfma_f64_16x16x4f64(-l, l, Am, 0, 0, 0);
         Ym = __builtin_amdgcn_mfma_f64_16x16x4f64(-u, yrow, Ym, 0, 0, 0);
+        r_cur = r_nxt;
+        if (c + 2 < 16) {
+          // pivot of column c+2 from the tile after update c, plus the (not yet
+          // applied) contribution of column c+1
+          const int R = c + 2, gR = R & 3, qR = R >> 2;
+          const double a21 = read_lane(Am[qR], 16 * gR + c + 1);
+          const double a22 = read_lane(Am[qR], 16 * gR + c + 2);
+          const double l21 = a21 * r_nxt;
+          const double p2 = fma(-l21, l21, a22);
+          if (!(p2 > 0.0)) notpd = 1;
+          r_nxt = rsqrt_nr(p2);
+        }
       }
       acc_store(sYk, YLD, 0, 0, lane, Ym);
       acc_store(inv, 64, o, o, lane, Ym);
