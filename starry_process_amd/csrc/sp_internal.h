@@ -43,7 +43,7 @@ struct sp_handle {
   double *d_tab_scratch;        // [ntab][2][N] row reductions of the kernel table
   size_t tab_scratch_bytes;
   int superpanel;               // panels per super-panel (SP_SUPER, default 4)
-  int groups;                   // concurrent star groups (SP_GROUPS, default 2)
+  int groups;                   // concurrent star groups (SP_GROUPS, default 1)
   int fuse_diag;                // fuse the diagonal-block factorisation into the block-column update
   std::vector<hipStream_t> gstream;
   std::vector<hipEvent_t> gdone;
