@@ -250,6 +250,14 @@ int sp_cholesky_lnlike_batched(sp_handle *h, int S, int K, int M,
                                void *workspace_dev, double *lnlike_dev,
                                uint32_t *status_dev, void *stream);
 
+/* ---- upstream of the hot path, host only ---------------- */
+/* LatitudeIntegralOp values (ops/latitude/latitude.py, ops/include/latitude.h:
+ * 21-173): q [N], Q [N x N] for Beta shape parameters alpha, beta.  The
+ * remaining upstream integrals are NumPy in the reference and in
+ * starry_process_amd/upstream.py.                                             */
+int sp_latitude_integrals(int ydeg, double alpha, double beta, double *q_host,
+                          double *Q_host);
+
 /* ---- measurement hooks (bench.py) ------------------------------------------ */
 /* Between begin and end every launch of the trailing-update kernel (the
  * dominant kernel of the factorisation) is bracketed by HIP events on the

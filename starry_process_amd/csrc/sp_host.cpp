@@ -350,3 +350,105 @@ const char *sp_strerror(int status) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// Upstream of the hot path: latitude moment integrals of
+// the Beta-distributed spot latitude (reference ops/include/latitude.h:21-173,
+// ops/include/special.h:172-232), values only -- the reference also carries
+// d/dalpha, d/dbeta for its reverse-mode Ops, which are out of scope here.
+// ---------------------------------------------------------------------------
+namespace {
+
+// Gauss 2F1 by its power series.  The reference stops when the value AND its
+// two parameter derivatives have converged (special.h:187-189); the derivative
+// terms are carried along only to stop at the same term.
+double hyp2f1_series(double a, double b, double c, double z) {
+  double term = a * b * z / c;
+  double dtermdb = a * z / c, dtermdc = -term / c;
+  double value = 1.0 + term, dfdb = dtermdb, dfdc = dtermdc;
+  int n = 1;
+  while ((std::fabs(term / value) > 1e-15 || std::fabs(dtermdb / dfdb) > 1e-13 ||
+          std::fabs(dtermdc / dfdc) > 1e-13) &&
+         n < 500) {
+    a += 1;
+    b += 1;
+    c += 1;
+    n += 1;
+    const double fac1 = a * z / c / n;
+    const double fac2 = fac1 * b;
+    const double fac3 = -fac2 / c;
+    dtermdb *= fac2;
+    dtermdb += fac1 * term;
+    dtermdc *= fac2;
+    dtermdc += fac3 * term;
+    term *= fac2;
+    value += term;
+    dfdb += dtermdb;
+    dfdc += dtermdc;
+  }
+  return value;
+}
+
+}  // namespace
+
+extern "C" int sp_latitude_integrals(int ydeg, double alpha, double beta, double *q,
+                                     double *Q) {
+  if (ydeg < 0 || ydeg > SP_MAX_YDEG || !q || !Q) return SP_ERR_INVALID;
+  alpha = alpha > 0.0 ? alpha : 0.0;  // ops/latitude/latitude.cc:47-48
+  beta = beta > 0.0 ? beta : 0.0;
+  const int n = 4 * ydeg + 1, N = (ydeg + 1) * (ydeg + 1);
+  std::vector<double> B(n), F(n), term((size_t)n * n, 0.0);
+  B[0] = 1.0;
+  for (int k = 1; k < n; ++k) {
+    const double c1 = 1.0 / (alpha + beta + k - 1.0);
+    B[k] = (alpha + k - 1.0) * c1 * B[k - 1];
+  }
+  const double ab = alpha + beta;
+  F[0] = std::sqrt(2.0) * hyp2f1_series(-0.5, beta, ab, 0.5);
+  if (n > 1) F[1] = std::sqrt(2.0) * hyp2f1_series(-0.5, beta, ab + 1.0, 0.5);
+  for (int k = 2; k < n; ++k) {
+    const double c1 = (ab + k - 1.0) / ((alpha + k - 1.0) * (ab + k - 0.5));
+    const double c2 = c1 * (ab + k - 2.0);
+    const double c3 = c1 * (1.5 - beta);
+    F[k] = c2 * F[k - 2] + c3 * F[k - 1];
+  }
+  for (int k = 0; k < n; ++k) F[k] = F[k] * B[k];
+  for (int i = 0; i < n; ++i) {
+    const double *func = (i % 2 == 0) ? B.data() : F.data();
+    const int i2 = (i % 2 == 0) ? i / 2 : (i - 1) / 2;
+    for (int j = 0; j < n; j += 2) {
+      const int j2 = j / 2;
+      double fac1 = 1.0, acc = 0.0;
+      for (int k1 = 0; k1 < i2 + 1; ++k1) {
+        double fac2 = fac1;
+        for (int k2 = 0; k2 < j2 + 1; ++k2) {
+          acc += fac2 * func[k1 + k2];
+          fac2 *= (k2 - j2) / (k2 + 1.0);
+        }
+        fac1 *= (i2 - k1) / (k1 + 1.0);
+      }
+      term[(size_t)i * n + j] = acc;
+    }
+  }
+  int n1 = 0;
+  double inv_two_l1 = 1.0;
+  for (int l1 = 0; l1 <= ydeg; ++l1) {
+    for (int m1 = -l1; m1 <= l1; ++m1) {
+      const int j1 = m1 + l1, i1 = l1 - m1;
+      q[n1] = term[(size_t)j1 * n + i1] * inv_two_l1;
+      int n2 = 0;
+      double inv = inv_two_l1;
+      for (int l2 = 0; l2 <= ydeg; ++l2) {
+        for (int m2 = -l2; m2 <= l2; ++m2) {
+          const int j2 = m2 + l2, i2 = l2 - m2;
+          Q[(size_t)n1 * N + n2] = term[(size_t)(j1 + j2) * n + (i1 + i2)] * inv;
+          ++n2;
+        }
+        inv *= 0.5;
+      }
+      ++n1;
+    }
+    inv_two_l1 *= 0.5;
+  }
+  return SP_OK;
+}

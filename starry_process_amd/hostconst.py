@@ -28,10 +28,6 @@ __all__ = ["G_matrix", "wigner_poly", "wigner_poly_rows", "marginal_constants", 
 
 _cache = {}
 
-_C4 = (1, 0, -1, 0)  # cos(k pi/2)
-_S4 = (0, 1, 0, -1)  # sin(k pi/2)
-
-
 def G_matrix(ydeg):
     """G[a, b] = int_0^{pi/2} cos(x/2)^a sin(x/2)^b sin x dx, a, b = 0..4*ydeg,
     in the reference's layout and with the reference's expression
@@ -101,11 +97,24 @@ def _dpoly_next(l, D1, D2):
     return D
 
 
-def wigner_poly(ydeg):
-    """Polynomial real rotation matrices for the Euler angles flux.py:49-51
-    requests (alpha = pi/2, gamma = -pi/2): list over l of arrays [m', m, i]
-    (reference wigner.py:265-372)."""
-    key = ("R", ydeg)
+def _trig_multiples(c, s, n):
+    """cos(k a), sin(k a) for k = 1..n by the reference's angle-addition
+    recurrence (wigner.py:289-291); exact for the 0 / +-1 inputs used here."""
+    cs, sn = [None], [None]
+    ck, sk = c, s
+    for _ in range(n):
+        cs.append(ck)
+        sn.append(sk)
+        ck, sk = ck * c - sk * s, sk * c + ck * s
+    return cs, sn
+
+
+def wigner_poly(ydeg, cos_alpha=0, sin_alpha=1, cos_gamma=0, sin_gamma=-1):
+    """Polynomial real rotation matrices for the given Euler angles alpha, gamma
+    (defaults: the ones flux.py:49-51 and latitude.py:201-203 request; the
+    longitude integral uses (1, 0, 1, 0), longitude.py:21-23): list over l of
+    arrays [m', m, i] (reference wigner.py:265-372)."""
+    key = ("R", ydeg, cos_alpha, sin_alpha, cos_gamma, sin_gamma)
     if key in _cache:
         return _cache[key]
     r2 = np.sqrt(2.0)
@@ -124,20 +133,22 @@ def wigner_poly(ydeg):
         Ds.append(D1)
     for l in range(2, ydeg + 1):
         Ds.append(_dpoly_next(l, Ds[l - 1], Ds[l - 2]))
+    cal, sal = _trig_multiples(cos_alpha, sin_alpha, ydeg)
+    cga, sga = _trig_multiples(cos_gamma, sin_gamma, ydeg)
     out = []
     for l, D in enumerate(Ds):
         w = 2 * l + 1
         R = np.zeros((w, w, w))
         R[l, l] = D[l, l]
         for mp in range(1, l + 1):
-            ca, sa = _C4[mp & 3], _S4[mp & 3]      # cos / sin(mp * pi/2)
+            ca, sa = cal[mp], sal[mp]
             sg = -1 if mp & 1 else 1
             aux = r2 * D[l, l + mp]
             R[l + mp, l] = aux * ca
             R[l - mp, l] = aux * sa
             m = np.arange(1, l + 1)
-            cg = np.array([_C4[k & 3] for k in m], dtype=float)[:, None]
-            sgm = np.array([-_S4[k & 3] for k in m], dtype=float)[:, None]
+            cg = np.array([cga[k] for k in m], dtype=float)[:, None]
+            sgm = np.array([sga[k] for k in m], dtype=float)[:, None]
             auxm = r2 * D[l + m, l]
             R[l, l + m] = auxm * cg
             R[l, l - m] = -auxm * sgm

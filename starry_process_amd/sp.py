@@ -128,6 +128,12 @@ class StarryProcess(object):
     mean_ylm = property(lambda self: Eager(self._mean_ylm))
     cov_ylm = property(lambda self: Eager(self._cov_ylm))
 
+    def log_jac(self):
+        """Log |Jacobian| of the (a, b) -> (mu, sigma) transform (sp.py:1004-1050)."""
+        from .upstream import log_jac
+
+        return Eager(np.float64(log_jac(self._a, self._b, **self._kwargs)))
+
     # -- mean / cov (sp.py:643-703) --------------------------------------------------
     def mean(self, t, i=defaults["i"], p=defaults["p"], u=defaults["u"][: defaults["udeg"]]):
         if self._normalized:

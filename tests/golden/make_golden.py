@@ -22,6 +22,8 @@ Files (L = ydeg):
   cov_L{L}.npz      small-K covariances (marginal / conditional / temporal /
                     normalised), design matrix, int64 spline indices
   norm.npz          AlphaBetaOp values
+  upstream.npz      upstream-of-path pieces: size / latitude / longitude first
+                    moments, log_jac, gauss2beta / beta2gauss, mu / sigma
   lnlike.npz        log-likelihoods for the BASELINE.json configs
 """
 import os
@@ -222,6 +224,40 @@ def gen_norm():
     save("norm.npz", z=zs, abN20=vals, abN10=vals10)
 
 
+def gen_upstream():
+    """Upstream integrals (SURVEY 8f next #1), ydeg = 15."""
+    from starry_process.latitude import beta2gauss, gauss2beta
+
+    out = {}
+    for name, hp in HYPER.items():
+        sp = SP(ydeg=15, **hp)
+        out[name + "_hyper"] = np.array(
+            [hp["r"], hp.get("dr", np.nan) or np.nan, hp["a"], hp["b"], hp["c"], hp["n"]]
+        )
+        out[name + "_size_q"] = A(sp.size._first_moment())
+        out[name + "_lat_mom1"] = A(sp.latitude._first_moment(sp.size._first_moment()))
+        out[name + "_lon_mom1"] = A(
+            sp.longitude._first_moment(sp.latitude._first_moment(sp.size._first_moment()))
+        )
+        out[name + "_lat_q"] = A(sp.latitude._q)
+        out[name + "_lat_Q"] = A(sp.latitude._Q)
+        out[name + "_log_jac"] = np.array(float(A(sp.log_jac())))
+        out[name + "_mu_sigma"] = np.array([float(A(sp.latitude.mu)), float(A(sp.latitude.sigma))])
+    mu = np.array([0.0, 10.0, 30.0, 45.0, 60.0, 85.0])
+    sg = np.array([5.0, 5.0, 10.0, 20.0, 3.0, 8.0])
+    a, b = gauss2beta(mu, sg)
+    out["g2b_mu"], out["g2b_sigma"], out["g2b_a"], out["g2b_b"] = mu, sg, A(a), A(b)
+    aa = np.array([0.1, 0.4, 0.7, 0.95, 0.0])
+    bb = np.array([0.2, 0.27, 0.5, 0.9, 0.5])
+    m, s_ = beta2gauss(aa, bb)
+    out["b2g_a"], out["b2g_b"], out["b2g_mu"], out["b2g_sigma"] = aa, bb, A(m), A(s_)
+    sp = SP(ydeg=15)
+    lon = sp.longitude
+    out["lon_q"] = A(lon._q)
+    out["lon_Q_diag"] = np.diag(A(lon._Q)).copy()
+    save("upstream.npz", **out)
+
+
 def gen_lnlike():
     out = {}
     t0 = time.time()
@@ -276,7 +312,7 @@ def gen_lnlike():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "consts", "moments", "cov", "norm", "lnlike"]
+    which = sys.argv[1:] or ["ops", "consts", "moments", "cov", "norm", "lnlike", "upstream"]
     for L in (5, 15, 20):
         if "ops" in which:
             gen_ops(L)
@@ -291,3 +327,5 @@ if __name__ == "__main__":
         gen_norm()
     if "lnlike" in which:
         gen_lnlike()
+    if "upstream" in which:
+        gen_upstream()

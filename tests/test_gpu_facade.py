@@ -160,3 +160,25 @@ def test_flux_integral_mirror():
     k = np.asarray(fm.kernel(np.array([0.0, 0.1, 0.7]), 60.0, 1.0, [0.0, 0.0]))
     tab = mom["default_u0_yp"]
     assert abs(k[0] - tab[1]) < 1e-12 * abs(tab[1])   # zero lag = yp at x = 0
+
+
+def test_from_hyperparameters_end_to_end():
+    """StarryProcess(r, a, b, c, n) with no injected moments: upstream.ylm_moments
+    feeds the GPU path; the end-to-end value matches the executed reference
+    (README quick-start call)."""
+    from starry_process_amd import StarryProcess
+
+    g = golden("lnlike")
+    sp = StarryProcess(ydeg=15)  # all defaults, like the reference README
+    mom = golden("moments_L15")
+    assert np.abs(sp.mean_ylm.eval() - mom["default_mean_ylm"]).max() < 1e-12
+    st = synthetic_star(0, 1000)
+    v = sp.log_likelihood(st["t"], st["flux"], st["data_cov"], p=st["p"])
+    assert abs(float(v) / g["cfg2_L15_K1000"][0] - 1) < 1e-8
+    up = golden("upstream")
+    assert np.isclose(float(sp.log_jac()), float(up["default_log_jac"]), rtol=1e-12)
+    # mu / sigma parametrisation (sp.py:243-255)
+    sp2 = StarryProcess(ydeg=5, mu=30.0, sigma=5.0)
+    assert np.isfinite(float(sp2.log_likelihood(st["t"][:100], st["flux"][:100], 1e-6)))
+    with pytest.raises(ValueError):
+        StarryProcess(ydeg=5, mu=30.0)

@@ -1,0 +1,91 @@
+"""
+Upstream of the hot path: hyperparameters -> (mu_y, Sigma_y).
+Host code (NumPy + the host C++ entry point sp_latitude_integrals), so these
+run without a GPU.  Expected values were produced by the executed reference
+(tests/golden/make_golden.py: gen_moments, gen_upstream).
+"""
+import numpy as np
+import pytest
+
+from conftest import golden
+from starry_process_amd import upstream
+
+
+def _hyper(hp):
+    r, dr, a, b, c, n = hp
+    return dict(r=r, dr=None if np.isnan(dr) else dr, a=a, b=b, c=c, n=n)
+
+
+@pytest.mark.parametrize("L,name", [(5, "default"), (15, "default"), (15, "hilat"), (15, "spread"), (20, "default")])
+def test_ylm_moments_match_reference(L, name):
+    g = golden("moments_L%d" % L)
+    mu, Sig = upstream.ylm_moments(ydeg=L, **_hyper(g[name + "_hyper"]))
+    mref, Sref = g[name + "_mean_ylm"], g[name + "_cov_ylm"]
+    # eigh-based square roots: LAPACK build differences move the last few bits
+    tol = 1e-10 if L <= 15 else 1e-9
+    assert np.abs(mu - mref).max() <= tol * np.abs(mref).max()
+    assert np.abs(Sig - Sref).max() <= tol * np.abs(Sref).max()
+    assert np.array_equal(Sig, Sig.T) or np.abs(Sig - Sig.T).max() < 1e-18 + 1e-14 * np.abs(Sig).max()
+
+
+@pytest.mark.parametrize("name", ["default", "hilat", "spread"])
+def test_stage_first_moments(name):
+    g = golden("upstream")
+    hp = _hyper(g[name + "_hyper"])
+    L = 15
+    q, eigQ = upstream.size_moments(hp["r"], hp["dr"], L)
+    assert np.abs(q - g[name + "_size_q"]).max() <= 1e-13 * np.abs(g[name + "_size_q"]).max()
+    alpha, beta = upstream.ab_to_alphabeta(hp["a"], hp["b"])
+    ql, Ql = upstream.latitude_integrals(L, alpha, beta)
+    # the native integral is bit-identical to the reference's header
+    assert np.array_equal(ql, g[name + "_lat_q"])
+    assert np.array_equal(Ql, g[name + "_lat_Q"])
+    from starry_process_amd.hostconst import wigner_poly
+
+    t, T = upstream._wigner_operators(L, ql, Ql, wigner_poly(L, 0, 1, 0, -1))
+    e = upstream._first_moment(L, t, q)
+    assert np.abs(e - g[name + "_lat_mom1"]).max() <= 1e-12 * np.abs(g[name + "_lat_mom1"]).max()
+    qo, Qo = upstream._longitude_integrals(L)
+    t2, _ = upstream._wigner_operators(L, qo, Qo, wigner_poly(L, 1, 0, 1, 0))
+    m1 = upstream._first_moment(L, t2, e)
+    assert np.abs(m1 - g[name + "_lon_mom1"]).max() <= 1e-12 * np.abs(g[name + "_lon_mom1"]).max()
+
+
+def test_longitude_constants():
+    g = golden("upstream")
+    q, Q = upstream._longitude_integrals(15)
+    assert np.allclose(q, g["lon_q"], rtol=1e-14, atol=0)
+    assert np.allclose(np.diag(Q), g["lon_Q_diag"], rtol=1e-14, atol=0)
+
+
+@pytest.mark.parametrize("name", ["default", "hilat", "spread"])
+def test_log_jac(name):
+    g = golden("upstream")
+    hp = _hyper(g[name + "_hyper"])
+    assert np.isclose(upstream.log_jac(hp["a"], hp["b"]), float(g[name + "_log_jac"]), rtol=1e-12, atol=0)
+    mu, sigma = upstream.beta2gauss(hp["a"], hp["b"])
+    # the reference's `latitude.mu` / `.sigma` properties return radians * (pi / 180)
+    # (latitude.py:214-220); undo both factors to compare in degrees
+    assert np.allclose([mu, sigma], g[name + "_mu_sigma"] / (np.pi / 180) ** 2, rtol=1e-12)
+
+
+def test_gauss_beta_transforms():
+    g = golden("upstream")
+    a, b = upstream.gauss2beta(g["g2b_mu"], g["g2b_sigma"])
+    assert np.allclose(a, g["g2b_a"], rtol=1e-13, atol=1e-15)
+    assert np.allclose(b, g["g2b_b"], rtol=1e-13, atol=1e-15)
+    mu, sg = upstream.beta2gauss(g["b2g_a"], g["b2g_b"])
+    assert np.allclose(mu, g["b2g_mu"], rtol=1e-12, equal_nan=True)
+    assert np.allclose(sg, g["b2g_sigma"], rtol=1e-12, equal_nan=True)
+    # round trip
+    a, b = upstream.gauss2beta(30.0, 5.0)
+    assert np.allclose(upstream.beta2gauss(a, b), (30.0, 5.0), rtol=1e-10)
+
+
+def test_bounds():
+    with pytest.raises(ValueError):
+        upstream.ylm_moments(r=95.0, ydeg=5)
+    with pytest.raises(ValueError):
+        upstream.ylm_moments(a=1.5, ydeg=5)
+    with pytest.raises(ValueError):
+        upstream.ylm_moments(n=-1.0, ydeg=5)
