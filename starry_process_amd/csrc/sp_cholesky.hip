@@ -3,10 +3,14 @@
 //
 // Blocked factorisation, panels of SP_NB = 64 columns (driver:
 // sp_launch_cholesky_groups below):
-//   diag_block (sp_diag.h)  factors the 64x64 diagonal block and forms L_d^-1;
+//   diag_block (sp_diag.h)  factors the 64x64 diagonal block (and writes L_d^T
+//                  with the reciprocal diagonal for the solve);
+//   trsm_quad_kernel        the panel solve X = P L_d^-T by substitution, four
+//                  lanes per row (fp64 VALU has the MFMA's peak on gfx950 and
+//                  substitution needs half the flops of a product with L_d^-1);
 //   sp_launch_gemm_nt (sp_gemm.hip) does everything else on the matrix cores:
-//                  the panel solve X = P L_d^-T, the left-looking block-column
-//                  updates and the rank-64w trailing updates.
+//                  the left-looking block-column updates and the rank-64w
+//                  trailing updates.
 // The systems are padded to a multiple of 64 rows and carry the residual
 // vectors as EXTRA ROWS below the matrix: factoring
 //     [ C   . ]          gives          [ L   . ]
@@ -29,7 +33,7 @@ __global__ __launch_bounds__(256) void diag_kernel(double *__restrict__ sys, lon
                                                    double *__restrict__ invL_all,
                                                    int32_t *__restrict__ info) {
   __shared__ __attribute__((aligned(16))) double lds[SP_DIAG_LDS_DOUBLES];
-  double *sD = lds, *sY = lds + 64 * BLD;
+  double *sD = lds, *sRd = lds + 64 * BLD;
   double *Mx = sys + (size_t)blockIdx.x * stride;
   const int tid = threadIdx.x;
   // stage the block; outside the active nact x nact part use the identity so a
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(256) void diag_kernel(double *__restrict__ sys, lon
     }
   }
   __syncthreads();
-  const int notpd = diag_block(sD, sY, invL_all + (size_t)blockIdx.x * 4096);
+  const int notpd = diag_block(sD, sRd, invL_all + (size_t)blockIdx.x * 4096);
   if (notpd && info) info[blockIdx.x] = 1;
   {
     const int cj = (tid & 15) * 4, ri = tid >> 4;
@@ -63,6 +67,113 @@ __global__ __launch_bounds__(256) void diag_kernel(double *__restrict__ sys, lon
         const int c = cj + e;
         if (c <= r && r < nact) dst[e] = sD[r * BLD + c];
       }
+    }
+  }
+}
+
+// Panel solve  X = P L_d^-T  (rows below the diagonal block, in place) by forward
+// substitution on the vector ALU.  Four lanes share a row: lane q of the quad
+// holds the columns 8 i + 2 q + {0, 1}, i = 0..7, so that the quad's 16-byte
+// loads cover 64 contiguous bytes of the row.  With the row pre-scaled by
+// 1 / L_cc and  lt[k][c] = L_ck / L_cc  (diag_block's output), step k is: a
+// quad-permute DPP broadcasts x_k from its owner lane and every lane updates
+// its remaining columns,  x_c -= x_k lt[k][c]  -- lt is staged in LDS (zero on
+// and left of the diagonal) and read as 16-byte pairs two steps ahead of use.
+// 576 fused multiply-adds per lane; the dependent chain per step is
+// FMA -> DPP -> FMA.  No barrier after the staging one.
+struct TrsmRow {
+  d2v v[8];
+};
+
+template <int K>
+__device__ __forceinline__ void trsm_fetch(TrsmRow &r, const double *sLT, int q) {
+  if (K < 64) {
+    const double *row = sLT + (K < 64 ? K : 0) * 64 + 2 * q;
+#pragma unroll
+    for (int i = (K >> 3); i < 8; ++i) r.v[i] = *reinterpret_cast<const d2v *>(row + 8 * i);
+  }
+}
+
+template <int K>
+struct TrsmStep {
+  static __device__ __forceinline__ void run(double (&x)[16], const TrsmRow &cur,
+                                             const TrsmRow &nxt, const double *sLT, int q) {
+    constexpr int IK = K >> 3, QK = (K >> 1) & 3, REG = 2 * IK + (K & 1);
+    constexpr int CTRL = QK * 0x55;  // quad_perm:[QK, QK, QK, QK]
+    TrsmRow nn;
+    trsm_fetch<K + 2>(nn, sLT, q);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x[REG]), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x[REG]), CTRL, 0xf, 0xf, false);
+    const double xk = __hiloint2double(hi, lo);
+    // (cur.v holds 0 for the columns <= K, so x[REG] itself is left alone)
+#pragma unroll
+    for (int i = IK; i < 8; ++i) {
+      x[2 * i] = fma(-xk, cur.v[i].x, x[2 * i]);
+      x[2 * i + 1] = fma(-xk, cur.v[i].y, x[2 * i + 1]);
+    }
+    TrsmStep<K + 1>::run(x, nxt, nn, sLT, q);
+  }
+};
+template <>
+struct TrsmStep<64> {
+  static __device__ __forceinline__ void run(double (&)[16], const TrsmRow &, const TrsmRow &,
+                                             const double *, int) {}
+};
+
+__global__ __launch_bounds__(256) void trsm_quad_kernel(double *sys, long ld, long stride,
+                                                        int r1, int c0, int nrows,
+                                                        const double *__restrict__ LT_all,
+                                                        int batch, int ntiles) {
+  __shared__ __attribute__((aligned(16))) double sLT[64 * 64];
+  __shared__ __attribute__((aligned(16))) double sRd[64];
+  // XCD-aware decode as in sp_gemm.hip: all row tiles of one star on one XCD
+  const int b = blockIdx.x;
+  const int xcd = b & 7, slot = b >> 3;
+  const int mtx = (slot / ntiles) * 8 + xcd;
+  if (mtx >= batch) return;
+  const int tile = slot % ntiles;
+  const int tid = threadIdx.x;
+  const int lrow = tile * 64 + (tid >> 2), q = tid & 3;
+  const bool valid = lrow < nrows;
+  double *prow = sys + (size_t)mtx * stride + (size_t)(r1 + (valid ? lrow : 0)) * ld + c0 + 2 * q;
+  d2v lt[8], px[8];
+  {
+    const double *LT = LT_all + (size_t)mtx * 4096;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lt[i] = *reinterpret_cast<const d2v *>(LT + 2 * (tid + 256 * i));
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) px[i] = *reinterpret_cast<const d2v *>(prow + 8 * i);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int e = 2 * (tid + 256 * i);
+    const int k = e >> 6, c = e & 63;
+    d2v v = lt[i];
+    const bool d0 = c == k, d1 = c + 1 == k;
+    if (d0 || d1) sRd[k] = d0 ? v.x : v.y;
+    v.x = d0 ? 0.0 : v.x;
+    v.y = d1 ? 0.0 : v.y;
+    *reinterpret_cast<d2v *>(sLT + e) = v;
+  }
+  __syncthreads();
+  double x[16];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const d2v rd = *reinterpret_cast<const d2v *>(sRd + 8 * i + 2 * q);
+    x[2 * i] = px[i].x * rd.x;
+    x[2 * i + 1] = px[i].y * rd.y;
+  }
+  TrsmRow r0, r1v;
+  trsm_fetch<0>(r0, sLT, q);
+  trsm_fetch<1>(r1v, sLT, q);
+  TrsmStep<0>::run(x, r0, r1v, sLT, q);
+  if (valid) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      d2v v;
+      v.x = x[2 * i];
+      v.y = x[2 * i + 1];
+      *reinterpret_cast<d2v *>(prow + 8 * i) = v;
     }
   }
 }
@@ -249,24 +360,31 @@ static int bulk_update(sp_handle *h, double *sys, long ld, long stride, int S, i
   return SP_OK;
 }
 
+// rows r1..Kp-1 of panel column c0: X = P L_d^-T in place (LT = diag_block's output)
+static int launch_trsm(double *sys, long ld, long stride, int S, int r1, int c0, int Kp,
+                       const double *LT, hipStream_t st) {
+  const int nrows = Kp - r1;
+  if (nrows <= 0) return SP_OK;
+  const int ntiles = (nrows + 63) / 64;
+  const long nblk = 8L * ((S + 7) / 8) * ntiles;
+  hipLaunchKernelGGL(trsm_quad_kernel, dim3((unsigned)nblk), dim3(256), 0, st, sys, ld, stride,
+                     r1, c0, nrows, LT, S, ntiles);
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}
+
 static int diag_and_solve(double *sys, long ld, long stride, int S, int K, int Kp, int j,
                           int32_t *info, double *invL, hipStream_t st, bool have_diag = false) {
   const int c0 = j * SP_NB;
   const int nact = K - c0 < SP_NB ? K - c0 : SP_NB;
-  // diagonal block: L_d and L_d^-1
+  // diagonal block: L_d (and L_d^T for the solve)
   if (!have_diag) {
     hipLaunchKernelGGL(diag_kernel, dim3(S), dim3(256), 0, st, sys, ld, stride, c0, nact,
                        invL, info);
     SP_LAUNCH_CHECK();
   }
-  // rows below the active block: X = P L_d^-T, in place, on the matrix cores
-  const int r1 = c0 + nact;
-  if (r1 < Kp) {
-    double *P = sys + (size_t)r1 * ld + c0;
-    return sp_launch_gemm_nt(P, ld, stride, invL, SP_NB, (long)SP_NB * SP_NB, P, ld, stride,
-                             Kp - r1, SP_NB, SP_NB, 1.0, 0, 0, S, st);
-  }
-  return SP_OK;
+  // rows below the active block: X = P L_d^-T, in place
+  return launch_trsm(sys, ld, stride, S, c0 + nact, c0, Kp, invL, st);
 }
 
 // In-place factorisation of S padded systems (Kp x Kp, ld = Kp): the leading
@@ -303,13 +421,8 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
                                           SP_NB, q * SP_NB, -1.0, 0, G.S, nact, G.invL, G.info,
                                           G.st);
           if (rc != SP_OK) return rc;
-          const int r1 = c0 + nact;
-          if (r1 < Kp) {
-            double *P = G.sys + (size_t)r1 * ld + c0;
-            rc = sp_launch_gemm_nt(P, ld, stride, G.invL, SP_NB, (long)SP_NB * SP_NB, P, ld,
-                                   stride, Kp - r1, SP_NB, SP_NB, 1.0, 0, 0, G.S, G.st);
-            if (rc != SP_OK) return rc;
-          }
+          rc = launch_trsm(G.sys, ld, stride, G.S, c0 + nact, c0, Kp, G.invL, G.st);
+          if (rc != SP_OK) return rc;
           continue;
         }
         if (q > 0) {  // left-looking update of block column j by panels s0..j-1
@@ -361,10 +474,7 @@ int sp_debug_phase(sp_handle *h, double *sys, int S, int K, int Kp, int32_t *inf
     return SP_OK;
   }
   if (phase == 1) {
-    const int r1 = c0 + nact;
-    double *P = sys + (size_t)r1 * ld + c0;
-    return sp_launch_gemm_nt(P, ld, stride, invL, SP_NB, (long)SP_NB * SP_NB, P, ld, stride,
-                             Kp - r1, SP_NB, SP_NB, 1.0, 0, 0, S, st);
+    return launch_trsm(sys, ld, stride, S, c0 + nact, c0, Kp, invL, st);
   }
   return bulk_update(nullptr, sys, ld, stride, S, c0, c0 + SP_NB, Kp, SP_NB, st);
 }

@@ -81,8 +81,8 @@ __device__ __forceinline__ void stage_store(const PanelRegs<BK> &R, double scale
 //
 // FUSE_DIAG: tile (0, 0) of the launch is the diagonal block of the next panel.
 // The workgroup that owns it does not stop after its tile: it keeps the updated
-// block in LDS and factors it (diag_block, sp_diag.h), writing L_d and L_d^-1.
-// The ~15 us latency-bound factorisation then runs concurrently with the other
+// block in LDS and factors it (diag_block, sp_diag.h), writing L_d and L_d^T.
+// The latency-bound factorisation then runs concurrently with the other
 // tiles of the same launch instead of as a kernel of its own between launches.
 template <int BK, bool DEFER_C, bool FUSE_DIAG>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
 
   if (FUSE_DIAG && ti == 0 && tj == 0) {
     // the updated tile is the next diagonal block: factor it right here
-    double *sD = smem, *sY = smem + 64 * BLD;
+    double *sD = smem, *sRd = smem + 64 * BLD;
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
         sD[li * BLD + lj] = v;
       }
     __syncthreads();
-    const int notpd = diag_block(sD, sY, invL_all + (size_t)mtx * 4096);
+    const int notpd = diag_block(sD, sRd, invL_all + (size_t)mtx * 4096);
     if (notpd && info) info[mtx] = 1;
     const int cj = (threadIdx.x & 15) * 4, ri = threadIdx.x >> 4;
 #pragma unroll

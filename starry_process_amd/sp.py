@@ -94,7 +94,8 @@ class StarryProcess(object):
         if mean_ylm is None or cov_ylm is None:
             from .upstream import ylm_moments
 
-            mean_ylm, cov_ylm = ylm_moments(r=r, dr=dr, a=a, b=b, c=c, n=n, ydeg=self._ydeg, **kwargs)
+            mean_ylm, cov_ylm = ylm_moments(r=r, dr=dr, a=a, b=b, c=c, n=n, ydeg=self._ydeg,
+                                             **{k: v for k, v in kwargs.items() if k != "ydeg"})
         self._mean_ylm = np.asarray(mean_ylm, dtype=np.float64).reshape(-1)
         self._cov_ylm = np.asarray(cov_ylm, dtype=np.float64)
         if self._mean_ylm.shape != (self._nylm,) or self._cov_ylm.shape != (self._nylm, self._nylm):
