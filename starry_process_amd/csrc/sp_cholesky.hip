@@ -17,6 +17,9 @@
 //     [ r^T . ]                         [ y^T . ] ,   y = L^-1 r,
 // so r^T C^-1 r = |y|^2 falls out of the factorisation and no separate
 // triangular solve is needed for the likelihood.
+#include <cstdio>
+#include <vector>
+
 #include "sp_internal.h"
 
 #include "sp_diag.h"
@@ -28,11 +31,15 @@ namespace {
 // Stand-alone diagonal-block kernel: one workgroup per star (used for the first
 // panel of every super-panel; the other panels get their diagonal block from the
 // fused tile-(0,0) workgroup of the block-column update, sp_gemm.hip).
+template <bool TIMED>
 __global__ __launch_bounds__(256) void diag_kernel(double *__restrict__ sys, long ld,
                                                    long stride, int c0, int nact,
                                                    double *__restrict__ invL_all,
-                                                   int32_t *__restrict__ info) {
+                                                   int32_t *__restrict__ info,
+                                                   long long *__restrict__ dbg) {
   __shared__ __attribute__((aligned(16))) double lds[SP_DIAG_LDS_DOUBLES];
+  long long ts[5], tc[5];
+  if (TIMED) { ts[0] = wall_clock64(); tc[0] = clock64(); }
   double *sD = lds, *sRd = lds + 64 * BLD;
   double *Mx = sys + (size_t)blockIdx.x * stride;
   const int tid = threadIdx.x;
@@ -54,8 +61,11 @@ __global__ __launch_bounds__(256) void diag_kernel(double *__restrict__ sys, lon
     }
   }
   __syncthreads();
-  const int notpd = diag_block(sD, sRd, invL_all + (size_t)blockIdx.x * 4096);
+  if (TIMED) { ts[1] = wall_clock64(); tc[1] = clock64(); }
+  const int notpd = diag_block(sD, sRd, invL_all + (size_t)blockIdx.x * 4096,
+                               TIMED ? dbg + 8 + 40 * blockIdx.x + 0 : nullptr);
   if (notpd && info) info[blockIdx.x] = 1;
+  if (TIMED) { ts[2] = wall_clock64(); tc[2] = clock64(); }
   {
     const int cj = (tid & 15) * 4, ri = tid >> 4;
 #pragma unroll
@@ -66,6 +76,17 @@ __global__ __launch_bounds__(256) void diag_kernel(double *__restrict__ sys, lon
       for (int e = 0; e < 4; ++e) {
         const int c = cj + e;
         if (c <= r && r < nact) dst[e] = sD[r * BLD + c];
+      }
+    }
+  }
+  if (TIMED) {
+    __syncthreads();
+    ts[3] = wall_clock64();
+    tc[3] = clock64();
+    if (threadIdx.x == 0) {
+      for (int i = 0; i < 4; ++i) {
+        dbg[blockIdx.x * 40 + i] = ts[i];
+        dbg[blockIdx.x * 40 + 4 + i] = tc[i];
       }
     }
   }
@@ -379,8 +400,8 @@ static int diag_and_solve(double *sys, long ld, long stride, int S, int K, int K
   const int nact = K - c0 < SP_NB ? K - c0 : SP_NB;
   // diagonal block: L_d (and L_d^T for the solve)
   if (!have_diag) {
-    hipLaunchKernelGGL(diag_kernel, dim3(S), dim3(256), 0, st, sys, ld, stride, c0, nact,
-                       invL, info);
+    hipLaunchKernelGGL(diag_kernel<false>, dim3(S), dim3(256), 0, st, sys, ld, stride, c0, nact,
+                       invL, info, nullptr);
     SP_LAUNCH_CHECK();
   }
   // rows below the active block: X = P L_d^-T, in place
@@ -468,9 +489,44 @@ int sp_debug_phase(sp_handle *h, double *sys, int S, int K, int Kp, int32_t *inf
   const int c0 = j * SP_NB;
   const int nact = K - c0 < SP_NB ? K - c0 : SP_NB;
   if (phase == 0) {
-    hipLaunchKernelGGL(diag_kernel, dim3(S), dim3(256), 0, st, sys, ld, stride, c0, nact,
-                       invL, info);
+    hipLaunchKernelGGL(diag_kernel<false>, dim3(S), dim3(256), 0, st, sys, ld, stride, c0, nact,
+                       invL, info, nullptr);
     SP_LAUNCH_CHECK();
+    return SP_OK;
+  }
+  if (phase == 3) {  // in-kernel timestamps of the diagonal-block kernel, printed to stderr
+    long long *dbg = nullptr;
+    SP_HIP(hipMalloc(&dbg, sizeof(long long) * 40 * S));
+    for (int rep = 0; rep < 3; ++rep) {
+      hipLaunchKernelGGL(diag_kernel<true>, dim3(S), dim3(256), 0, st, sys, ld, stride, c0, nact,
+                         invL, info, dbg);
+      SP_LAUNCH_CHECK();
+    }
+    SP_HIP(hipStreamSynchronize(st));
+    std::vector<long long> hst(40 * (size_t)S);
+    SP_HIP(hipMemcpy(hst.data(), dbg, sizeof(long long) * 40 * S, hipMemcpyDeviceToHost));
+    (void)hipFree(dbg);
+    long long t0 = hst[0];
+    for (int b = 0; b < S; ++b) t0 = hst[40 * b] < t0 ? hst[40 * b] : t0;
+    {
+      const long long *r = &hst[0], c0k = r[5];
+      for (int kb = 0; kb < 4; ++kb) {
+        const long long *q = r + 8 + 8 * kb;
+        fprintf(stderr,
+                "  panel %d: start %6lld | load %5lld | leaf %6lld | publish %5lld | below %5lld | "
+                "barrier %5lld | update %5lld\n",
+                kb, q[0] - c0k, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4],
+                q[6] - q[5]);
+      }
+    }
+    for (int b = 0; b < S; b += (S > 8 ? S / 8 : 1)) {
+      const long long *r = &hst[40 * b];
+      fprintf(stderr,
+              "diag wg %3d: start +%6.2f us | load %6.2f us (%lld clk) | factor %6.2f us (%lld clk) | "
+              "store %6.2f us (%lld clk)\n",
+              b, (r[0] - t0) * 0.01, (r[1] - r[0]) * 0.01, r[5] - r[4], (r[2] - r[1]) * 0.01,
+              r[6] - r[5], (r[3] - r[2]) * 0.01, r[7] - r[6]);
+    }
     return SP_OK;
   }
   if (phase == 1) {

@@ -44,3 +44,6 @@ for j in range(nsteps):
     n = ((K + 1 + 63) // 64) * 64 - 64 * (j + 1)
     print("step %2d  n=%4d  diag %6.1f us  solve %6.1f us  update %7.1f us" % (j, n, *row))
 print("totals: diag %.1f  solve %.1f  update %.1f  sum %.1f us" % (*tot, sum(tot)))
+# in-kernel timestamps of the diagonal-block kernel (stderr)
+check(e._L.sp_debug_cholesky_phase(e._h, S, K, 1, e._p(ws), 3, 0, st))
+torch.cuda.synchronize()
