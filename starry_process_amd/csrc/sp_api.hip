@@ -189,7 +189,7 @@ Layout make_layout(const sp_handle *h, int S, int K, int M, bool with_sys) {
   L.cs = take(d * S * 2);
   L.vrow = take(d * S * L.N);
   L.Rinc = take(d * S * L.NWIG);
-  L.invL = take(d * (size_t)S * SP_NB * SP_NB);
+  L.invL = take(d * (size_t)S * SP_LT_DOUBLES);
   L.A = take(d * (size_t)S * K * L.N);
   L.B1 = take(d * (size_t)S * K * L.N);
   L.raw = take(d * (size_t)S * K * K);
@@ -301,7 +301,7 @@ Layout sub_layout(const Layout &L, int s0, int Sg) {
   G.cs += z * 2 * d;
   G.vrow += z * L.N * d;
   G.Rinc += z * L.NWIG * d;
-  G.invL += z * SP_NB * SP_NB * d;
+  G.invL += z * SP_LT_DOUBLES * d;
   G.A += z * L.K * L.N * d;
   G.B1 += z * L.K * L.N * d;
   G.raw += z * (size_t)L.K * L.K * d;
@@ -409,6 +409,7 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
   h->tab_scratch_bytes = 0;
   h->superpanel = 4;
   h->groups = 1;
+  h->chol_variant = 1;
   h->fuse_diag = 2;
   h->gfork = nullptr;
   h->prof_on = false;
@@ -455,6 +456,8 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
     h->fuse_diag = e4 ? atoi(e4) : 2;  // 0 off, 1 block-column updates, 2 + bulk updates
     const char *e3 = getenv("SP_GROUPS");
     h->groups = e3 ? atoi(e3) : 1;
+    const char *e9 = getenv("SP_CHOL");
+    h->chol_variant = e9 ? atoi(e9) : 1;
     const char *e2 = getenv("SP_SUPER");
     h->superpanel = e2 ? atoi(e2) : 4;
     if (h->superpanel < 1) h->superpanel = 1;
@@ -785,7 +788,7 @@ int sp_cho_factor(sp_handle *h, double *A_dev, int K, long lda, long strideA,
   hipStream_t st = (hipStream_t)stream;
   const int Kp = sp_roundup(K, SP_NB);
   const size_t sysb = align_up(sizeof(double) * (size_t)batch * Kp * Kp);
-  const size_t invb = align_up(sizeof(double) * (size_t)batch * SP_NB * SP_NB);
+  const size_t invb = align_up(sizeof(double) * (size_t)batch * SP_LT_DOUBLES);
   void *ws = nullptr;
   int rc = ensure_big(h, sysb + invb + align_up(sizeof(int32_t) * batch), &ws);
   if (rc) return rc;

@@ -22,7 +22,7 @@
 
 #include "sp_internal.h"
 
-#include "sp_diag.h"
+#include "sp_tile.h"
 
 #define DLD 65  // padded row length of a diagonal block in cho_solve_kernel
 
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void diag_kernel(double *__restrict__ sys, lon
   }
   __syncthreads();
   if (TIMED) { ts[1] = wall_clock64(); tc[1] = clock64(); }
-  const int notpd = diag_block(sD, sRd, invL_all + (size_t)blockIdx.x * 4096,
+  const int notpd = diag_block(sD, sRd, invL_all + (size_t)blockIdx.x * SP_LT_STRIDE,
                                TIMED ? dbg + 8 + 40 * blockIdx.x + 0 : nullptr);
   if (notpd && info) info[blockIdx.x] = 1;
   if (TIMED) { ts[2] = wall_clock64(); tc[2] = clock64(); }
@@ -102,51 +102,11 @@ __global__ __launch_bounds__(256) void diag_kernel(double *__restrict__ sys, lon
 // and left of the diagonal) and read as 16-byte pairs two steps ahead of use.
 // 576 fused multiply-adds per lane; the dependent chain per step is
 // FMA -> DPP -> FMA.  No barrier after the staging one.
-struct TrsmRow {
-  d2v v[8];
-};
-
-template <int K>
-__device__ __forceinline__ void trsm_fetch(TrsmRow &r, const double *sLT, int q) {
-  if (K < 64) {
-    const double *row = sLT + (K < 64 ? K : 0) * 64 + 2 * q;
-#pragma unroll
-    for (int i = (K >> 3); i < 8; ++i) r.v[i] = *reinterpret_cast<const d2v *>(row + 8 * i);
-  }
-}
-
-template <int K>
-struct TrsmStep {
-  static __device__ __forceinline__ void run(double (&x)[16], const TrsmRow &cur,
-                                             const TrsmRow &nxt, const double *sLT, int q) {
-    constexpr int IK = K >> 3, QK = (K >> 1) & 3, REG = 2 * IK + (K & 1);
-    constexpr int CTRL = QK * 0x55;  // quad_perm:[QK, QK, QK, QK]
-    TrsmRow nn;
-    trsm_fetch<K + 2>(nn, sLT, q);
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x[REG]), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x[REG]), CTRL, 0xf, 0xf, false);
-    const double xk = __hiloint2double(hi, lo);
-    // (cur.v holds 0 for the columns <= K, so x[REG] itself is left alone)
-#pragma unroll
-    for (int i = IK; i < 8; ++i) {
-      x[2 * i] = fma(-xk, cur.v[i].x, x[2 * i]);
-      x[2 * i + 1] = fma(-xk, cur.v[i].y, x[2 * i + 1]);
-    }
-    TrsmStep<K + 1>::run(x, nxt, nn, sLT, q);
-  }
-};
-template <>
-struct TrsmStep<64> {
-  static __device__ __forceinline__ void run(double (&)[16], const TrsmRow &, const TrsmRow &,
-                                             const double *, int) {}
-};
-
 __global__ __launch_bounds__(256) void trsm_quad_kernel(double *sys, long ld, long stride,
                                                         int r1, int c0, int nrows,
                                                         const double *__restrict__ LT_all,
                                                         int batch, int ntiles) {
-  __shared__ __attribute__((aligned(16))) double sLT[64 * 64];
-  __shared__ __attribute__((aligned(16))) double sRd[64];
+  __shared__ __attribute__((aligned(16))) double sLT[64 * 64 + 64];
   // XCD-aware decode as in sp_gemm.hip: all row tiles of one star on one XCD
   const int b = blockIdx.x;
   const int xcd = b & 7, slot = b >> 3;
@@ -157,46 +117,58 @@ __global__ __launch_bounds__(256) void trsm_quad_kernel(double *sys, long ld, lo
   const int lrow = tile * 64 + (tid >> 2), q = tid & 3;
   const bool valid = lrow < nrows;
   double *prow = sys + (size_t)mtx * stride + (size_t)(r1 + (valid ? lrow : 0)) * ld + c0 + 2 * q;
-  d2v lt[8], px[8];
-  {
-    const double *LT = LT_all + (size_t)mtx * 4096;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) lt[i] = *reinterpret_cast<const d2v *>(LT + 2 * (tid + 256 * i));
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) px[i] = *reinterpret_cast<const d2v *>(prow + 8 * i);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int e = 2 * (tid + 256 * i);
-    const int k = e >> 6, c = e & 63;
-    d2v v = lt[i];
-    const bool d0 = c == k, d1 = c + 1 == k;
-    if (d0 || d1) sRd[k] = d0 ? v.x : v.y;
-    v.x = d0 ? 0.0 : v.x;
-    v.y = d1 ? 0.0 : v.y;
-    *reinterpret_cast<d2v *>(sLT + e) = v;
-  }
-  __syncthreads();
+  LtRegs lt;
+  lt_load(lt, LT_all + (size_t)mtx * SP_LT_STRIDE);
   double x[16];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const d2v rd = *reinterpret_cast<const d2v *>(sRd + 8 * i + 2 * q);
-    x[2 * i] = px[i].x * rd.x;
-    x[2 * i + 1] = px[i].y * rd.y;
+    const d2v v = *reinterpret_cast<const d2v *>(prow + 8 * i);
+    x[2 * i] = v.x;
+    x[2 * i + 1] = v.y;
   }
-  TrsmRow r0, r1v;
-  trsm_fetch<0>(r0, sLT, q);
-  trsm_fetch<1>(r1v, sLT, q);
-  TrsmStep<0>::run(x, r0, r1v, sLT, q);
-  if (valid) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      d2v v;
-      v.x = x[2 * i];
-      v.y = x[2 * i + 1];
-      *reinterpret_cast<d2v *>(prow + 8 * i) = v;
-    }
+  lt_store(lt, sLT, sLT + 4096);
+  __syncthreads();
+  quad_solve_store(x, sLT, sLT + 4096, prow, valid);
+}
+
+// One launch for the rows below a super-panel (first column cS, wp panels): the
+// workgroup of a 64-row tile walks the wp panels itself -- bring the tile of panel
+// q up to date with the q panels before it (operands: its own rows, solved a
+// moment ago, and the L blocks of the factored diagonal block), then solve it
+// against L_d of panel q.  No dependency on any other workgroup of the launch.
+__global__ __launch_bounds__(256) void panel_solve_kernel(double *sys, long ld, long stride,
+                                                          int cS, int wp, int r0,
+                                                          const double *__restrict__ LT_all,
+                                                          int batch, int ntiles) {
+  __shared__ __attribute__((aligned(16))) double smem[SP_TILE_LDS_DOUBLES];
+  const int b = blockIdx.x;
+  const int xcd = b & 7, slot = b >> 3;
+  const int mtx = (slot / ntiles) * 8 + xcd;
+  if (mtx >= batch) return;
+  const int tile = slot % ntiles;
+  double *Mx = sys + (size_t)mtx * stride;
+  double *rows = Mx + (size_t)(r0 + 64 * tile) * ld;
+  const double *LT = LT_all + (size_t)mtx * SP_LT_STRIDE;
+  for (int q = 0; q < wp; ++q) {
+    const int c0 = cS + 64 * q;
+    LtRegs lt;
+    lt_load(lt, LT + (size_t)q * SP_LT_IMG);
+    d4 acc[4];
+    tile_load(acc, rows + c0, ld);
+    if (q > 0) tile_mac(acc, rows + cS, ld, Mx + (size_t)c0 * ld + cS, ld, 64 * q, smem);
+    tile_trsm_store(acc, lt, rows + c0, ld, smem);
   }
+}
+
+// Diagonal block of the first super-panel (the later ones are factored inside
+// the trailing-update launches, sp_gemm.hip FUSE == 2): one workgroup per star.
+__global__ __launch_bounds__(256) void superpanel_kernel(double *sys, long ld, long stride,
+                                                         int cS, int wp, int K, double *LT_all,
+                                                         int32_t *info) {
+  __shared__ __attribute__((aligned(16))) double smem[SP_TILE_LDS_DOUBLES];
+  const int mtx = blockIdx.x;
+  superpanel_factor(sys + (size_t)mtx * stride, ld, cS, wp, K,
+                    LT_all + (size_t)mtx * SP_LT_STRIDE, info ? info + mtx : nullptr, smem);
 }
 
 // lnlike = -1/2 sum_m |y_m|^2 - M sum_i log L_ii - K M / 2 log(2 pi)
@@ -418,8 +390,17 @@ static int diag_and_solve(double *sys, long ld, long stride, int S, int K, int K
 // per super-panel with a rank-64w update instead of w rank-64 updates.  The
 // trailing update is HBM-bound at k = 64 (8 flop per byte of C traffic,
 // measured 4.0 TB/s, profiles/r01_*); k = 64 w divides that traffic by w.
+static int cholesky_superpanels(sp_handle *h, const sp_chol_group &G, int K, int Kp);
+
 int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *grp, int K,
                               int Kp) {
+  if (!h || h->chol_variant == 1) {
+    for (int g = 0; g < ngroups; ++g) {
+      int rc = cholesky_superpanels(h, grp[g], K, Kp);
+      if (rc != SP_OK) return rc;
+    }
+    return SP_OK;
+  }
   const long ld = Kp, stride = (long)Kp * Kp;
   const int nsteps = (K + SP_NB - 1) / SP_NB;
   const int w = (h && h->superpanel > 0) ? h->superpanel : 1;
@@ -469,6 +450,53 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
                              grp[g].st, (h && h->fuse_diag > 1) ? nactE : 0, grp[g].invL,
                              grp[g].info);
         if (rc != SP_OK) return rc;
+      }
+    }
+  }
+  return SP_OK;
+}
+
+// Variant 1 (default): per super-panel of w <= 4 panels
+//   panel_solve_kernel   rows below the super-panel, all w panels in one launch
+//   trailing update      rank-64w, one launch; the workgroup that completes the
+//                        next super-panel's diagonal block factors it on the spot
+// plus one superpanel_kernel launch for the very first diagonal block:
+// 2 launches per super-panel instead of 2 per panel.
+static int cholesky_superpanels(sp_handle *h, const sp_chol_group &G, int K, int Kp) {
+  const long ld = Kp, stride = (long)Kp * Kp;
+  const int nsteps = (K + SP_NB - 1) / SP_NB;
+  const int W = 4;
+  // arrival counters of the fused factorisation (one per star, after the images)
+  SP_HIP(hipMemset2DAsync(G.invL + 4 * SP_LT_IMG, sizeof(double) * SP_LT_STRIDE, 0,
+                          sizeof(double), G.S, G.st));
+  hipLaunchKernelGGL(superpanel_kernel, dim3(G.S), dim3(256), 0, G.st, G.sys, ld, stride, 0,
+                     nsteps < W ? nsteps : W, K, G.invL, G.info);
+  SP_LAUNCH_CHECK();
+  for (int s0 = 0; s0 < nsteps; s0 += W) {
+    const int wp = nsteps - s0 < W ? nsteps - s0 : W;
+    const int cS = s0 * SP_NB, rB = cS + wp * SP_NB;
+    if (rB < Kp) {
+      const int ntiles = (Kp - rB) / SP_NB;
+      const long nblk = 8L * ((G.S + 7) / 8) * ntiles;
+      hipLaunchKernelGGL(panel_solve_kernel, dim3((unsigned)nblk), dim3(256), 0, G.st, G.sys, ld,
+                         stride, cS, wp, rB, G.invL, G.S, ntiles);
+      SP_LAUNCH_CHECK();
+    }
+    if (s0 + W < nsteps) {
+      const int wpn = nsteps - s0 - W < W ? nsteps - s0 - W : W;
+      const int n = Kp - rB;
+      double *X = G.sys + (size_t)rB * ld + cS;
+      double *T = G.sys + (size_t)rB * ld + rB;
+      const bool timed = h && h->prof_on && h->prof_used + 2 <= h->prof_ev.size();
+      if (timed) SP_HIP(hipEventRecord(h->prof_ev[h->prof_used], G.st));
+      int rc = sp_launch_gemm_nt_super(X, ld, stride, T, ld, stride, n, wp * SP_NB, G.S, G.sys,
+                                       stride, rB, wpn, K, G.invL, G.info, G.st);
+      if (rc != SP_OK) return rc;
+      if (timed) {
+        SP_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], G.st));
+        h->prof_used += 2;
+        h->prof_flops += (double)G.S * (double)n * (n + 1) * (wp * SP_NB);
+        h->prof_launches += 1;
       }
     }
   }

@@ -19,7 +19,7 @@
 #include <cstdlib>
 
 #include "sp_internal.h"
-#include "sp_diag.h"
+#include "sp_tile.h"
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
@@ -79,27 +79,36 @@ __device__ __forceinline__ void stage_store(const PanelRegs<BK> &R, double scale
 // the C-tile loads before staging but consume them only after the MFMA loop, so
 // their HBM latency hides behind the panel staging and the matrix work.
 //
-// FUSE_DIAG: tile (0, 0) of the launch is the diagonal block of the next panel.
+// FUSE == 1: tile (0, 0) of the launch is the diagonal block of the next panel.
 // The workgroup that owns it does not stop after its tile: it keeps the updated
 // block in LDS and factors it (diag_block, sp_diag.h), writing L_d and L_d^T.
 // The latency-bound factorisation then runs concurrently with the other
 // tiles of the same launch instead of as a kernel of its own between launches.
-template <int BK, bool DEFER_C, bool FUSE_DIAG>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(
+//
+// FUSE == 2 (the rank-64w trailing update): the tiles with tile row < wpn are
+// the diagonal block of the NEXT super-panel.  Each of their workgroups counts
+// itself in (agent-scope release, one atomic add per workgroup); the one that
+// arrives last -- no workgroup ever waits -- goes on to factor that whole block
+// (superpanel_factor, sp_tile.h) while the rest of the launch keeps the machine
+// busy.  These tiles come first in the launch order, so the factorisation starts
+// a few microseconds into the launch.
+template <int BK, bool DEFER_C, int FUSE>
+__global__ __launch_bounds__(256, FUSE == 2 ? 3 : 1) void gemm_nt_kernel(
     const double *A, long lda, long strideA,
     const double *__restrict__ B, long ldb, long strideB, double *C,
     long ldc, long strideC, int Mrows, int Nrows, int Kd, double alpha,
     int beta, int lower_only, int batch, int ntm, int ntn, int ntiles, int nact,
-    double *invL_all, int32_t *info) {
+    double *invL_all, int32_t *info, double *sys_all, long stride_sys, int cS2, int wpn,
+    int Kord) {
   // Padded LDS row of BK + 1 doubles.  hipcc fuses the per-k-step fragment reads
   // into ds_read2_b64, which is banked mod 32 dwords in 16-lane groups: an ODD
   // row length puts the 16 rows of a group on 16 distinct bank pairs.  (An even
   // row length of BK + 2 is conflict-free only for plain ds_read_b64 and cost
   // 42% extra LDS cycles here: SQ_LDS_BANK_CONFLICT, profiles/r01_v3_pmc.txt.)
   constexpr int LDW = BK + 1;
-  constexpr int NLDS = FUSE_DIAG ? (2 * GT * LDW > SP_DIAG_LDS_DOUBLES ? 2 * GT * LDW
-                                                                       : SP_DIAG_LDS_DOUBLES)
-                                 : 2 * GT * LDW;
+  constexpr int NLDS = FUSE ? (2 * GT * LDW > SP_TILE_LDS_DOUBLES ? 2 * GT * LDW
+                                                                  : SP_TILE_LDS_DOUBLES)
+                            : 2 * GT * LDW;
   __shared__ __attribute__((aligned(16))) double smem[NLDS];
   double *sA = smem, *sB = smem + GT * LDW;
 
@@ -191,7 +200,27 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
       if (full || (gi < Mrows && gj < Nrows)) Cb[(size_t)gi * ldc + gj] = acc[n][r];
     }
 
-  if (FUSE_DIAG && ti == 0 && tj == 0) {
+  if (FUSE == 2 && ti < wpn) {
+    // a tile of the next super-panel's diagonal block: publish it, count in
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    int *cnt = reinterpret_cast<int *>(invL_all + (size_t)mtx * SP_LT_STRIDE + 4 * SP_LT_IMG);
+    if (threadIdx.x == 0) {
+      const int target = wpn * (wpn + 1) / 2;
+      const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = old == target - 1;
+      if (s_last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (s_last) {
+      __threadfence();
+      __builtin_amdgcn_s_setprio(3);
+      superpanel_factor(sys_all + (size_t)mtx * stride_sys, ldc, cS2, wpn, Kord,
+                        invL_all + (size_t)mtx * SP_LT_STRIDE, info ? info + mtx : nullptr, smem);
+    }
+  }
+  if (FUSE == 1 && ti == 0 && tj == 0) {
     // the updated tile is the next diagonal block: factor it right here
     double *sD = smem, *sRd = smem + 64 * BLD;
 #pragma unroll
@@ -204,7 +233,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
         sD[li * BLD + lj] = v;
       }
     __syncthreads();
-    const int notpd = diag_block(sD, sRd, invL_all + (size_t)mtx * 4096);
+    const int notpd = diag_block(sD, sRd, invL_all + (size_t)mtx * SP_LT_STRIDE);
     if (notpd && info) info[mtx] = 1;
     const int cj = (threadIdx.x & 15) * 4, ri = threadIdx.x >> 4;
 #pragma unroll
@@ -223,7 +252,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
 static int launch_gemm(const double *A, long lda, long strideA, const double *B, long ldb,
                        long strideB, double *C, long ldc, long strideC, int Mrows, int Nrows,
                        int Kd, double alpha, int beta, int lower_only, int batch, int fuse,
-                       int nact, double *invL, int32_t *info, hipStream_t st) {
+                       int nact, double *invL, int32_t *info, hipStream_t st,
+                       double *sys_all = nullptr, long stride_sys = 0, int cS2 = 0, int wpn = 0,
+                       int Kord = 0) {
   if (Mrows <= 0 || Nrows <= 0 || batch <= 0) return SP_OK;
   if (Kd < 0) return SP_ERR_INVALID;
   const int ntm = (Mrows + GT - 1) / GT, ntn = (Nrows + GT - 1) / GT;
@@ -239,15 +270,18 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
 #define SP_GO(BK, DC, FD)                                                              \
   hipLaunchKernelGGL((gemm_nt_kernel<BK, DC, FD>), dim3((unsigned)nblk), dim3(256), 0, st, \
                      A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd, \
-                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info)
-  if (fuse) {
-    SP_GO(32, false, true);
+                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, sys_all, \
+                     stride_sys, cS2, wpn, Kord)
+  if (fuse == 2) {
+    SP_GO(32, false, 2);
+  } else if (fuse) {
+    SP_GO(32, false, 1);
   } else {
     switch (variant) {
-      case 1: SP_GO(32, true, false); break;
-      case 2: SP_GO(64, false, false); break;
-      case 3: SP_GO(64, true, false); break;
-      default: SP_GO(32, false, false); break;
+      case 1: SP_GO(32, true, 0); break;
+      case 2: SP_GO(64, false, 0); break;
+      case 3: SP_GO(64, true, 0); break;
+      default: SP_GO(32, false, 0); break;
     }
   }
 #undef SP_GO
@@ -271,4 +305,16 @@ int sp_launch_gemm_nt_diag(const double *A, long lda, long strideA, const double
                            int nact, double *invL, int32_t *info, hipStream_t st) {
   return launch_gemm(A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd,
                      alpha, 1, lower_only, batch, 1, nact, invL, info, st);
+}
+
+// Rank-kd trailing update C -= X X^T (lower tiles) whose first wpn tile rows are
+// the diagonal block of the next super-panel (first column cS2 of the systems
+// sys_all): the last of those tiles' workgroups to finish factors that block
+// (FUSE == 2 above).  LT: per-star scratch of SP_LT_STRIDE doubles.
+int sp_launch_gemm_nt_super(const double *X, long ldx, long strideX, double *C, long ldc,
+                            long strideC, int n, int Kd, int batch, double *sys_all,
+                            long stride_sys, int cS2, int wpn, int Kord, double *LT,
+                            int32_t *info, hipStream_t st) {
+  return launch_gemm(X, ldx, strideX, X, ldx, strideX, C, ldc, strideC, n, n, Kd, -1.0, 1, 1,
+                     batch, 2, 0, LT, info, st, sys_all, stride_sys, cS2, wpn, Kord);
 }
