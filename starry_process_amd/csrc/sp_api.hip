@@ -409,7 +409,6 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
   h->tab_scratch_bytes = 0;
   h->superpanel = 4;
   h->groups = 1;
-  h->chol_variant = 1;
   h->fuse_diag = 2;
   h->gfork = nullptr;
   h->prof_on = false;
@@ -456,8 +455,6 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
     h->fuse_diag = e4 ? atoi(e4) : 2;  // 0 off, 1 block-column updates, 2 + bulk updates
     const char *e3 = getenv("SP_GROUPS");
     h->groups = e3 ? atoi(e3) : 1;
-    const char *e9 = getenv("SP_CHOL");
-    h->chol_variant = e9 ? atoi(e9) : 1;
     const char *e2 = getenv("SP_SUPER");
     h->superpanel = e2 ? atoi(e2) : 4;
     if (h->superpanel < 1) h->superpanel = 1;

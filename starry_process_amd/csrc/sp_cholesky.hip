@@ -131,46 +131,6 @@ __global__ __launch_bounds__(256) void trsm_quad_kernel(double *sys, long ld, lo
   quad_solve_store(x, sLT, sLT + 4096, prow, valid);
 }
 
-// One launch for the rows below a super-panel (first column cS, wp panels): the
-// workgroup of a 64-row tile walks the wp panels itself -- bring the tile of panel
-// q up to date with the q panels before it (operands: its own rows, solved a
-// moment ago, and the L blocks of the factored diagonal block), then solve it
-// against L_d of panel q.  No dependency on any other workgroup of the launch.
-__global__ __launch_bounds__(256) void panel_solve_kernel(double *sys, long ld, long stride,
-                                                          int cS, int wp, int r0,
-                                                          const double *__restrict__ LT_all,
-                                                          int batch, int ntiles) {
-  __shared__ __attribute__((aligned(16))) double smem[SP_TILE_LDS_DOUBLES];
-  const int b = blockIdx.x;
-  const int xcd = b & 7, slot = b >> 3;
-  const int mtx = (slot / ntiles) * 8 + xcd;
-  if (mtx >= batch) return;
-  const int tile = slot % ntiles;
-  double *Mx = sys + (size_t)mtx * stride;
-  double *rows = Mx + (size_t)(r0 + 64 * tile) * ld;
-  const double *LT = LT_all + (size_t)mtx * SP_LT_STRIDE;
-  for (int q = 0; q < wp; ++q) {
-    const int c0 = cS + 64 * q;
-    LtRegs lt;
-    lt_load(lt, LT + (size_t)q * SP_LT_IMG);
-    d4 acc[4];
-    tile_load(acc, rows + c0, ld);
-    if (q > 0) tile_mac(acc, rows + cS, ld, Mx + (size_t)c0 * ld + cS, ld, 64 * q, smem);
-    tile_trsm_store(acc, lt, rows + c0, ld, smem);
-  }
-}
-
-// Diagonal block of the first super-panel (the later ones are factored inside
-// the trailing-update launches, sp_gemm.hip FUSE == 2): one workgroup per star.
-__global__ __launch_bounds__(256) void superpanel_kernel(double *sys, long ld, long stride,
-                                                         int cS, int wp, int K, double *LT_all,
-                                                         int32_t *info) {
-  __shared__ __attribute__((aligned(16))) double smem[SP_TILE_LDS_DOUBLES];
-  const int mtx = blockIdx.x;
-  superpanel_factor(sys + (size_t)mtx * stride, ld, cS, wp, K,
-                    LT_all + (size_t)mtx * SP_LT_STRIDE, info ? info + mtx : nullptr, smem);
-}
-
 // lnlike = -1/2 sum_m |y_m|^2 - M sum_i log L_ii - K M / 2 log(2 pi)
 // (sp.py:1157-1188).  One workgroup per star.
 __global__ __launch_bounds__(256) void lnlike_reduce_kernel(
@@ -320,6 +280,41 @@ __global__ __launch_bounds__(256) void cho_solve_kernel(
   for (int i = tid; i < K; i += 256) B[(size_t)i * nrhs] = x[i];
 }
 
+// Sustained fp64 MFMA rate of the device (debug phase 5): every wavefront issues
+// `iters` x 8 independent v_mfma_f64_16x16x4_f64 from registers; clock64() /
+// wall_clock64() give the shader clock actually held under that load.
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, double *sink, long long *ts, int rnd) {
+  d4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+  // operands with random mantissas (two alternating sets): data toggling as in a
+  // real product, which is what the power management reacts to
+  unsigned long long hsh = (threadIdx.x + 1) * 0x9E3779B97F4A7C15ull + blockIdx.x * 0xD1B54A32D192ED03ull;
+  double av[2], bv[2];
+  for (int i = 0; i < 2; ++i) {
+    hsh ^= hsh >> 29; hsh *= 0xBF58476D1CE4E5B9ull; hsh ^= hsh >> 32;
+    av[i] = rnd ? __longlong_as_double(0x3FE0000000000000ull | (hsh & 0xFFFFFFFFFFFFFull)) - 0.75 : 1.0 + threadIdx.x * 1e-9;
+    hsh ^= hsh >> 29; hsh *= 0x94D049BB133111EBull; hsh ^= hsh >> 32;
+    bv[i] = rnd ? __longlong_as_double(0x3FE0000000000000ull | (hsh & 0xFFFFFFFFFFFFFull)) - 0.75 : 1.0 - threadIdx.x * 1e-9;
+  }
+  const long long w0 = wall_clock64(), c0 = clock64();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      acc[i % NACC] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i & 1], bv[i & 1], acc[i % NACC], 0, 0, 0);
+  }
+  const long long c1 = clock64(), w1 = wall_clock64();
+  double t = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (t == 123.456) sink[0] = t;
+  if (threadIdx.x == 0) {
+    ts[2 * blockIdx.x] = w1 - w0;
+    ts[2 * blockIdx.x + 1] = c1 - c0;
+  }
+}
+
 }  // namespace
 
 // ---- launchers ---------------------------------------------------------------
@@ -390,17 +385,8 @@ static int diag_and_solve(double *sys, long ld, long stride, int S, int K, int K
 // per super-panel with a rank-64w update instead of w rank-64 updates.  The
 // trailing update is HBM-bound at k = 64 (8 flop per byte of C traffic,
 // measured 4.0 TB/s, profiles/r01_*); k = 64 w divides that traffic by w.
-static int cholesky_superpanels(sp_handle *h, const sp_chol_group &G, int K, int Kp);
-
 int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *grp, int K,
                               int Kp) {
-  if (!h || h->chol_variant == 1) {
-    for (int g = 0; g < ngroups; ++g) {
-      int rc = cholesky_superpanels(h, grp[g], K, Kp);
-      if (rc != SP_OK) return rc;
-    }
-    return SP_OK;
-  }
   const long ld = Kp, stride = (long)Kp * Kp;
   const int nsteps = (K + SP_NB - 1) / SP_NB;
   const int w = (h && h->superpanel > 0) ? h->superpanel : 1;
@@ -456,53 +442,6 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
   return SP_OK;
 }
 
-// Variant 1 (default): per super-panel of w <= 4 panels
-//   panel_solve_kernel   rows below the super-panel, all w panels in one launch
-//   trailing update      rank-64w, one launch; the workgroup that completes the
-//                        next super-panel's diagonal block factors it on the spot
-// plus one superpanel_kernel launch for the very first diagonal block:
-// 2 launches per super-panel instead of 2 per panel.
-static int cholesky_superpanels(sp_handle *h, const sp_chol_group &G, int K, int Kp) {
-  const long ld = Kp, stride = (long)Kp * Kp;
-  const int nsteps = (K + SP_NB - 1) / SP_NB;
-  const int W = 4;
-  // arrival counters of the fused factorisation (one per star, after the images)
-  SP_HIP(hipMemset2DAsync(G.invL + 4 * SP_LT_IMG, sizeof(double) * SP_LT_STRIDE, 0,
-                          sizeof(double), G.S, G.st));
-  hipLaunchKernelGGL(superpanel_kernel, dim3(G.S), dim3(256), 0, G.st, G.sys, ld, stride, 0,
-                     nsteps < W ? nsteps : W, K, G.invL, G.info);
-  SP_LAUNCH_CHECK();
-  for (int s0 = 0; s0 < nsteps; s0 += W) {
-    const int wp = nsteps - s0 < W ? nsteps - s0 : W;
-    const int cS = s0 * SP_NB, rB = cS + wp * SP_NB;
-    if (rB < Kp) {
-      const int ntiles = (Kp - rB) / SP_NB;
-      const long nblk = 8L * ((G.S + 7) / 8) * ntiles;
-      hipLaunchKernelGGL(panel_solve_kernel, dim3((unsigned)nblk), dim3(256), 0, G.st, G.sys, ld,
-                         stride, cS, wp, rB, G.invL, G.S, ntiles);
-      SP_LAUNCH_CHECK();
-    }
-    if (s0 + W < nsteps) {
-      const int wpn = nsteps - s0 - W < W ? nsteps - s0 - W : W;
-      const int n = Kp - rB;
-      double *X = G.sys + (size_t)rB * ld + cS;
-      double *T = G.sys + (size_t)rB * ld + rB;
-      const bool timed = h && h->prof_on && h->prof_used + 2 <= h->prof_ev.size();
-      if (timed) SP_HIP(hipEventRecord(h->prof_ev[h->prof_used], G.st));
-      int rc = sp_launch_gemm_nt_super(X, ld, stride, T, ld, stride, n, wp * SP_NB, G.S, G.sys,
-                                       stride, rB, wpn, K, G.invL, G.info, G.st);
-      if (rc != SP_OK) return rc;
-      if (timed) {
-        SP_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], G.st));
-        h->prof_used += 2;
-        h->prof_flops += (double)G.S * (double)n * (n + 1) * (wp * SP_NB);
-        h->prof_launches += 1;
-      }
-    }
-  }
-  return SP_OK;
-}
-
 int sp_launch_cholesky_systems(sp_handle *h, double *sys, int S, int K, int Kp,
                                int32_t *info, double *invL, hipStream_t st) {
   sp_chol_group g{sys, info, invL, S, st};
@@ -522,6 +461,41 @@ int sp_debug_phase(sp_handle *h, double *sys, int S, int K, int Kp, int32_t *inf
     SP_LAUNCH_CHECK();
     return SP_OK;
   }
+  if (phase == 5) {
+    const int nb = 256 * (j > 0 ? j : 1), iters = 20000;
+    long long *ts = nullptr;
+    double *sink = nullptr;
+    SP_HIP(hipMalloc(&ts, sizeof(long long) * 2 * nb));
+    SP_HIP(hipMalloc(&sink, 64));
+    hipEvent_t e0, e1;
+    SP_HIP(hipEventCreate(&e0));
+    SP_HIP(hipEventCreate(&e1));
+    const int rnd = K & 1 ? 0 : 1;  // (debug) odd K: constant operands
+    const int nacc = (K >> 1) & 3;  // (debug) accumulators per wave: 0 -> 8, 1 -> 4, 2 -> 2, 3 -> 1
+#define SP_PEAK_GO(N, IT) hipLaunchKernelGGL(mfma_peak_kernel<N>, dim3(nb), dim3(256), 0, st, IT, sink, ts, rnd)
+    if (nacc == 0) SP_PEAK_GO(8, 100); else if (nacc == 1) SP_PEAK_GO(4, 100); else if (nacc == 2) SP_PEAK_GO(2, 100); else SP_PEAK_GO(1, 100);
+    SP_HIP(hipEventRecord(e0, st));
+    if (nacc == 0) SP_PEAK_GO(8, iters); else if (nacc == 1) SP_PEAK_GO(4, iters); else if (nacc == 2) SP_PEAK_GO(2, iters); else SP_PEAK_GO(1, iters);
+    SP_HIP(hipEventRecord(e1, st));
+    SP_HIP(hipStreamSynchronize(st));
+    float ms = 0;
+    SP_HIP(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<long long> hst(2 * (size_t)nb);
+    SP_HIP(hipMemcpy(hst.data(), ts, sizeof(long long) * 2 * nb, hipMemcpyDeviceToHost));
+    double mhz = 0;
+    for (int b = 0; b < nb; ++b) mhz += (double)hst[2 * b + 1] / ((double)hst[2 * b] * 0.01);
+    mhz /= nb;
+    const double flops = (double)nb * 4 * iters * 8 * 2048.0;
+    fprintf(stderr, "fp64 MFMA peak (%s operands): %d workgroups/CU-slot x 4 waves: %.1f TFLOP/s, shader clock %.0f MHz, %.3f ms\n",
+            nacc == 0 ? "8 acc" : nacc == 1 ? "4 acc" : nacc == 2 ? "2 acc" : "1 acc", j > 0 ? j : 1, flops / (ms * 1e-3) * 1e-12, mhz, ms);
+    (void)hipFree(ts);
+    (void)hipFree(sink);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return SP_OK;
+  }
+  if (phase == 4)  // the rank-256 trailing update of the first super-panel, not fused
+    return bulk_update(nullptr, sys, ld, stride, S, 0, 4 * SP_NB, Kp, 4 * SP_NB, st);
   if (phase == 3) {  // in-kernel timestamps of the diagonal-block kernel, printed to stderr
     long long *dbg = nullptr;
     SP_HIP(hipMalloc(&dbg, sizeof(long long) * 40 * S));

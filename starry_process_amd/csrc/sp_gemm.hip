@@ -84,22 +84,17 @@ __device__ __forceinline__ void stage_store(const PanelRegs<BK> &R, double scale
 // block in LDS and factors it (diag_block, sp_diag.h), writing L_d and L_d^T.
 // The latency-bound factorisation then runs concurrently with the other
 // tiles of the same launch instead of as a kernel of its own between launches.
-//
-// FUSE == 2 (the rank-64w trailing update): the tiles with tile row < wpn are
-// the diagonal block of the NEXT super-panel.  Each of their workgroups counts
-// itself in (agent-scope release, one atomic add per workgroup); the one that
-// arrives last -- no workgroup ever waits -- goes on to factor that whole block
-// (superpanel_factor, sp_tile.h) while the rest of the launch keeps the machine
-// busy.  These tiles come first in the launch order, so the factorisation starts
-// a few microseconds into the launch.
-template <int BK, bool DEFER_C, int FUSE>
-__global__ __launch_bounds__(256, FUSE == 2 ? 3 : 1) void gemm_nt_kernel(
+// ABL (debug only, tools/microbench.py): ablations that locate the bound of the
+// trailing update -- 1: operand slices fetched from global memory once, 2: also no
+// LDS staging stores / barriers in the loop, 3: also no LDS fragment reads (MFMA
+// issue only), 4: everything but the C tile load / store.  Results are garbage.
+template <int BK, bool DEFER_C, int FUSE, int ABL = 0>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(
     const double *A, long lda, long strideA,
     const double *__restrict__ B, long ldb, long strideB, double *C,
     long ldc, long strideC, int Mrows, int Nrows, int Kd, double alpha,
     int beta, int lower_only, int batch, int ntm, int ntn, int ntiles, int nact,
-    double *invL_all, int32_t *info, double *sys_all, long stride_sys, int cS2, int wpn,
-    int Kord) {
+    double *invL_all, int32_t *info) {
   // Padded LDS row of BK + 1 doubles.  hipcc fuses the per-k-step fragment reads
   // into ds_read2_b64, which is banked mod 32 dwords in 16-lane groups: an ODD
   // row length puts the 16 rows of a group on 16 distinct bank pairs.  (An even
@@ -143,7 +138,7 @@ __global__ __launch_bounds__(256, FUSE == 2 ? 3 : 1) void gemm_nt_kernel(
     cin[n] = d4{0.0, 0.0, 0.0, 0.0};
   }
   const bool full = row0 + GT <= Mrows && col0 + GT <= Nrows;
-  if (beta) {
+  if (beta && ABL != 4) {
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll
@@ -163,11 +158,19 @@ __global__ __launch_bounds__(256, FUSE == 2 ? 3 : 1) void gemm_nt_kernel(
   PanelRegs<BK> ra, rb;
   stage_load<BK>(Ab, lda, row0, Mrows, 0, Kd, vecA, ra);
   stage_load<BK>(Bb, ldb, col0, Nrows, 0, Kd, vecB, rb);
-  for (int k0 = 0; k0 < Kd; k0 += BK) {
+  if (ABL == 2 || ABL == 3) {
     stage_store<BK>(ra, alpha, sA);
     stage_store<BK>(rb, 1.0, sB);
     __syncthreads();
-    if (k0 + BK < Kd) {  // next slice: loads fly while this slice is multiplied
+  }
+  double fa = ra.v[0].x, fb0 = rb.v[0].x, fb1 = rb.v[0].y, fb2 = rb.v[1].x, fb3 = rb.v[1].y;
+  for (int k0 = 0; k0 < Kd; k0 += BK) {
+    if (ABL < 2 || ABL == 4) {
+      stage_store<BK>(ra, alpha, sA);
+      stage_store<BK>(rb, 1.0, sB);
+      __syncthreads();
+    }
+    if (k0 + BK < Kd && (ABL == 0 || ABL == 4)) {  // next slice: loads fly while this slice is multiplied
       stage_load<BK>(Ab, lda, row0, Mrows, k0 + BK, Kd, vecA, ra);
       stage_load<BK>(Bb, ldb, col0, Nrows, k0 + BK, Kd, vecB, rb);
     }
@@ -175,17 +178,17 @@ __global__ __launch_bounds__(256, FUSE == 2 ? 3 : 1) void gemm_nt_kernel(
     const double *pb = sB + fr * LDW + fk;
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
-      const double a = pa[kk];
-      const double b0 = pb[kk];
-      const double b1 = pb[16 * LDW + kk];
-      const double b2 = pb[32 * LDW + kk];
-      const double b3 = pb[48 * LDW + kk];
+      const double a = ABL == 3 ? fa : pa[kk];
+      const double b0 = ABL == 3 ? fb0 : pb[kk];
+      const double b1 = ABL == 3 ? fb1 : pb[16 * LDW + kk];
+      const double b2 = ABL == 3 ? fb2 : pb[32 * LDW + kk];
+      const double b3 = ABL == 3 ? fb3 : pb[48 * LDW + kk];
       acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc[1], 0, 0, 0);
       acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b2, acc[2], 0, 0, 0);
       acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b3, acc[3], 0, 0, 0);
     }
-    __syncthreads();
+    if (ABL < 2 || ABL == 4) __syncthreads();
   }
   if (DEFER_C && beta) {
 #pragma unroll
@@ -197,29 +200,10 @@ __global__ __launch_bounds__(256, FUSE == 2 ? 3 : 1) void gemm_nt_kernel(
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int gi = row0 + 16 * wave + fk + 4 * r, gj = col0 + 16 * n + fr;
-      if (full || (gi < Mrows && gj < Nrows)) Cb[(size_t)gi * ldc + gj] = acc[n][r];
+      if ((ABL != 4 || acc[n][r] == 123.456) && (full || (gi < Mrows && gj < Nrows)))
+        Cb[(size_t)gi * ldc + gj] = acc[n][r];
     }
 
-  if (FUSE == 2 && ti < wpn) {
-    // a tile of the next super-panel's diagonal block: publish it, count in
-    __shared__ int s_last;
-    __threadfence();
-    __syncthreads();
-    int *cnt = reinterpret_cast<int *>(invL_all + (size_t)mtx * SP_LT_STRIDE + 4 * SP_LT_IMG);
-    if (threadIdx.x == 0) {
-      const int target = wpn * (wpn + 1) / 2;
-      const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = old == target - 1;
-      if (s_last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (s_last) {
-      __threadfence();
-      __builtin_amdgcn_s_setprio(3);
-      superpanel_factor(sys_all + (size_t)mtx * stride_sys, ldc, cS2, wpn, Kord,
-                        invL_all + (size_t)mtx * SP_LT_STRIDE, info ? info + mtx : nullptr, smem);
-    }
-  }
   if (FUSE == 1 && ti == 0 && tj == 0) {
     // the updated tile is the next diagonal block: factor it right here
     double *sD = smem, *sRd = smem + 64 * BLD;
@@ -252,9 +236,7 @@ __global__ __launch_bounds__(256, FUSE == 2 ? 3 : 1) void gemm_nt_kernel(
 static int launch_gemm(const double *A, long lda, long strideA, const double *B, long ldb,
                        long strideB, double *C, long ldc, long strideC, int Mrows, int Nrows,
                        int Kd, double alpha, int beta, int lower_only, int batch, int fuse,
-                       int nact, double *invL, int32_t *info, hipStream_t st,
-                       double *sys_all = nullptr, long stride_sys = 0, int cS2 = 0, int wpn = 0,
-                       int Kord = 0) {
+                       int nact, double *invL, int32_t *info, hipStream_t st) {
   if (Mrows <= 0 || Nrows <= 0 || batch <= 0) return SP_OK;
   if (Kd < 0) return SP_ERR_INVALID;
   const int ntm = (Mrows + GT - 1) / GT, ntn = (Nrows + GT - 1) / GT;
@@ -270,10 +252,23 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
 #define SP_GO(BK, DC, FD)                                                              \
   hipLaunchKernelGGL((gemm_nt_kernel<BK, DC, FD>), dim3((unsigned)nblk), dim3(256), 0, st, \
                      A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd, \
-                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, sys_all, \
-                     stride_sys, cS2, wpn, Kord)
-  if (fuse == 2) {
-    SP_GO(32, false, 2);
+                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info)
+  static int abl = -1;
+  if (abl < 0) {
+    const char *e = getenv("SP_GEMM_ABL");
+    abl = e ? atoi(e) : 0;
+  }
+#define SP_GO_ABL(N)                                                                          \
+  hipLaunchKernelGGL((gemm_nt_kernel<32, false, 0, N>), dim3((unsigned)nblk), dim3(256), 0, st, \
+                     A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd,       \
+                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info)
+  if (abl > 0 && !fuse) {
+    switch (abl) {
+      case 1: SP_GO_ABL(1); break;
+      case 2: SP_GO_ABL(2); break;
+      case 3: SP_GO_ABL(3); break;
+      default: SP_GO_ABL(4); break;
+    }
   } else if (fuse) {
     SP_GO(32, false, 1);
   } else {
@@ -307,14 +302,3 @@ int sp_launch_gemm_nt_diag(const double *A, long lda, long strideA, const double
                      alpha, 1, lower_only, batch, 1, nact, invL, info, st);
 }
 
-// Rank-kd trailing update C -= X X^T (lower tiles) whose first wpn tile rows are
-// the diagonal block of the next super-panel (first column cS2 of the systems
-// sys_all): the last of those tiles' workgroups to finish factors that block
-// (FUSE == 2 above).  LT: per-star scratch of SP_LT_STRIDE doubles.
-int sp_launch_gemm_nt_super(const double *X, long ldx, long strideX, double *C, long ldc,
-                            long strideC, int n, int Kd, int batch, double *sys_all,
-                            long stride_sys, int cS2, int wpn, int Kord, double *LT,
-                            int32_t *info, hipStream_t st) {
-  return launch_gemm(X, ldx, strideX, X, ldx, strideX, C, ldc, strideC, n, n, Kd, -1.0, 1, 1,
-                     batch, 2, 0, LT, info, st, sys_all, stride_sys, cS2, wpn, Kord);
-}

@@ -45,7 +45,6 @@ struct sp_handle {
   int superpanel;               // panels per super-panel (SP_SUPER, default 4)
   int groups;                   // concurrent star groups (SP_GROUPS, default 1)
   int fuse_diag;                // fuse the diagonal-block factorisation into the block-column update
-  int chol_variant;             // 1: super-panel factor + one-launch panel solve (default), 0: per-panel chain
   std::vector<hipStream_t> gstream;
   std::vector<hipEvent_t> gdone;
   hipEvent_t gfork;
@@ -120,12 +119,7 @@ int sp_launch_gemm_nt_diag(const double *A, long lda, long strideA, const double
                            int Nrows, int Kd, double alpha, int lower_only, int batch,
                            int nact, double *invL, int32_t *info, hipStream_t st);
 
-int sp_launch_gemm_nt_super(const double *X, long ldx, long strideX, double *C, long ldc,
-                            long strideC, int n, int Kd, int batch, double *sys_all,
-                            long stride_sys, int cS2, int wpn, int Kord, double *LT,
-                            int32_t *info, hipStream_t st);
-
-// per-star scratch of the factorisation (doubles): 4 L_d^T images + a counter line
-#define SP_LT_DOUBLES (4 * 4096 + 8)
+// per-star scratch of the factorisation (doubles): the L_d^T image of the current panel
+#define SP_LT_DOUBLES 4096
 
 #endif

@@ -32,3 +32,6 @@ ql, Ql = upstream._longitude_integrals(15)
 print("lon q sum %.17e Q sum %.17e" % (ql.sum(), Ql.sum()))
 from starry_process_amd.hostconst import wigner_poly
 print("R sums %.17e %.17e" % (sum(r.sum() for r in wigner_poly(15, 0, 1, 0, -1)), sum(np.abs(r).sum() for r in wigner_poly(15, 1, 0, 1, 0))))
+for l in range(16):
+    blk = slice(l * l, (l + 1) ** 2)
+    print("l=%2d  max|dS| in rows of degree l: %.3e   (max|S| there %.3e)" % (l, d[blk, :].max(), np.abs(R[blk, :]).max()))
