@@ -40,7 +40,8 @@ typedef enum {
   SP_ERR_HIP = -2,      /* a HIP runtime call failed (see sp_last_hip_error)  */
   SP_ERR_NO_DEVICE = -3,/* no usable gfx950 device                            */
   SP_ERR_STATE = -4,    /* required constants / moments were not set first    */
-  SP_ERR_ALLOC = -5     /* host or device allocation failed                   */
+  SP_ERR_ALLOC = -5,    /* host or device allocation failed                   */
+  SP_ERR_COMM = -6      /* no RCCL in the process, or the collective failed   */
 } sp_status;
 
 /* per-star status bits written by the likelihood kernels */
@@ -266,7 +267,22 @@ int sp_latitude_integrals(int ydeg, double alpha, double beta, double *q_host,
  * (n (n + 1) / 2 x 64 multiply-adds x 2 per star and launch).                */
 int sp_profile_begin(sp_handle *h, int max_launches);
 int sp_profile_end(sp_handle *h, long *launches, double *total_ms, double *flops);
-/* launch ONE phase (0 diagonal block, 1 panel solve, 2 trailing update) of panel
+
+/* ---- multi-GPU ------------------------------------------------------
+ * The only exchange of the path: every rank contributes the log-likelihoods of
+ * its `count` stars and receives all `count * nranks` of them, in rank order
+ * (ncclAllGather over RCCL / xGMI, fp64, on `stream`).  `nccl_comm` is the
+ * caller's ncclComm_t (one process per GPU); the RCCL that created it is looked
+ * up in the running process (dlsym), so the library itself does not link RCCL
+ * and single-GPU users never load it.  Replaces nothing in the reference, which
+ * has no multi-GPU path (joss/paper.md:160-172 describes the ensemble use case);
+ * the Python host side (ensemble.py) does the same through torch.distributed.    */
+int sp_allgather_lnlike(sp_handle *h, void *nccl_comm, const double *local_dev, int count,
+                        double *all_dev, void *stream);
+
+/* launch ONE phase (0 diagonal block, 1 panel solve, 2 trailing update, 3 timestamps
+ * inside the diagonal-block kernel, 4 rank-256 update of the first super-panel, 5
+ * sustained fp64 MFMA rate) of panel
  * step j on the systems left in `workspace_dev` by sp_lnlike_ensemble; used by
  * tools/microbench.py to time the kernels in isolation.                        */
 int sp_debug_cholesky_phase(sp_handle *h, int S, int K, int M, void *workspace_dev,

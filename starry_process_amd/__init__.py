@@ -11,7 +11,7 @@ def __getattr__(name):
         from .sp import StarryProcess
 
         return StarryProcess
-    if name in ("ops", "flux", "sp", "engine", "ensemble", "upstream", "hostconst"):
+    if name in ("ops", "flux", "sp", "engine", "ensemble", "upstream", "hostconst", "calibrate"):
         import importlib
 
         return importlib.import_module("." + name, __name__)

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <dlfcn.h>
 #include <cstring>
 #include <new>
 
@@ -898,6 +899,23 @@ int sp_lnlike_ensemble(sp_handle *h, int S, int K, int M, const double *t_dev,
     }
   }
   return SP_OK;
+}
+
+// The one collective of the path.  RCCL is resolved in the running
+// process: the communicator belongs to the caller, so must the library.
+int sp_allgather_lnlike(sp_handle *h, void *nccl_comm, const double *local_dev, int count,
+                        double *all_dev, void *stream) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || !nccl_comm || !local_dev || !all_dev || count < 0) return SP_ERR_INVALID;
+  if (count == 0) return SP_OK;
+  typedef int (*allgather_fn)(const void *, void *, size_t, int, void *, hipStream_t);
+  static allgather_fn fn = nullptr;
+  if (!fn) fn = reinterpret_cast<allgather_fn>(dlsym(RTLD_DEFAULT, "ncclAllGather"));
+  if (!fn) return SP_ERR_COMM;
+  const int nccl_float64 = 8;  // ncclFloat64 / ncclDouble
+  return fn(local_dev, all_dev, (size_t)count, nccl_float64, nccl_comm, (hipStream_t)stream) == 0
+             ? SP_OK
+             : SP_ERR_COMM;
 }
 
 // micro-benchmark hook (not part of the reference-facing API): one phase of one

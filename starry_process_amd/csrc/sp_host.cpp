@@ -345,6 +345,7 @@ const char *sp_strerror(int status) {
     case SP_ERR_NO_DEVICE: return "no usable gfx950 device";
     case SP_ERR_STATE: return "constants or Ylm moments not set";
     case SP_ERR_ALLOC: return "allocation failed";
+    case SP_ERR_COMM: return "RCCL not loaded in this process, or the collective failed";
     default: return "unknown status";
   }
 }

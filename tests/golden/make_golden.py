@@ -22,6 +22,11 @@ Files (L = ydeg):
   cov_L{L}.npz      small-K covariances (marginal / conditional / temporal /
                     normalised), design matrix, int64 spline indices
   norm.npz          AlphaBetaOp values
+  calibrate.npz     calibrate.get_log_prob values.  The reference
+                    function builds a compiled Theano function of symbolic scalars,
+                    which the eager stand-in cannot represent; the generator evaluates
+                    the same expression sequence (calibrate/log_prob.py:37-91) eagerly on
+                    the reference's own StarryProcess / cho_factor / cho_solve.
   upstream.npz      upstream-of-path pieces: size / latitude / longitude first
                     moments, log_jac, gauss2beta / beta2gauss, mu / sigma
   lnlike.npz        log-likelihoods for the BASELINE.json configs
@@ -258,6 +263,47 @@ def gen_upstream():
     save("upstream.npz", **out)
 
 
+def gen_calibrate():
+    """calibrate/log_prob.py:37-91 evaluated eagerly on the reference classes."""
+    cho_factor, cho_solve = ref.math.cho_factor, ref.math.cho_solve
+    K, nlc = 100, 3
+    t = np.linspace(0, 3, K)
+    rng = np.random.RandomState(77)
+    flux = 5e-3 * np.sin(2 * np.pi * t / 1.3)[None, :] * rng.rand(nlc, 1) + 1e-3 * rng.randn(nlc, K)
+    out = {"t": t, "flux": flux}
+
+    def log_prob(r, a, b, c, n, m=None, v=None, i=60.0, p=1.0, ferr=1e-3, ydeg=15,
+                 baseline_mean=0.0, baseline_log_var=0.0, apply_jac=True, normalized=True,
+                 marginalize_over_inclination=True, u=[0.0, 0.0]):
+        sp = SP(ydeg=ydeg, r=r, a=a, b=b, c=c, n=n, normalized=normalized,
+                marginalize_over_inclination=marginalize_over_inclination, covpts=K - 1)
+        gp_mean = A(sp.mean(t, p=p, i=i, u=u))
+        gp_cov = A(sp.cov(t, p=p, i=i, u=u))
+        R = flux.T - gp_mean.reshape(-1, 1)
+        R = R - (m if baseline_mean is None else baseline_mean)
+        gp_cov = gp_cov + ferr ** 2 * np.eye(K)
+        gp_cov = gp_cov + 10 ** (v if baseline_log_var is None else baseline_log_var)
+        L = A(cho_factor(gp_cov))
+        CInvR = A(cho_solve(L, R))
+        ll = -0.5 * np.sum(R * CInvR) - nlc * np.sum(np.log(np.diag(L))) - 0.5 * nlc * K * np.log(2 * np.pi)
+        if np.isnan(ll):
+            ll = -np.inf
+        return float(ll + (float(A(sp.log_jac())) if apply_jac else 0.0))
+
+    cases = [
+        ("default", dict(), (20.0, 0.40, 0.27, 0.1, 10.0)),
+        ("nojac_p", dict(apply_jac=False, p=1.3, ferr=2e-3), (15.0, 0.62, 0.11, 0.2, 5.0)),
+        ("free_baseline", dict(baseline_mean=None, baseline_log_var=None, m=1e-3, v=-5.0), (20.0, 0.40, 0.27, 0.1, 10.0)),
+        ("cond_i", dict(marginalize_over_inclination=False, i=70.0, u=[0.3, 0.1]), (25.0, 0.3, 0.5, 0.05, 20.0)),
+        ("unnormalized", dict(normalized=False, baseline_log_var=-6.0), (20.0, 0.40, 0.27, 0.1, 10.0)),
+    ]
+    for name, kw, hyper in cases:
+        out[name + "_hyper"] = np.array(hyper)
+        out[name] = np.array(log_prob(*hyper, **kw))
+        print("  calibrate %-14s %.10f" % (name, out[name]))
+    save("calibrate.npz", **out)
+
+
 def gen_lnlike():
     out = {}
     t0 = time.time()
@@ -312,7 +358,7 @@ def gen_lnlike():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "consts", "moments", "cov", "norm", "lnlike", "upstream"]
+    which = sys.argv[1:] or ["ops", "consts", "moments", "cov", "norm", "lnlike", "upstream", "calibrate"]
     for L in (5, 15, 20):
         if "ops" in which:
             gen_ops(L)
@@ -329,3 +375,5 @@ if __name__ == "__main__":
         gen_lnlike()
     if "upstream" in which:
         gen_upstream()
+    if "calibrate" in which:
+        gen_calibrate()

@@ -191,3 +191,48 @@ def test_from_hyperparameters_end_to_end():
     assert np.isfinite(float(sp2.log_likelihood(st["t"][:100], st["flux"][:100], 1e-6)))
     with pytest.raises(ValueError):
         StarryProcess(ydeg=5, mu=30.0)
+
+
+def test_calibrate_get_log_prob():
+    """calibrate.get_log_prob.  Two references: (i) values produced by
+    the reference's own classes evaluated along calibrate/log_prob.py:37-91 on the fixture
+    host (make_golden.py: gen_calibrate) -- Sigma_y carries the cross-platform noise of
+    DESIGN.md 8, hence 1e-4; (ii) the oracle fed with the moments computed on THIS host,
+    which isolates the device path and the callable's plumbing: 1e-8."""
+    from starry_process_amd import upstream
+    from starry_process_amd.calibrate import get_log_prob, get_log_prob_ensemble
+
+    g = golden("calibrate")
+    t, flux = g["t"], g["flux"]
+    K = len(t)
+
+    def expected(hyper, m=0.0, v=0.0, i=60.0, p=1.0, ferr=1e-3, u=(0.0, 0.0), jac=True, **kw):
+        r, a, b, c, n = hyper
+        mu, Sig = upstream.ylm_moments(r=r, a=a, b=b, c=c, n=n, ydeg=15)
+        o = orc.OracleProcess(mu, Sig, ydeg=15, covpts=K - 1, normalization_zmax=np.inf, **kw)
+        ll = o.log_likelihood(t, flux, ferr ** 2, i=i, p=p, u=u, baseline_mean=m, baseline_var=10.0 ** v)
+        return ll + (upstream.log_jac(a, b) if jac else 0.0)
+
+    cases = [
+        ("default", dict(), (), dict()),
+        ("nojac_p", dict(apply_jac=False, p=1.3, ferr=2e-3), (), dict(jac=False, p=1.3, ferr=2e-3)),
+        ("free_baseline", dict(baseline_mean=None, baseline_log_var=None), (1e-3, -5.0), dict(m=1e-3, v=-5.0)),
+        ("cond_i", dict(marginalize_over_inclination=False, u=[0.3, 0.1]), (70.0,),
+         dict(i=70.0, u=(0.3, 0.1), marginalize_over_inclination=False)),
+        ("unnormalized", dict(normalized=False, baseline_log_var=-6.0), (), dict(v=-6.0, normalized=False)),
+    ]
+    for name, kw, extra, okw in cases:
+        hyper = g[name + "_hyper"]
+        val = get_log_prob(t, flux, **kw)(*hyper, *extra)
+        assert abs(val / float(g[name]) - 1) < 1e-4, name
+        assert abs(val / expected(hyper, **okw) - 1) < 1e-8, name
+    # free flux: first positional argument, like the reference
+    f0 = get_log_prob(t, flux)
+    assert get_log_prob(t)(flux, *g["default_hyper"]) == f0(*g["default_hyper"])
+    with pytest.raises(TypeError):
+        f0(*g["default_hyper"], 1.0)
+    # per-star ensemble with identical settings = the shared-covariance value
+    # (the ensemble path applies the z > zmax guard of sp.py:1178-1183; not triggered here)
+    fe = get_log_prob_ensemble(t, flux, ferr=1e-3, p=1.0, covpts=K - 1, apply_jac=False)
+    fs = get_log_prob(t, flux, apply_jac=False)
+    assert abs(fe(*g["default_hyper"]) / fs(*g["default_hyper"]) - 1) < 1e-9

@@ -258,3 +258,39 @@ def test_gemm_layout_asymmetric(engines):
     ref = A @ S @ A.T
     assert relerr(host(cov)[0], ref) < 1e-13
     assert abs(host(mean)[0] - (A @ mu)[0]) < 1e-13 * abs((A @ mu)[0])
+
+
+def test_allgather_lnlike_single_rank_communicator():
+    """sp_allgather_lnlike through a real RCCL communicator of one rank:
+    the library resolves ncclAllGather in the running process (torch's RCCL)."""
+    import ctypes
+    import os
+    import torch
+    from starry_process_amd import _lib
+    from starry_process_amd.engine import get_engine
+
+    e = get_engine(5, 2, 0)
+    rccl = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), mode=ctypes.RTLD_GLOBAL)
+    uid = (ctypes.c_char * 128)()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+
+    class UID(ctypes.Structure):
+        _fields_ = [("b", ctypes.c_char * 128)]
+
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UID, ctypes.c_int]
+    u = UID()
+    ctypes.memmove(ctypes.byref(u), uid, 128)
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, u, 0) == 0
+    try:
+        x = torch.arange(7, dtype=torch.float64, device="cuda") * 1.5 - 2.0
+        y = torch.full((7,), float("nan"), dtype=torch.float64, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().sp_allgather_lnlike(e._h, comm, x.data_ptr(), 7, y.data_ptr(), st))
+        torch.cuda.synchronize()
+        assert torch.equal(x, y)
+        assert _lib.lib().sp_allgather_lnlike(e._h, None, x.data_ptr(), 7, y.data_ptr(), st) == -1
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)
