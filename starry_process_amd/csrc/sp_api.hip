@@ -15,7 +15,8 @@ int sp_launch_kernel_table(sp_handle *h, const double *rta1_dev, int ntab,
                            int covpts, const double *xp_dev, double *tab_dev,
                            double *meanvar_dev, hipStream_t st);
 int sp_launch_theta(int S, int K, const double *t, const sp_star *stars,
-                    double *theta, hipStream_t st);
+                    double *theta, hipStream_t st, int32_t *info = nullptr,
+                    uint32_t *status = nullptr);
 int sp_launch_spline_index(int K, const double *theta, double dx, long long *out,
                            hipStream_t st);
 int sp_launch_rowsum(int S, int K, const double *theta, const double *t,
@@ -41,7 +42,7 @@ int sp_debug_phase(sp_handle *h, double *sys, int S, int K, int Kp, int32_t *inf
                    double *invL, int phase, int j, hipStream_t st);
 int sp_launch_lnlike_reduce(const double *sys, int S, int K, int M, int Kp,
                             const int32_t *info, double *lnlike, uint32_t *status,
-                            hipStream_t st);
+                            hipStream_t st, uint32_t *status_out = nullptr);
 int sp_launch_pad_in(const double *A, int K, long lda, long strideA, double *sys,
                      int Kp, int M, const double *resid, int S, hipStream_t st);
 int sp_launch_pad_out(const double *sys, int Kp, double *A, int K, long lda,
@@ -59,15 +60,6 @@ const char *sp_set_hip_error(hipError_t e, const char *what) {
 namespace {
 
 // ---- small kernels used only by the driver -----------------------------------
-
-__global__ void second_moment_kernel(int N, const double *__restrict__ mu,
-                                     const double *__restrict__ cov,
-                                     double *__restrict__ out) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= N * N) return;
-  const int i = e / N, j = e % N;
-  out[e] = cov[e] + mu[i] * mu[j];  // flux.py:58-60
-}
 
 // per star: cos / sin of -inc  (the angle of the first rotation, flux.py:97)
 __global__ void inc_cs_kernel(int S, const sp_star *__restrict__ stars,
@@ -324,9 +316,7 @@ int lnlike_assemble(sp_handle *h, const Layout &L, void *ws, int K, int M, const
   int32_t *info = at<int32_t>(ws, L.info);
   uint32_t *status = at<uint32_t>(ws, L.status);
   int rc;
-  SP_HIP(hipMemsetAsync(info, 0, sizeof(int32_t) * S, st));
-  SP_HIP(hipMemsetAsync(status, 0, sizeof(uint32_t) * S, st));
-  if ((rc = sp_launch_theta(S, K, t_dev, stars_dev, theta, st))) return rc;
+  if ((rc = sp_launch_theta(S, K, t_dev, stars_dev, theta, st, info, status))) return rc;
   const double *rawp = nullptr;
   const double *condmean = nullptr;
   if (conditional) {
@@ -356,11 +346,9 @@ int lnlike_finish(const Layout &L, void *ws, int K, int M, double *lnlike_dev,
   int rc;
   uint32_t *status = at<uint32_t>(ws, L.status);
   if ((rc = sp_launch_lnlike_reduce(at<double>(ws, L.sys), S, K, M, L.Kp,
-                                    at<int32_t>(ws, L.info), lnlike_dev, status, st)))
+                                    at<int32_t>(ws, L.info), lnlike_dev, status, st,
+                                    status_dev)))
     return rc;
-  if (status_dev)
-    SP_HIP(hipMemcpyAsync(status_dev, status, sizeof(uint32_t) * S, hipMemcpyDeviceToDevice,
-                          st));
   return SP_OK;
 }
 
@@ -558,20 +546,9 @@ int sp_set_ylm_moments(sp_handle *h, const double *mean_ylm, const double *cov_y
   SP_HIP(hipMemcpy(h->d_mean_ylm, mean_ylm, sizeof(double) * N, hipMemcpyHostToDevice));
   SP_HIP(hipMemcpy(h->d_cov_ylm, cov_ylm, sizeof(double) * N * N, hipMemcpyHostToDevice));
   hipStream_t st = nullptr;
-  // ez = R^T mu  (flux.py:55-57)
-  int rc = sp_launch_dotRx(h, h->d_mean_ylm, 0, N, 1, 1, h->d_Rx90, 0, h->d_ez, 1, st);
+  // ez = R^T mu, Ez = R^T (Sigma + mu mu^T) R  (flux.py:55-62)
+  int rc = sp_launch_polar_moments(h, h->d_mean_ylm, h->d_cov_ylm, st);
   if (rc) return rc;
-  // Ez = R^T (Sigma + mu mu^T) R  (flux.py:58-62)
-  hipLaunchKernelGGL(second_moment_kernel, dim3((N * N + 255) / 256), dim3(256), 0,
-                     st, N, h->d_mean_ylm, h->d_cov_ylm, h->d_tmpNN);
-  SP_LAUNCH_CHECK();
-  rc = sp_launch_dotRx(h, h->d_tmpNN, 0, N, 1, N, h->d_Rx90, 0, h->d_Ez, 1, st);
-  if (rc) return rc;
-  // transpose view of the intermediate: element (r, c) = Ez_tmp[c, r]
-  rc = sp_launch_dotRx(h, h->d_Ez, 0, 1, N, N, h->d_Rx90, 0, h->d_tmpNN, 1, st);
-  if (rc) return rc;
-  SP_HIP(hipMemcpyAsync(h->d_Ez, h->d_tmpNN, sizeof(double) * N * N,
-                        hipMemcpyDeviceToDevice, st));
   SP_HIP(hipStreamSynchronize(st));
   h->have_moments = true;
   return SP_OK;
@@ -581,23 +558,10 @@ int sp_set_ylm_moments_dev(sp_handle *h, const double *mean_ylm_dev,
                            const double *cov_ylm_dev, void *stream) {
   if (h && h->device < 0) return SP_ERR_NO_DEVICE;
   if (!h || !mean_ylm_dev || !cov_ylm_dev) return SP_ERR_INVALID;
-  const int N = h->N;
   hipStream_t st = (hipStream_t)stream;
-  SP_HIP(hipMemcpyAsync(h->d_mean_ylm, mean_ylm_dev, sizeof(double) * N,
-                        hipMemcpyDeviceToDevice, st));
-  SP_HIP(hipMemcpyAsync(h->d_cov_ylm, cov_ylm_dev, sizeof(double) * N * N,
-                        hipMemcpyDeviceToDevice, st));
-  int rc = sp_launch_dotRx(h, h->d_mean_ylm, 0, N, 1, 1, h->d_Rx90, 0, h->d_ez, 1, st);
+  // one launch: resident copies of mu / Sigma, ez and Ez
+  int rc = sp_launch_polar_moments(h, mean_ylm_dev, cov_ylm_dev, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(second_moment_kernel, dim3((N * N + 255) / 256), dim3(256), 0,
-                     st, N, h->d_mean_ylm, h->d_cov_ylm, h->d_tmpNN);
-  SP_LAUNCH_CHECK();
-  rc = sp_launch_dotRx(h, h->d_tmpNN, 0, N, 1, N, h->d_Rx90, 0, h->d_Ez, 1, st);
-  if (rc) return rc;
-  rc = sp_launch_dotRx(h, h->d_Ez, 0, 1, N, N, h->d_Rx90, 0, h->d_tmpNN, 1, st);
-  if (rc) return rc;
-  SP_HIP(hipMemcpyAsync(h->d_Ez, h->d_tmpNN, sizeof(double) * N * N,
-                        hipMemcpyDeviceToDevice, st));
   h->have_moments = true;
   return SP_OK;
 }

@@ -72,9 +72,13 @@ struct SplineGen {
 
 __global__ __launch_bounds__(256) void theta_kernel(
     int K, const double *__restrict__ t, const sp_star *__restrict__ stars,
-    double *__restrict__ theta) {
+    double *__restrict__ theta, int32_t *__restrict__ info, uint32_t *__restrict__ status) {
   const int s = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {  // first kernel of a likelihood call: also clears the per-star flags
+    if (info) info[s] = 0;
+    if (status) status[s] = 0u;
+  }
   if (i >= K) return;
   const double a = t[(size_t)s * K + i] / stars[s].period;
   double m = fmod(a, 1.0);
@@ -316,9 +320,9 @@ static void allow_big_lds(F f) {
 }
 
 int sp_launch_theta(int S, int K, const double *t, const sp_star *stars,
-                    double *theta, hipStream_t st) {
+                    double *theta, hipStream_t st, int32_t *info, uint32_t *status) {
   hipLaunchKernelGGL(theta_kernel, dim3((K + 255) / 256, S), dim3(256), 0, st, K,
-                     t, stars, theta);
+                     t, stars, theta, info, status);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }

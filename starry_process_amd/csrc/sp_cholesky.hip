@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void trsm_quad_kernel(double *sys, long ld, lo
 __global__ __launch_bounds__(256) void lnlike_reduce_kernel(
     const double *__restrict__ sys, long ld, long stride, int K, int M,
     const int32_t *__restrict__ info, double *__restrict__ lnlike,
-    uint32_t *__restrict__ status) {
+    uint32_t *__restrict__ status, uint32_t *__restrict__ status_out) {
   __shared__ double red[8];
   const int s = blockIdx.x;
   const double *Mx = sys + (size_t)s * stride;
@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256) void lnlike_reduce_kernel(
     if (st & (SP_STAR_NOT_PD | SP_STAR_ZMAX | SP_STAR_NAN)) v = -INFINITY;
     lnlike[s] = v;
     if (status) status[s] = st;
+    if (status_out) status_out[s] = st;
   }
 }
 
@@ -539,9 +540,9 @@ int sp_debug_phase(sp_handle *h, double *sys, int S, int K, int Kp, int32_t *inf
 
 int sp_launch_lnlike_reduce(const double *sys, int S, int K, int M, int Kp,
                             const int32_t *info, double *lnlike, uint32_t *status,
-                            hipStream_t st) {
+                            hipStream_t st, uint32_t *status_out) {
   hipLaunchKernelGGL(lnlike_reduce_kernel, dim3(S), dim3(256), 0, st, sys,
-                     (long)Kp, (long)Kp * Kp, K, M, info, lnlike, status);
+                     (long)Kp, (long)Kp * Kp, K, M, info, lnlike, status, status_out);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }

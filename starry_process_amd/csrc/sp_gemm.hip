@@ -124,6 +124,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
     tj = tile % ntn;
   }
   const int row0 = ti * GT, col0 = tj * GT;
+  // the workgroup that will factor the diagonal block is the critical path of the
+  // launch: let its wavefronts win the issue arbitration on their SIMDs
+  if (FUSE == 1 && ti == 0 && tj == 0) __builtin_amdgcn_s_setprio(3);
   const double *Ab = A + (size_t)mtx * strideA;
   const double *Bb = B + (size_t)mtx * strideB;
   double *Cb = C + (size_t)mtx * strideC;

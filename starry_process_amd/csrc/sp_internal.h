@@ -105,6 +105,10 @@ int sp_launch_dotRx(sp_handle *h, const double *M, long strideM, long rs,
                     long cs, int rows, const double *R, long strideR,
                     double *out, int batch, hipStream_t st);
 
+// ez, Ez (and the resident copies of mu, Sigma) from device pointers, one launch
+int sp_launch_polar_moments(sp_handle *h, const double *mu_src, const double *cov_src,
+                            hipStream_t st);
+
 // C[b] (+)= alpha * A[b] . B[b]^T  on 64x64 tiles with fp64 MFMA.
 //   A: Mrows x Kd (lda), B: Nrows x Kd (ldb), C: Mrows x Nrows (ldc)
 //   beta is 0 or 1;  lower_only: only tiles with tile_i >= tile_j are touched
