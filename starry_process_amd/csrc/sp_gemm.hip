@@ -58,6 +58,18 @@ __device__ __forceinline__ void stage_load(const double *P, long ld, int row0, i
   }
 }
 
+// the same without bounds checks: full 64-row tiles, BK | Kd, 16-byte aligned rows
+template <int BK>
+__device__ __forceinline__ void stage_load_fast(const double *P, long ld, int row0, int k0,
+                                                PanelRegs<BK> &R) {
+  constexpr int LPR = BK / 2, RPP = 256 / LPR;
+  const int t = threadIdx.x;
+  const double *src = P + (size_t)(row0 + t / LPR) * ld + k0 + (t % LPR) * 2;
+#pragma unroll
+  for (int pass = 0; pass < GT / RPP; ++pass)
+    R.v[pass] = *reinterpret_cast<const d2 *>(src + (size_t)(RPP * pass) * ld);
+}
+
 template <int BK>
 __device__ __forceinline__ void stage_store(const PanelRegs<BK> &R, double scale,
                                             double *__restrict__ s) {
@@ -88,7 +100,7 @@ __device__ __forceinline__ void stage_store(const PanelRegs<BK> &R, double scale
 // trailing update -- 1: operand slices fetched from global memory once, 2: also no
 // LDS staging stores / barriers in the loop, 3: also no LDS fragment reads (MFMA
 // issue only), 4: everything but the C tile load / store.  Results are garbage.
-template <int BK, bool DEFER_C, int FUSE, int ABL = 0>
+template <int BK, bool DEFER_C, int FUSE, int ABL = 0, bool FAST = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(
     const double *A, long lda, long strideA,
     const double *__restrict__ B, long ldb, long strideB, double *C,
@@ -140,7 +152,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
     acc[n] = d4{0.0, 0.0, 0.0, 0.0};
     cin[n] = d4{0.0, 0.0, 0.0, 0.0};
   }
-  const bool full = row0 + GT <= Mrows && col0 + GT <= Nrows;
+  const bool full = FAST || (row0 + GT <= Mrows && col0 + GT <= Nrows);
   if (beta && ABL != 4) {
 #pragma unroll
     for (int n = 0; n < 4; ++n)
@@ -159,8 +171,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
   const bool vecB = ((ldb & 1) == 0) && ((reinterpret_cast<uintptr_t>(Bb) & 15) == 0);
 
   PanelRegs<BK> ra, rb;
-  stage_load<BK>(Ab, lda, row0, Mrows, 0, Kd, vecA, ra);
-  stage_load<BK>(Bb, ldb, col0, Nrows, 0, Kd, vecB, rb);
+  if (FAST) {
+    stage_load_fast<BK>(Ab, lda, row0, 0, ra);
+    stage_load_fast<BK>(Bb, ldb, col0, 0, rb);
+  } else {
+    stage_load<BK>(Ab, lda, row0, Mrows, 0, Kd, vecA, ra);
+    stage_load<BK>(Bb, ldb, col0, Nrows, 0, Kd, vecB, rb);
+  }
   if (ABL == 2 || ABL == 3) {
     stage_store<BK>(ra, alpha, sA);
     stage_store<BK>(rb, 1.0, sB);
@@ -174,8 +191,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
       __syncthreads();
     }
     if (k0 + BK < Kd && (ABL == 0 || ABL == 4)) {  // next slice: loads fly while this slice is multiplied
-      stage_load<BK>(Ab, lda, row0, Mrows, k0 + BK, Kd, vecA, ra);
-      stage_load<BK>(Bb, ldb, col0, Nrows, k0 + BK, Kd, vecB, rb);
+      if (FAST) {
+        stage_load_fast<BK>(Ab, lda, row0, k0 + BK, ra);
+        stage_load_fast<BK>(Bb, ldb, col0, k0 + BK, rb);
+      } else {
+        stage_load<BK>(Ab, lda, row0, Mrows, k0 + BK, Kd, vecA, ra);
+        stage_load<BK>(Bb, ldb, col0, Nrows, k0 + BK, Kd, vecB, rb);
+      }
     }
     const double *pa = sA + (16 * wave + fr) * LDW + fk;
     const double *pb = sB + fr * LDW + fk;
@@ -252,6 +274,13 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
     const char *e = getenv("SP_GEMM_VARIANT");
     variant = e ? atoi(e) : 0;
   }
+  const bool fast = (Mrows % GT) == 0 && (Nrows % GT) == 0 && (Kd % 32) == 0 && Kd > 0 &&
+                    ((lda | ldb) & 1) == 0 && (strideA & 1) == 0 && (strideB & 1) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
+#define SP_GO_FAST(FD)                                                                       \
+  hipLaunchKernelGGL((gemm_nt_kernel<32, false, FD, 0, true>), dim3((unsigned)nblk), dim3(256), 0, \
+                     st, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd,  \
+                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info)
 #define SP_GO(BK, DC, FD)                                                              \
   hipLaunchKernelGGL((gemm_nt_kernel<BK, DC, FD>), dim3((unsigned)nblk), dim3(256), 0, st, \
                      A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd, \
@@ -272,8 +301,12 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
       case 3: SP_GO_ABL(3); break;
       default: SP_GO_ABL(4); break;
     }
+  } else if (fuse && fast) {
+    SP_GO_FAST(1);
   } else if (fuse) {
     SP_GO(32, false, 1);
+  } else if (fast && variant == 0) {
+    SP_GO_FAST(0);
   } else {
     switch (variant) {
       case 1: SP_GO(32, true, 0); break;
