@@ -307,6 +307,10 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
     SP_GO(32, false, 1);
   } else if (fast && variant == 0) {
     SP_GO_FAST(0);
+  } else if (fast && variant == 2 && (Kd % 64) == 0) {
+    hipLaunchKernelGGL((gemm_nt_kernel<64, false, 0, 0, true>), dim3((unsigned)nblk), dim3(256), 0,
+                       st, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd,
+                       alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info);
   } else {
     switch (variant) {
       case 1: SP_GO(32, true, 0); break;

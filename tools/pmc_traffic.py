@@ -38,12 +38,12 @@ grids = [78 * 64 * 256, 36 * 64 * 256, 10 * 64 * 256]
 
 
 def bulk_only(d):
-    """The third bulk grid (10 tiles x 64) is shared with the panel solve and the
-    block-column update at n = 640; the bulk launch is the one that directly
-    follows the panel solve of panel 11 (4 row tiles x 64 stars = 65,536 threads)."""
+    """The third bulk grid (10 tiles x 64) is shared with the block-column update of
+    panel 6 (10 row tiles); among the gemm_nt_kernel dispatches the bulk launch is the
+    one that follows the block-column update of panel 11 (5 row tiles x 64 stars x 256)."""
     out, prev = [], None
     for g, v in d.values():
-        if g in grids[:2] or (g == grids[2] and prev == 4 * 64 * 256):
+        if g in grids[:2] or (g == grids[2] and prev == 5 * 64 * 256):
             out.append(v)
         prev = g
     return out
