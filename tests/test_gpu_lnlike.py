@@ -168,3 +168,53 @@ def test_matches_oracle_on_random_hyper(eng):
         assert np.max(np.abs(v / np.array(ref) - 1)) < TOL
     finally:
         e.set_moments(mom["default_mean_ylm"], mom["default_cov_ylm"])
+
+
+@pytest.mark.parametrize("L,K,S,tspan,tau", [(15, 1000, 8, 4.0, None), (20, 3000, 3, 30.0, 3.0)])
+def test_full_size_properties(eng, L, K, S, tspan, tau):
+    """Size-independent checks at the BASELINE sizes (cfg3 / cfg5), where the CPU oracle
+    is too slow to be the checker for every star:
+      * L L^T reproduces the assembled covariance (factor <-> matrix round trip);
+      * the fused value equals  -1/2 r^T C^-1 r - log det L - K/2 log 2 pi  rebuilt from the
+        separately assembled covariance with the vendor's Cholesky (independent code path);
+      * a star's value does not depend on its position in the batch or on the batch (bit-exact)."""
+    import torch
+    from starry_process_amd.engine import make_stars
+
+    e = eng(L)
+    temporal = "matern32" if tau else None
+    idx = np.arange(S)
+    sts = [synthetic_star(int(s), K, tspan) for s in idx]
+    t = np.array([st["t"] for st in sts])
+    flux = np.array([st["flux"] for st in sts])
+    u = (0.4, 0.2) if L == 20 else (0.0, 0.0)
+    rta1 = e.f64(e.rTA1L(u))
+    tab, mv = e.kernel_table(rta1, 300)
+
+    def lnl(order):
+        stars = make_stars(len(order), period=[sts[s]["p"] for s in order], tau=tau or 0.0,
+                           data_var=[sts[s]["data_cov"] for s in order])
+        out, status = e.lnlike_ensemble(e.f64(t[order]), e.f64(flux[order][:, None, :]),
+                                        e.stars_to_device(stars), covpts=300, tab=tab, meanvar=mv,
+                                        rta1=rta1, temporal=temporal, normalized=True)
+        assert not status.cpu().numpy().any()
+        return out.cpu().numpy()
+
+    base = lnl(idx)
+    perm = idx[::-1].copy()
+    assert np.array_equal(lnl(perm)[::-1], base)            # position in the batch
+    assert np.array_equal(lnl(idx[:1]), base[:1])           # batch of one
+    # independent reconstruction on the device
+    stars = make_stars(S, period=[st["p"] for st in sts], tau=tau or 0.0)
+    cov, z = e.cov_marginal(t, stars, 300, tab, mv, temporal=temporal, normalized=True)
+    C = cov + 1e-6 * torch.eye(K, dtype=torch.float64, device=cov.device)
+    Lg, info = e.cho_factor(C)
+    assert not info.cpu().numpy().any()
+    rec = Lg @ Lg.transpose(1, 2)
+    assert float((rec - C).abs().max() / C.abs().max()) < 1e-13
+    Lv = torch.linalg.cholesky(C)
+    r = e.f64(flux).unsqueeze(2)                             # normalised process: zero mean
+    y = torch.linalg.solve_triangular(Lv, r, upper=False)
+    ref = (-0.5 * (y * y).sum(dim=(1, 2)) - torch.log(torch.diagonal(Lv, dim1=1, dim2=2)).sum(1)
+           - 0.5 * K * np.log(2 * np.pi)).cpu().numpy()
+    assert np.abs(base / ref - 1).max() < 1e-9
