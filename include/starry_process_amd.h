@@ -251,6 +251,21 @@ int sp_cholesky_lnlike_batched(sp_handle *h, int S, int K, int M,
                                void *workspace_dev, double *lnlike_dev,
                                uint32_t *status_dev, void *stream);
 
+/* ---- Gaussian conditioning (sp.py:767-903 `predict`, 905-1002
+ * `sample_conditional`) -----------------------------------------------------------
+ * Ktt_dev [K, K]: covariance at the observed times INCLUDING data covariance and
+ * baseline variance (full symmetric, not modified); Kst_dev [Ks, K]: cross covariance
+ * (sample times x observed times); Kss_dev [Ks, Ks]: prior covariance at the sample
+ * times, overwritten with the posterior  K_ss - K_st K_tt^-1 K_st^T;  r_dev [K]:
+ * observed flux minus mean;  mu_dev [Ks] receives  K_st K_tt^-1 r  (add the process
+ * mean on the host).  One factorisation of K_tt with K_st and r riding along as extra
+ * rows (Y = K_st L^-T, w = L^-1 r), then mu = Y w and K_ss -= Y Y^T on
+ * the matrix cores.  info_dev[0] != 0: K_tt was not positive definite (outputs are
+ * then meaningless; math.py:82-91 returns NaN in that case).                       */
+int sp_gp_condition(sp_handle *h, int K, int Ks, const double *Ktt_dev, const double *Kst_dev,
+                    double *Kss_dev, const double *r_dev, double *mu_dev, int32_t *info_dev,
+                    void *stream);
+
 /* ---- upstream of the hot path, host only ---------------- */
 /* LatitudeIntegralOp values (ops/latitude/latitude.py, ops/include/latitude.h:
  * 21-173): q [N], Q [N x N] for Beta shape parameters alpha, beta.  The

@@ -865,6 +865,40 @@ int sp_lnlike_ensemble(sp_handle *h, int S, int K, int M, const double *t_dev,
   return SP_OK;
 }
 
+int sp_gp_condition(sp_handle *h, int K, int Ks, const double *Ktt_dev, const double *Kst_dev,
+                    double *Kss_dev, const double *r_dev, double *mu_dev, int32_t *info_dev,
+                    void *stream) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || K < 1 || Ks < 1 || !Ktt_dev || !Kst_dev || !Kss_dev || !r_dev || !mu_dev)
+    return SP_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const int M = Ks + 1, Kp = sp_roundup(K + M, SP_NB);
+  const size_t sysb = align_up(sizeof(double) * (size_t)Kp * Kp);
+  const size_t resb = align_up(sizeof(double) * (size_t)M * K);
+  const size_t invb = align_up(sizeof(double) * SP_LT_DOUBLES);
+  void *ws = nullptr;
+  int rc = ensure_big(h, sysb + resb + invb + 256, &ws);
+  if (rc) return rc;
+  double *sys = at<double>(ws, 0), *res = at<double>(ws, sysb);
+  double *lt = at<double>(ws, sysb + resb);
+  int32_t *info = at<int32_t>(ws, sysb + resb + invb);
+  SP_HIP(hipMemsetAsync(info, 0, sizeof(int32_t), st));
+  SP_HIP(hipMemcpyAsync(res, Kst_dev, sizeof(double) * (size_t)Ks * K, hipMemcpyDeviceToDevice, st));
+  SP_HIP(hipMemcpyAsync(res + (size_t)Ks * K, r_dev, sizeof(double) * K, hipMemcpyDeviceToDevice,
+                        st));
+  if ((rc = sp_launch_pad_in(Ktt_dev, K, K, (long)K * K, sys, Kp, M, res, 1, st))) return rc;
+  if ((rc = sp_launch_cholesky_systems(h, sys, 1, K, Kp, info, lt, st))) return rc;
+  const double *Y = sys + (size_t)K * Kp;          // [Ks, K], row stride Kp
+  const double *w = sys + (size_t)(K + Ks) * Kp;   // [1, K]
+  if ((rc = sp_launch_gemm_nt(Y, Kp, 0, w, Kp, 0, mu_dev, 1, 0, Ks, 1, K, 1.0, 0, 0, 1, st)))
+    return rc;
+  if ((rc = sp_launch_gemm_nt(Y, Kp, 0, Y, Kp, 0, Kss_dev, Ks, 0, Ks, Ks, K, -1.0, 1, 0, 1, st)))
+    return rc;
+  if (info_dev)
+    SP_HIP(hipMemcpyAsync(info_dev, info, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  return SP_OK;
+}
+
 // The one collective of the path.  RCCL is resolved in the running
 // process: the communicator belongs to the caller, so must the library.
 int sp_allgather_lnlike(sp_handle *h, void *nccl_comm, const double *local_dev, int count,

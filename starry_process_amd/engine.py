@@ -269,6 +269,19 @@ class Engine(object):
         check(self._L.sp_cho_solve(self._h, self._p(Lb), K, K, K * K, self._p(bb), nrhs, B, self._stream()))
         return bb.reshape(shape)
 
+    def gp_condition(self, Ktt, Kst, Kss, r):
+        """mu = K_st K_tt^-1 r and the posterior covariance K_ss - K_st K_tt^-1 K_st^T
+        (device tensors; Kss is not modified).  Returns (mu, Kpost, info)."""
+        torch = _torch()
+        Ktt, Kst, r = self.f64(Ktt).contiguous(), self.f64(Kst).contiguous(), self.f64(r).contiguous()
+        Kpost = self.f64(Kss).clone().contiguous()
+        Ks, K = Kst.shape
+        mu = self.empty(Ks)
+        info = torch.zeros(1, dtype=torch.int32, device=self.device)
+        check(self._L.sp_gp_condition(self._h, K, Ks, self._p(Ktt), self._p(Kst), self._p(Kpost),
+                                      self._p(r), self._p(mu), self._p(info), self._stream()))
+        return mu, Kpost, info
+
     # -- fused likelihood ----------------------------------------------------------
     def workspace(self, S, K, M):
         torch = _torch()

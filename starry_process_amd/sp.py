@@ -221,6 +221,77 @@ class StarryProcess(object):
             val = -np.inf
         return Eager(val)
 
+    # -- conditioning on data (sp.py:767-1002) ---------------------------------------------
+    def predict(
+        self,
+        t,
+        flux,
+        data_cov,
+        t_sample=None,
+        i=defaults["i"],
+        p=defaults["p"],
+        u=defaults["u"][: defaults["udeg"]],
+        baseline_mean=defaults["baseline_mean"],
+        baseline_var=defaults["baseline_var"],
+    ):
+        """Mean and covariance of the light curve distribution conditioned on the observed
+        flux (sp.py:767-903).  As in the reference: not implemented for normalized
+        processes.  The three covariance blocks come from ONE device assembly on the
+        concatenated times [t_sample, t]; the conditioning is one factorisation with the
+        cross covariance riding along as extra rows (``sp_gp_condition``)."""
+        if self._normalized:
+            raise NotImplementedError("Method not implemented when the flux is normalized.")
+        e = self._engine
+        t = np.asarray(t, dtype=np.float64).reshape(-1)
+        K = t.shape[0]
+        if t_sample is None:
+            tall, Ks = t, K
+        else:
+            ts = np.asarray(t_sample, dtype=np.float64).reshape(-1)
+            Ks = ts.shape[0]
+            tall = np.concatenate([ts, t])
+        _, cov, fmean = self._device_cov(tall, i, p, u)
+        mean = float(fmean)
+        if t_sample is None:
+            Ktt, Kst, Kss = cov.clone(), cov.clone(), cov.clone()
+        else:
+            Kss, Kst, Ktt = cov[:Ks, :Ks].clone(), cov[:Ks, Ks:].clone(), cov[Ks:, Ks:].clone()
+        data_cov = np.asarray(data_cov, dtype=np.float64)
+        if data_cov.ndim == 0:
+            Ktt.diagonal().add_(float(data_cov))
+        elif data_cov.ndim == 1:
+            Ktt.diagonal().add_(e.f64(data_cov))
+        else:
+            Ktt += e.f64(data_cov)
+        bvar = np.asarray(baseline_var, dtype=np.float64)
+        bv = e.f64(bvar) if bvar.ndim else float(bvar)
+        Ktt += bv
+        Kss += bv
+        Kst += bv
+        y = e.f64(np.asarray(flux, dtype=np.float64).reshape(-1) - np.asarray(baseline_mean, dtype=np.float64))
+        mu, Kpost, info = e.gp_condition(Ktt, Kst, Kss, y - mean)
+        mu = mu.cpu().numpy() + mean
+        Kpost = Kpost.cpu().numpy()
+        if int(info.item()):
+            mu, Kpost = np.full_like(mu, np.nan), np.full_like(Kpost, np.nan)
+        return Eager(mu), Eager(Kpost)
+
+    def sample_conditional(self, t, flux, data_cov, t_sample=None, i=defaults["i"], p=defaults["p"],
+                           u=defaults["u"][: defaults["udeg"]], baseline_mean=defaults["baseline_mean"],
+                           baseline_var=defaults["baseline_var"], nsamples=1, eps=1e-12, seed=None):
+        """Samples from the conditional distribution (sp.py:905-1002): predict, then
+        mean + L z with L the device Cholesky factor of the posterior covariance.  The
+        random numbers are NumPy's (the reference's Theano stream cannot be reproduced)."""
+        mu, Kpost = self.predict(t, flux, data_cov, t_sample, i, p, u, baseline_mean, baseline_var)
+        Kpost = np.array(Kpost)
+        Kpost[np.diag_indices_from(Kpost)] += eps
+        L, info = self._engine.cho_factor(Kpost)
+        L = L.cpu().numpy()
+        if int(info.reshape(-1)[0].item()):
+            L = np.full_like(L, np.nan)
+        z = np.random.RandomState(seed).randn(Kpost.shape[0], int(nsamples))
+        return Eager(np.array(mu)[None, :] + (L @ z).T)
+
     def log_likelihood_ensemble(self, t, flux, data_cov, i=None, p=None, u=None,
                                 baseline_mean=0.0, baseline_var=0.0):
         """Per-star log-likelihoods of S independent stars in one device call.

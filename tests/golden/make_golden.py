@@ -27,6 +27,7 @@ Files (L = ydeg):
                     which the eager stand-in cannot represent; the generator evaluates
                     the same expression sequence (calibrate/log_prob.py:37-91) eagerly on
                     the reference's own StarryProcess / cho_factor / cho_solve.
+  predict.npz       StarryProcess.predict (sp.py:767-903): conditional mean / covariance
   upstream.npz      upstream-of-path pieces: size / latitude / longitude first
                     moments, log_jac, gauss2beta / beta2gauss, mu / sigma
   lnlike.npz        log-likelihoods for the BASELINE.json configs
@@ -263,6 +264,37 @@ def gen_upstream():
     save("upstream.npz", **out)
 
 
+def gen_predict():
+    """StarryProcess.predict for small cases (unnormalised processes only, sp.py:855-858)."""
+    mom = np.load(os.path.join(OUT, "moments_L15.npz"))
+    out = {}
+    K, Ks = 60, 25
+    t = np.linspace(0, 2.5, K)
+    ts = np.linspace(0.1, 3.0, Ks)
+    rng = np.random.RandomState(5)
+    flux = 4e-3 * np.sin(2 * np.pi * t / 0.9) + 5e-4 * rng.randn(K)
+    out.update(t=t, ts=ts, flux=flux)
+    cases = [
+        ("marg", dict(marginalize_over_inclination=True), dict(p=0.9, u=[0.0, 0.0])),
+        ("marg_same_t", dict(marginalize_over_inclination=True), dict(p=0.9, u=[0.3, 0.1], t_sample=None)),
+        ("cond", dict(marginalize_over_inclination=False), dict(p=1.1, i=55.0, u=[0.4, 0.2])),
+        ("marg_tau", dict(marginalize_over_inclination=True, tau=2.0), dict(p=0.9, u=[0.0, 0.0])),
+    ]
+    for name, ckw, kw in cases:
+        sp = SP(ydeg=15, normalized=False, **ckw)
+        # fixture moments so that the comparison is free of the platform noise of Sigma_y
+        sp._mean_ylm = mom["default_mean_ylm"]
+        sp._cov_ylm = mom["default_cov_ylm"]
+        sp._flux = ref.flux.FluxIntegral(sp._mean_ylm, sp._cov_ylm, marginalize_over_inclination=ckw["marginalize_over_inclination"], covpts=sp._covpts, ydeg=15)
+        kw = dict(kw)
+        tsamp = kw.pop("t_sample", ts)
+        mu, Kp = sp.predict(t, flux, 2.5e-7, t_sample=tsamp, baseline_mean=1e-4, baseline_var=1e-6, **kw)
+        out[name + "_mu"] = A(mu)
+        out[name + "_K"] = A(Kp)
+        print("  predict %-12s mu[0]=%.8e K[0,0]=%.8e" % (name, out[name + "_mu"][0], out[name + "_K"][0, 0]))
+    save("predict.npz", **out)
+
+
 def gen_calibrate():
     """calibrate/log_prob.py:37-91 evaluated eagerly on the reference classes."""
     cho_factor, cho_solve = ref.math.cho_factor, ref.math.cho_solve
@@ -358,7 +390,7 @@ def gen_lnlike():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "consts", "moments", "cov", "norm", "lnlike", "upstream", "calibrate"]
+    which = sys.argv[1:] or ["ops", "consts", "moments", "cov", "norm", "lnlike", "upstream", "calibrate", "predict"]
     for L in (5, 15, 20):
         if "ops" in which:
             gen_ops(L)
@@ -377,3 +409,5 @@ if __name__ == "__main__":
         gen_upstream()
     if "calibrate" in which:
         gen_calibrate()
+    if "predict" in which:
+        gen_predict()

@@ -236,3 +236,41 @@ def test_calibrate_get_log_prob():
     fe = get_log_prob_ensemble(t, flux, ferr=1e-3, p=1.0, covpts=K - 1, apply_jac=False)
     fs = get_log_prob(t, flux, apply_jac=False)
     assert abs(fe(*g["default_hyper"]) / fs(*g["default_hyper"]) - 1) < 1e-9
+
+
+def test_predict_and_sample_conditional():
+    """StarryProcess.predict / sample_conditional against the reference's
+    own predict (sp.py:767-903) on the fixture moments (tests/golden/make_golden.py:
+    gen_predict): conditional mean and covariance for the marginal, conditional and
+    time-variable branches, on a separate sample grid and on the observed grid."""
+    from starry_process_amd import StarryProcess
+
+    g = golden("predict")
+    mom = golden("moments_L15")
+    t, ts, flux = g["t"], g["ts"], g["flux"]
+    cases = [
+        ("marg", dict(marginalize_over_inclination=True), dict(p=0.9, u=[0.0, 0.0]), ts),
+        ("marg_same_t", dict(marginalize_over_inclination=True), dict(p=0.9, u=[0.3, 0.1]), None),
+        ("cond", dict(marginalize_over_inclination=False), dict(p=1.1, i=55.0, u=[0.4, 0.2]), ts),
+        ("marg_tau", dict(marginalize_over_inclination=True, tau=2.0), dict(p=0.9, u=[0.0, 0.0]), ts),
+    ]
+    for name, ckw, kw, tsamp in cases:
+        sp = StarryProcess(ydeg=15, normalized=False, mean_ylm=mom["default_mean_ylm"],
+                           cov_ylm=mom["default_cov_ylm"], **ckw)
+        mu, Kp = sp.predict(t, flux, 2.5e-7, t_sample=tsamp, baseline_mean=1e-4, baseline_var=1e-6, **kw)
+        mu, Kp = np.array(mu), np.array(Kp)
+        # the posterior covariance is a difference of nearly equal matrices (prior 1e-6
+        # scale, posterior 1e-8): errors are measured against the prior scale
+        scale = 1e-6 + np.abs(g[name + "_K"]).max()
+        assert np.abs(mu - g[name + "_mu"]).max() < 1e-9 * np.abs(g[name + "_mu"]).max() + 1e-12, name
+        assert np.abs(Kp - g[name + "_K"]).max() < 1e-9 * scale, name
+    # samples: right shape, reproducible, and distributed around the conditional mean
+    sp = StarryProcess(ydeg=15, normalized=False, mean_ylm=mom["default_mean_ylm"], cov_ylm=mom["default_cov_ylm"])
+    s1 = np.array(sp.sample_conditional(t, flux, 2.5e-7, t_sample=ts, p=0.9, nsamples=400, seed=3))
+    s2 = np.array(sp.sample_conditional(t, flux, 2.5e-7, t_sample=ts, p=0.9, nsamples=400, seed=3))
+    assert s1.shape == (400, len(ts)) and np.array_equal(s1, s2)
+    mu, Kp = sp.predict(t, flux, 2.5e-7, t_sample=ts, p=0.9)
+    sig = np.sqrt(np.diag(np.array(Kp)) + 1e-12)
+    assert np.all(np.abs(s1.mean(0) - np.array(mu)) < 5 * sig / np.sqrt(400))
+    with pytest.raises(NotImplementedError):
+        StarryProcess(ydeg=15, mean_ylm=mom["default_mean_ylm"], cov_ylm=mom["default_cov_ylm"]).predict(t, flux, 1e-6)
