@@ -183,7 +183,7 @@ def main():
                 "algorithmic_flops_per_launch": kern_flops / max(launches, 1),
             },
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:   # reported at N = 1 only (rank 0 would hold the others up)
             base, ref_vals = cpu_baseline(mu, Sig, args.cpu_stars)
             line["cpu_baseline"] = base
             n = min(len(ref_vals), S)
