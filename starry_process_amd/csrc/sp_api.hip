@@ -396,7 +396,7 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
   h->scratch_bytes = 0;
   h->d_tab_scratch = nullptr;
   h->tab_scratch_bytes = 0;
-  h->superpanel = 4;
+  h->superpanel = 0;
   h->groups = 1;
   h->fuse_diag = 2;
   h->gfork = nullptr;
@@ -445,8 +445,8 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
     const char *e3 = getenv("SP_GROUPS");
     h->groups = e3 ? atoi(e3) : 1;
     const char *e2 = getenv("SP_SUPER");
-    h->superpanel = e2 ? atoi(e2) : 4;
-    if (h->superpanel < 1) h->superpanel = 1;
+    h->superpanel = e2 ? atoi(e2) : 0;   // 0: chosen from K (sp_launch_cholesky_groups)
+    if (h->superpanel < 0) h->superpanel = 0;
   }
   // Rx(pi/2): the polar-frame rotation every path uses (flux.py:56,61,62,103)
   const double th = 0.5 * M_PI;

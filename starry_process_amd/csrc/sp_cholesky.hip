@@ -390,7 +390,10 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
                               int Kp) {
   const long ld = Kp, stride = (long)Kp * Kp;
   const int nsteps = (K + SP_NB - 1) / SP_NB;
-  const int w = (h && h->superpanel > 0) ? h->superpanel : 1;
+  // panels per super-panel: wider super-panels raise the arithmetic intensity of the
+  // trailing update (k = 64 w) at the price of more left-looking work per block column;
+  // measured: w = 4, 6, 8 equal at K = 1000 (16 panels), w = 8 +3 % at K = 3000 (47 panels)
+  const int w = (h && h->superpanel > 0) ? h->superpanel : (nsteps >= 32 ? 8 : 4);
   // launches are issued breadth-first over the groups so that the groups'
   // streams advance together (the host enqueues ~3-8 us per launch)
   for (int s0 = 0; s0 < nsteps; s0 += w) {

@@ -42,7 +42,7 @@ struct sp_handle {
   size_t scratch_bytes;
   double *d_tab_scratch;        // [ntab][2][N] row reductions of the kernel table
   size_t tab_scratch_bytes;
-  int superpanel;               // panels per super-panel (SP_SUPER, default 4)
+  int superpanel;               // panels per super-panel (SP_SUPER; 0 = chosen from K)
   int groups;                   // concurrent star groups (SP_GROUPS, default 1)
   int fuse_diag;                // fuse the diagonal-block factorisation into the block-column update
   std::vector<hipStream_t> gstream;
