@@ -160,9 +160,12 @@ int sp_kernel_table(sp_handle *h, const double *rta1_dev, int ntab, int covpts,
                     double *meanvar_dev, void *stream);
 
 /* ---- per-star parameter block -------------------------------------------- */
-/* All batched entry points below take `S` stars with a common number of
- * cadences K (ragged ensembles are grouped by K on the host side).  The array
- * of sp_star lives in DEVICE memory like every other batched input.           */
+/* All batched entry points below take `S` stars with a common row length K.  A
+ * RAGGED ensemble (light curves of different lengths) is padded to the longest:
+ * star s uses its first `nobs` cadences (0 = all K), the rest of its row of
+ * t / flux / diag is ignored; its covariance is nobs x nobs, the padding rows of
+ * the factored system are identity rows.  The array of sp_star lives in DEVICE
+ * memory like every other batched input.                                       */
 typedef struct {
   double period;        /* p  > 0                         (sp.py:1108-1109)   */
   double inc;           /* inclination in RADIANS, conditional path only       */
@@ -171,7 +174,7 @@ typedef struct {
   double baseline_mean; /* subtracted from the flux       (sp.py:1157)        */
   double data_var;      /* scalar data variance (used when diag_dev == NULL)   */
   int32_t table;        /* which kernel table / flux operator this star uses   */
-  int32_t reserved;
+  int32_t nobs;         /* valid cadences of this star, 0 = K (ragged ensembles) */
 } sp_star;
 
 /* ---- a11, a14-a16: marginal-path covariance ------------------------------- */

@@ -29,7 +29,7 @@ class sp_star(ctypes.Structure):
         ("baseline_mean", ctypes.c_double),
         ("data_var", ctypes.c_double),
         ("table", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("nobs", ctypes.c_int32),
     ]
 
 
@@ -42,7 +42,7 @@ STAR_DTYPE = np.dtype(
         ("baseline_mean", "<f8"),
         ("data_var", "<f8"),
         ("table", "<i4"),
-        ("reserved", "<i4"),
+        ("nobs", "<i4"),
     ]
 )
 assert STAR_DTYPE.itemsize == ctypes.sizeof(sp_star) == 56

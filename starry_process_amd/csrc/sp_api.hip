@@ -42,7 +42,8 @@ int sp_debug_phase(sp_handle *h, double *sys, int S, int K, int Kp, int32_t *inf
                    double *invL, int phase, int j, hipStream_t st);
 int sp_launch_lnlike_reduce(const double *sys, int S, int K, int M, int Kp,
                             const int32_t *info, double *lnlike, uint32_t *status,
-                            hipStream_t st, uint32_t *status_out = nullptr);
+                            hipStream_t st, uint32_t *status_out = nullptr,
+                            const sp_star *stars = nullptr);
 int sp_launch_pad_in(const double *A, int K, long lda, long strideA, double *sys,
                      int Kp, int M, const double *resid, int S, hipStream_t st);
 int sp_launch_pad_out(const double *sys, int Kp, double *A, int K, long lda,
@@ -341,13 +342,13 @@ int lnlike_assemble(sp_handle *h, const Layout &L, void *ws, int K, int M, const
 
 // stage C: reduction of one group's factored systems
 int lnlike_finish(const Layout &L, void *ws, int K, int M, double *lnlike_dev,
-                  uint32_t *status_dev, hipStream_t st) {
+                  uint32_t *status_dev, hipStream_t st, const sp_star *stars_dev) {
   const int S = L.S;
   int rc;
   uint32_t *status = at<uint32_t>(ws, L.status);
   if ((rc = sp_launch_lnlike_reduce(at<double>(ws, L.sys), S, K, M, L.Kp,
                                     at<int32_t>(ws, L.info), lnlike_dev, status, st,
-                                    status_dev)))
+                                    status_dev, stars_dev)))
     return rc;
   return SP_OK;
 }
@@ -855,7 +856,7 @@ int sp_lnlike_ensemble(sp_handle *h, int S, int K, int M, const double *t_dev,
   for (int g = 0; g < G; ++g) {
     const int s0 = first[g];
     int rc = lnlike_finish(LG[g], ws, K, M, lnlike_dev + s0,
-                           status_dev ? status_dev + s0 : nullptr, CG[g].st);
+                           status_dev ? status_dev + s0 : nullptr, CG[g].st, stars_dev + s0);
     if (rc) return rc;
     if (g > 0) {
       SP_HIP(hipEventRecord(h->gdone[g - 1], CG[g].st));

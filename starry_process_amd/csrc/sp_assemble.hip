@@ -19,6 +19,11 @@
 
 namespace {
 
+// valid cadences of a star: sp_star.nobs when 0 < nobs < K (ragged ensembles), else K
+__device__ __forceinline__ int star_nobs(const sp_star &st, int K) {
+  return (st.nobs > 0 && st.nobs < K) ? st.nobs : K;
+}
+
 struct Coef {   // per-star normalisation coefficients, 8 doubles
   double c1;    // alpha / mu^2          (1 when not normalised)
   double zab;   // alpha + beta
@@ -131,21 +136,22 @@ __global__ __launch_bounds__(256) void rowsum_kernel(
   __syncthreads();
   const int r = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + r;
+  const int nobs = star_nobs(st, K);
   double acc = 0.0;
-  if (i < K) {
+  if (i < nobs) {
     if (FROM_MATRIX) {
       const double *row = raw + ((size_t)s * K + i) * K;
       const double ti = temporal != SP_TEMPORAL_NONE ? s_t[i] : 0.0;
-      for (int j = q; j < K; j += 4)
+      for (int j = q; j < nobs; j += 4)
         acc += row[j] * temporal_factor(temporal, ti, temporal != SP_TEMPORAL_NONE ? s_t[j] : 0.0, st.tau);
-    } else if (K == 1) {
+    } else if (nobs == 1) {
       acc = q == 0 ? meanvar[2 * st.table + 1] : 0.0;
     } else {
       SplineGen g{s_tab, s_tab + 4 * np, 6.283185307179586 / covpts,
                   1.0 / (6.283185307179586 / covpts), covpts};
       const double thi = s_th[i];
       const double ti = temporal != SP_TEMPORAL_NONE ? s_t[i] : 0.0;
-      for (int j = q; j < K; j += 4)
+      for (int j = q; j < nobs; j += 4)
         acc += g(thi, s_th[j]) *
                temporal_factor(temporal, ti, temporal != SP_TEMPORAL_NONE ? s_t[j] : 0.0, st.tau);
     }
@@ -174,14 +180,15 @@ __global__ __launch_bounds__(256) void norm_coef_kernel(
   c.m = 0.0;
   c.mu = 1.0 + fmean;
   c.pad = 0.0;
+  const int nobs = star_nobs(stars[s], K);
   if (normalized) {
     double part = 0.0;
-    for (int i = threadIdx.x; i < K; i += 256) part += rowsum[(size_t)s * K + i];
+    for (int i = threadIdx.x; i < nobs; i += 256) part += rowsum[(size_t)s * K + i];
     for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
     __syncthreads();
     const double total = (red[0] + red[1]) + (red[2] + red[3]);
-    const double m = total / ((double)K * (double)K);
+    const double m = total / ((double)nobs * (double)nobs);
     const double mu = c.mu;
     const double z = m / (mu * mu);
     double fac = 1.0, alpha = 0.0, beta = 0.0;
@@ -195,9 +202,9 @@ __global__ __launch_bounds__(256) void norm_coef_kernel(
     c.za = alpha;
     c.z = z;
     c.m = m;
-    const double km = (double)K * m;
+    const double km = (double)nobs * m;
     for (int i = threadIdx.x; i < K; i += 256)
-      qv[(size_t)s * K + i] = rowsum[(size_t)s * K + i] / km;
+      qv[(size_t)s * K + i] = i < nobs ? rowsum[(size_t)s * K + i] / km : 0.0;
     if (threadIdx.x == 0 && status && z > zmax) atomicOr(&status[s], SP_STAR_ZMAX);
   }
   if (threadIdx.x == 0) coef[s] = c;
@@ -253,7 +260,8 @@ __global__ __launch_bounds__(256) void assemble_kernel(
   __syncthreads();
   SplineGen g{s_tab, s_tab + 4 * np, 6.283185307179586 / covpts,
               1.0 / (6.283185307179586 / covpts), covpts};
-  const double var1 = (!FROM_MATRIX && K == 1) ? meanvar[2 * st.table + 1] : 0.0;
+  const int nobs = star_nobs(st, K);
+  const double var1 = (!FROM_MATRIX && nobs == 1) ? meanvar[2 * st.table + 1] : 0.0;
   double *ob = out + (size_t)s * strideo;
   // thread -> 4 consecutive columns, 16 rows per pass
   const int cj = (threadIdx.x & 15) * 4, ri = threadIdx.x >> 4;
@@ -267,11 +275,11 @@ __global__ __launch_bounds__(256) void assemble_kernel(
     for (int e = 0; e < 4; ++e) {
       const int lj = cj + e, j = j0 + lj;
       double val = 0.0;
-      if (i < K && j < K) {
+      if (i < nobs && j < nobs) {
         double rawv;
         if (FROM_MATRIX)
           rawv = raw[((size_t)s * K + i) * K + j];
-        else if (K == 1)
+        else if (nobs == 1)
           rawv = var1;
         else
           rawv = g(s_thi[li], s_thj[lj]);
@@ -288,7 +296,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(
           val += st.baseline_var;
         }
       } else if (SYSTEM) {
-        if (i >= K && i < K + M && j < K)
+        if (i >= K && i < K + M && j < nobs)
           val = flux[((size_t)s * M + (i - K)) * K + j] - (c.gpmean + st.baseline_mean);
         else if (i == j)
           val = 1.0;

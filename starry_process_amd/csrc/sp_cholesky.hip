@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void trsm_quad_kernel(double *sys, long ld, lo
 __global__ __launch_bounds__(256) void lnlike_reduce_kernel(
     const double *__restrict__ sys, long ld, long stride, int K, int M,
     const int32_t *__restrict__ info, double *__restrict__ lnlike,
-    uint32_t *__restrict__ status, uint32_t *__restrict__ status_out) {
+    uint32_t *__restrict__ status, uint32_t *__restrict__ status_out,
+    const sp_star *__restrict__ stars) {
   __shared__ double red[8];
   const int s = blockIdx.x;
   const double *Mx = sys + (size_t)s * stride;
@@ -160,7 +161,10 @@ __global__ __launch_bounds__(256) void lnlike_reduce_kernel(
     const double quad = (red[4] + red[5]) + (red[6] + red[7]);
     double v = -0.5 * quad;
     v -= M * logdet;
-    v -= 0.5 * K * M * 1.8378770664093453;  // log(2 pi)
+    // (ragged ensembles: the padding rows have unit pivots and zero residuals, only
+    //  the constant knows the number of valid cadences)
+    const int nobs = (stars && stars[s].nobs > 0 && stars[s].nobs < K) ? stars[s].nobs : K;
+    v -= 0.5 * nobs * M * 1.8378770664093453;  // log(2 pi)
     uint32_t st = status ? status[s] : 0u;
     if (info && info[s]) st |= SP_STAR_NOT_PD;
     if (v != v) st |= SP_STAR_NAN;
@@ -543,9 +547,9 @@ int sp_debug_phase(sp_handle *h, double *sys, int S, int K, int Kp, int32_t *inf
 
 int sp_launch_lnlike_reduce(const double *sys, int S, int K, int M, int Kp,
                             const int32_t *info, double *lnlike, uint32_t *status,
-                            hipStream_t st, uint32_t *status_out) {
+                            hipStream_t st, uint32_t *status_out, const sp_star *stars) {
   hipLaunchKernelGGL(lnlike_reduce_kernel, dim3(S), dim3(256), 0, st, sys,
-                     (long)Kp, (long)Kp * Kp, K, M, info, lnlike, status, status_out);
+                     (long)Kp, (long)Kp * Kp, K, M, info, lnlike, status, status_out, stars);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }

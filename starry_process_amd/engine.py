@@ -22,9 +22,9 @@ def _torch():
 
 
 def make_stars(S, period=1.0, inc_deg=60.0, tau=0.0, baseline_var=0.0,
-               baseline_mean=0.0, data_var=0.0, table=0):
+               baseline_mean=0.0, data_var=0.0, table=0, nobs=0):
     """Structured host array of ``sp_star`` (inclination converted to radians,
-    flux.py:236-238)."""
+    flux.py:236-238).  ``nobs``: valid cadences per star for ragged ensembles (0 = all)."""
     st = np.zeros(S, dtype=STAR_DTYPE)
     st["period"] = period
     st["inc"] = np.asarray(inc_deg, dtype=float) * (np.pi / 180)
@@ -33,6 +33,7 @@ def make_stars(S, period=1.0, inc_deg=60.0, tau=0.0, baseline_var=0.0,
     st["baseline_mean"] = baseline_mean
     st["data_var"] = data_var
     st["table"] = table
+    st["nobs"] = nobs
     return st
 
 

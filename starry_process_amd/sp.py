@@ -297,9 +297,34 @@ class StarryProcess(object):
         """Per-star log-likelihoods of S independent stars in one device call.
 
         t: (K,) or (S, K); flux: (S, K); data_cov: scalar, (S,) or (S, K);
-        i, p: scalars or (S,); u: (udeg,) shared or (S, udeg)."""
+        i, p: scalars or (S,); u: (udeg,) shared or (S, udeg).
+
+        Ragged ensembles: ``t`` and ``flux`` may be lists of S 1-D arrays of different
+        lengths (and ``data_cov`` a list of per-cadence variance vectors): the light
+        curves are padded to the longest and each star is evaluated on its own cadences
+        only (``sp_star.nobs``)."""
         e = self._engine
         f = self._flux
+        nobs = 0
+        if isinstance(flux, (list, tuple)):
+            S = len(flux)
+            lens = np.array([np.size(x) for x in flux], dtype=np.int32)
+            K = int(lens.max())
+            if not isinstance(t, (list, tuple)) or len(t) != S or any(np.size(a) != n for a, n in zip(t, lens)):
+                raise ValueError("ragged ensembles need one time array per light curve, of the same length")
+            tp = np.empty((S, K))
+            fp = np.zeros((S, K))
+            for s_ in range(S):
+                n_ = int(lens[s_])
+                tp[s_, :n_] = np.asarray(t[s_], dtype=np.float64).reshape(-1)
+                tp[s_, n_:] = tp[s_, n_ - 1]
+                fp[s_, :n_] = np.asarray(flux[s_], dtype=np.float64).reshape(-1)
+            if isinstance(data_cov, (list, tuple)) and np.ndim(data_cov[0]) == 1:
+                dp = np.ones((S, K))
+                for s_ in range(S):
+                    dp[s_, : lens[s_]] = np.asarray(data_cov[s_], dtype=np.float64)
+                data_cov = dp
+            t, flux, nobs = tp, fp, lens
         flux = np.asarray(flux, dtype=np.float64)
         S, K = flux.shape
         t = np.asarray(t, dtype=np.float64)
@@ -326,7 +351,7 @@ class StarryProcess(object):
         stars = make_stars(S, period=p, inc_deg=i, tau=self._tau,
                            baseline_var=np.broadcast_to(np.asarray(baseline_var, float), (S,)),
                            baseline_mean=np.broadcast_to(np.asarray(baseline_mean, float), (S,)),
-                           data_var=dvar, table=table)
+                           data_var=dvar, table=table, nobs=nobs)
         f._bind()
         rta1 = e.f64(e.rTA1L(utab))
         tab = mv = None

@@ -274,3 +274,27 @@ def test_predict_and_sample_conditional():
     assert np.all(np.abs(s1.mean(0) - np.array(mu)) < 5 * sig / np.sqrt(400))
     with pytest.raises(NotImplementedError):
         StarryProcess(ydeg=15, mean_ylm=mom["default_mean_ylm"], cov_ylm=mom["default_cov_ylm"]).predict(t, flux, 1e-6)
+
+
+def test_ragged_ensemble_equals_per_star_calls():
+    """Light curves of different lengths in one device call (sp_star.nobs): every star's
+    value equals the one of a single-star call on its own cadences -- marginal and
+    conditional branches, scalar and per-cadence noise, normalised and not."""
+    rng = np.random.RandomState(11)
+    lens = [300, 257, 64, 129, 1, 200]
+    ts, fs, ps, dcs = [], [], [], []
+    for s, n in enumerate(lens):
+        st = synthetic_star(40 + s, 300)
+        ts.append(st["t"][:n].copy())
+        fs.append(st["flux"][:n].copy())
+        ps.append(st["p"])
+        dcs.append(1e-6 * (1 + rng.rand(n)))
+    inc = [60.0, 35.0, 80.0, 15.0, 50.0, 70.0]
+    for kw in (dict(), dict(marginalize_over_inclination=False), dict(normalized=False, tau=2.0)):
+        sp = SP(15, **kw)
+        for data_cov in (1e-6, dcs):
+            ens = np.array(sp.log_likelihood_ensemble(ts, fs, data_cov, p=ps, i=inc, baseline_var=1e-7))
+            for s, n in enumerate(lens):
+                dc = data_cov if np.isscalar(data_cov) else data_cov[s]
+                one = float(sp.log_likelihood(ts[s], fs[s], dc, p=ps[s], i=inc[s], baseline_var=1e-7))
+                assert abs(ens[s] - one) <= 1e-10 * abs(one), (kw, s, n, ens[s], one)
