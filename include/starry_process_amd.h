@@ -254,6 +254,22 @@ int sp_cholesky_lnlike_batched(sp_handle *h, int S, int K, int M,
                                void *workspace_dev, double *lnlike_dev,
                                uint32_t *status_dev, void *stream);
 
+/* ---- reverse-mode ops ------------------------------------------
+ * The native gradient kernels of the reference, one entry point each:
+ *   tensordotRzRevOp          ops/wigner/tensordotRz_rev.py:9-29, wigner.h:344-404
+ *       bf [K, N]  ->  bM [K, N], btheta [K]
+ *   special_tensordotRzRevOp  ops/wigner/special_tensordotRz_rev.py, wigner.h:464-531
+ *       bf [K]     ->  bM [N, N] (gradient w.r.t. M; the op returns zeros for T,
+ *                      special_tensordotRz.py:30), btheta [K]
+ *   rTA1LRevOp                ops/flux/rTA1L.py:31-48, flux.h:529-557  (host -> host)
+ *       bf [N]     ->  bu [udeg]                                                    */
+int sp_tensordotRz_rev(sp_handle *h, const double *M_dev, const double *theta_dev, int K,
+                       const double *bf_dev, double *bM_dev, double *btheta_dev, void *stream);
+int sp_special_tensordotRz_rev(sp_handle *h, const double *T_dev, const double *M_dev,
+                               const double *theta_dev, int K, const double *bf_dev,
+                               double *bM_dev, double *btheta_dev, void *stream);
+int sp_rTA1L_rev(sp_handle *h, const double *u_host, const double *bf_host, double *bu_host);
+
 /* ---- Gaussian conditioning (sp.py:767-903 `predict`, 905-1002
  * `sample_conditional`) -----------------------------------------------------------
  * Ktt_dev [K, K]: covariance at the observed times INCLUDING data covariance and

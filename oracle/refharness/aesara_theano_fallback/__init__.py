@@ -202,6 +202,24 @@ def _dispatch_native(op, inputs):
         f = np.empty(N)
         lib.spref_rTA1L(_p(u), _p(f))
         return [f]
+    if name == "APPLY_SPECIFIC(tensordotRz_rev)":
+        M, theta, bf = _c(inputs[0]), _c(inputs[1]), _c(inputs[2])
+        K = theta.shape[0]
+        bM, bth = np.empty((K, N)), np.empty(K)
+        lib.spref_tensordotRz_rev(_p(M), _p(theta), ctypes.c_int(K), _p(bf), _p(bM), _p(bth))
+        return [bM, bth]
+    if name == "APPLY_SPECIFIC(special_tensordotRz_rev)":
+        Tm, M, theta, bf = _c(inputs[0]), _c(inputs[1]), _c(inputs[2]), _c(inputs[3])
+        K = theta.shape[0]
+        bM, bth = np.empty((N, N)), np.empty(K)
+        lib.spref_special_tensordotRz_rev(_p(Tm), _p(M), _p(theta), ctypes.c_int(K), _p(bf),
+                                          _p(bM), _p(bth))
+        return [bM, bth]
+    if name == "APPLY_SPECIFIC(rTA1L_rev)":
+        u, bf = _c(inputs[0]), _c(inputs[1])
+        bu = np.empty(op.udeg)
+        lib.spref_rTA1L_rev(_p(u), _p(bf), _p(bu))
+        return [bu]
     if name == "APPLY_SPECIFIC(latitude)":
         alpha = float(np.asarray(inputs[0]))
         beta = float(np.asarray(inputs[1]))

@@ -64,6 +64,45 @@ void spref_rTA1L(const double *u, double *f) {
 #endif
 }
 
+// reverse-mode kernels (ops/wigner/tensordotRz_rev.cc, special_tensordotRz_rev.cc,
+// ops/flux/rTA1L_rev.cc)
+void spref_tensordotRz_rev(const double *M, const double *theta, int K, const double *bf,
+                           double *bM, double *btheta) {
+  Map<RowMatrix<double, Dynamic, SP__N>> Mm(const_cast<double *>(M), K, SP__N);
+  Map<Vector<double, Dynamic>> th(const_cast<double *>(theta), K);
+  Map<RowMatrix<double, Dynamic, SP__N>> bfm(const_cast<double *>(bf), K, SP__N);
+  Map<RowMatrix<double, Dynamic, SP__N>> bMm(bM, K, SP__N);
+  Map<Vector<double, Dynamic>> bth(btheta, K);
+  sp::wigner::computeTensordotRzGradient(Mm, th, bfm, bMm, bth);
+}
+
+void spref_special_tensordotRz_rev(const double *T, const double *M, const double *theta, int K,
+                                   const double *bf, double *bM, double *btheta) {
+  Map<RowMatrix<double, SP__N, SP__N>> Tm(const_cast<double *>(T));
+  Map<RowMatrix<double, SP__N, SP__N>> Mm(const_cast<double *>(M));
+  Map<Vector<double, Dynamic>> th(const_cast<double *>(theta), K);
+  Map<Vector<double, Dynamic>> bfm(const_cast<double *>(bf), K);
+  Map<RowMatrix<double, SP__N, SP__N>> bMm(bM);
+  Map<Vector<double, Dynamic>> bth(btheta, K);
+  sp::wigner::computeSpecialTensordotRzGradient(Tm, Mm, th, bfm, bMm, bth);
+}
+
+void spref_rTA1L_rev(const double *u, const double *bf, double *bu) {
+#if SP__UMAX > 0
+  if (LD == nullptr) LD = new sp::flux::LimbDark<double>();
+  Map<Vector<double, SP__UMAX>> um(const_cast<double *>(u));
+  Map<RowVector<double, SP__N>> bfm(const_cast<double *>(bf));
+  Map<Vector<double, SP__UMAX>> bum(bu);
+  // the reference computes the Jacobian DDp in the forward pass (rTA1L.cc:39-58)
+  RowVector<double, SP__N> f;
+  LD->computerTA1L(um, f);
+  Vector<double, SP__UMAX> uv = um;
+  LD->computerTA1L(uv, bfm, bum);
+#else
+  (void)u; (void)bf; (void)bu;
+#endif
+}
+
 void spref_latitude(double alpha_in, double beta_in, double *q, double *dqda,
                     double *dqdb, double *Q, double *dQda, double *dQdb) {
   double alpha = alpha_in > 0.0 ? alpha_in : 0.0;

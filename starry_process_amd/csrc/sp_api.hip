@@ -529,6 +529,12 @@ int sp_rTA1L(sp_handle *h, const double *u_host, int nsets, double *out) {
   return SP_OK;
 }
 
+int sp_rTA1L_rev(sp_handle *h, const double *u_host, const double *bf_host, double *bu_host) {
+  if (!h || h->udeg < 1 || !u_host || !bf_host || !bu_host) return SP_ERR_INVALID;
+  sp_host_rTA1L_rev(h, u_host, bf_host, bu_host);
+  return SP_OK;
+}
+
 int sp_set_marginal_constants(sp_handle *h, const double *wnp, const double *Wnp) {
   if (h && h->device < 0) return SP_ERR_NO_DEVICE;
   if (!h || !wnp || !Wnp) return SP_ERR_INVALID;

@@ -245,27 +245,11 @@ void sp_build_flux_constants(int ydeg, int udeg, std::vector<double> &rT,
     }
 }
 
-// rTA1L(u) (flux.h:500-523 with computeLp, flux.h:415-441)
-void sp_host_rTA1L(const sp_handle *h, const double *u, double *out) {
+// v -> rT . L(p) . A1 for a limb-darkening polynomial p in the (udeg + 1)^2 basis; LINEAR
+// in p (flux.h:415-441 computeLp, 500-523)
+static void rTA1L_linear(const sp_handle *h, const double *p, double *out) {
   const int ydeg = h->ydeg, udeg = h->udeg, N = h->N;
   const int LU = ydeg + udeg, NLU = (LU + 1) * (LU + 1);
-  const int nu1 = (udeg + 1) * (udeg + 1);
-  if (udeg == 0) {
-    for (int i = 0; i < N; ++i) out[i] = h->rta1[i];
-    return;
-  }
-  // limb-darkening polynomial p = U1 . [-1, u], normalised to pi / (rT . p)
-  double p[(SP_MAX_UDEG + 1) * (SP_MAX_UDEG + 1)];
-  double dotp = 0.0;
-  for (int r = 0; r < nu1; ++r) {
-    double s = h->U1[(size_t)r * (udeg + 1)] * -1.0;
-    for (int c = 1; c <= udeg; ++c) s += h->U1[(size_t)r * (udeg + 1) + c] * u[c - 1];
-    p[r] = s;
-    dotp += h->rT[r] * s;
-  }
-  const double scale = (1.0 / dotp) * M_PI;
-  for (int r = 0; r < nu1; ++r) p[r] *= scale;
-
   // v = rT . Lp, column n1 of Lp being (Ylm-basis monomial n1) x p
   std::vector<double> v(N, 0.0), col(NLU);
   for (int l1 = 0; l1 <= ydeg; ++l1)
@@ -283,6 +267,65 @@ void sp_host_rTA1L(const sp_handle *h, const double *u, double *out) {
     double s = 0.0;
     for (int r = 0; r < N; ++r) s += v[r] * h->A1[(size_t)r * NLU + c];
     out[c] = s;
+  }
+}
+
+// limb-darkening polynomial p = U1 . [-1, u] and rT . p (flux.h:506-512)
+static double ld_polynomial(const sp_handle *h, const double *u, double *p) {
+  const int udeg = h->udeg, nu1 = (udeg + 1) * (udeg + 1);
+  double dotp = 0.0;
+  for (int r = 0; r < nu1; ++r) {
+    double s = h->U1[(size_t)r * (udeg + 1)] * -1.0;
+    for (int c = 1; c <= udeg; ++c) s += h->U1[(size_t)r * (udeg + 1) + c] * u[c - 1];
+    p[r] = s;
+    dotp += h->rT[r] * s;
+  }
+  return dotp;
+}
+
+// rTA1L(u) (flux.h:500-523)
+void sp_host_rTA1L(const sp_handle *h, const double *u, double *out) {
+  const int udeg = h->udeg, N = h->N;
+  const int nu1 = (udeg + 1) * (udeg + 1);
+  if (udeg == 0) {
+    for (int i = 0; i < N; ++i) out[i] = h->rta1[i];
+    return;
+  }
+  // normalised to pi / (rT . p)
+  double p[(SP_MAX_UDEG + 1) * (SP_MAX_UDEG + 1)];
+  const double dotp = ld_polynomial(h, u, p);
+  const double scale = (1.0 / dotp) * M_PI;
+  for (int r = 0; r < nu1; ++r) p[r] *= scale;
+  rTA1L_linear(h, p, out);
+}
+
+// Reverse mode of rTA1L (flux.h:529-557): bu = (DDp bf)^T DpDu, with DDp the (constant)
+// Jacobian of the linear map above and DpDu the derivative of the normalised polynomial.
+void sp_host_rTA1L_rev(const sp_handle *h, const double *u, const double *bf, double *bu) {
+  const int udeg = h->udeg, N = h->N;
+  const int nu1 = (udeg + 1) * (udeg + 1);
+  if (udeg == 0) return;
+  double p[(SP_MAX_UDEG + 1) * (SP_MAX_UDEG + 1)], bp[(SP_MAX_UDEG + 1) * (SP_MAX_UDEG + 1)];
+  const double dotp = ld_polynomial(h, u, p);
+  const double norm = 1.0 / dotp;
+  for (int r = 0; r < nu1; ++r) p[r] *= norm * M_PI;
+  // bp = DDp . bf : row i of DDp is the image of the i-th unit polynomial
+  std::vector<double> e(nu1), row(N);
+  for (int i = 0; i < nu1; ++i) {
+    for (int r = 0; r < nu1; ++r) e[r] = r == i ? 1.0 : 0.0;
+    rTA1L_linear(h, e.data(), row.data());
+    double s = 0.0;
+    for (int n = 0; n < N; ++n) s += row[n] * bf[n];
+    bp[i] = s;
+  }
+  // DpDu = pi norm U1 - p (rT . U1) norm   (columns 1..udeg <-> u)
+  for (int c = 1; c <= udeg; ++c) {
+    double rTU = 0.0;
+    for (int r = 0; r < nu1; ++r) rTU += h->rT[r] * h->U1[(size_t)r * (udeg + 1) + c];
+    double s = 0.0;
+    for (int r = 0; r < nu1; ++r)
+      s += bp[r] * (M_PI * norm * h->U1[(size_t)r * (udeg + 1) + c] - p[r] * rTU * norm);
+    bu[c - 1] = s;
   }
 }
 

@@ -97,6 +97,7 @@ void sp_build_flux_constants(int ydeg, int udeg, std::vector<double> &rT,
                              std::vector<double> &A1, std::vector<double> &U1,
                              std::vector<double> &rta1);
 void sp_host_rTA1L(const sp_handle *h, const double *u, double *out);
+void sp_host_rTA1L_rev(const sp_handle *h, const double *u, const double *bf, double *bu);
 
 // ---- kernel launchers (one per .hip file) -----------------------------------
 int sp_launch_Rx(sp_handle *h, const double *cs_dev /* [n,2] cos,sin */, int n,

@@ -349,6 +349,108 @@ __global__ __launch_bounds__(256) void tensordotrz_kernel(
   }
 }
 
+// Reverse mode of tensordotRz (wigner.h:344-404), one workgroup per row k:
+//   bM[k][n]   = bf[k][n] cos(m_n th) + bf[k][mirror(n)] sin(m_mirror(n) th)
+//   btheta[k]  = sum_n m_n (M[k][mirror(n)] bf[k][n] cos(m_n th) - M[k][n] bf[k][n] sin(m_n th))
+// (the reference scatters tmp_s into column mirror(n); this is the gather form).
+__global__ __launch_bounds__(256) void tensordotrz_rev_kernel(
+    int ydeg, int N, const int32_t *__restrict__ m_of, const int32_t *__restrict__ mirror,
+    const double *__restrict__ M, const double *__restrict__ theta,
+    const double *__restrict__ bf, double *__restrict__ bM, double *__restrict__ btheta) {
+  __shared__ double cn[SP_MAX_YDEG + 1], sn[SP_MAX_YDEG + 1], red[4];
+  const int k = blockIdx.x;
+  if (threadIdx.x == 0) cheb_fill(ydeg, theta[k], cn, sn);
+  __syncthreads();
+  const double *Mk = M + (size_t)k * N, *bk = bf + (size_t)k * N;
+  double part = 0.0;
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    const int m = m_of[n], a = m < 0 ? -m : m, nm = mirror[n];
+    const double cm = cn[a];
+    const double sm = m < 0 ? -sn[a] : sn[a];
+    const double tc = bk[n] * cm, ts = bk[n] * sm;
+    // column n also receives tmp_s of its mirror, whose m is -m: sin(-m th) = -sm
+    bM[(size_t)k * N + n] = tc + bk[nm] * (-sm);
+    part += m * (Mk[nm] * tc - Mk[n] * ts);
+  }
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) btheta[k] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// Reverse mode of special_tensordotRz (wigner.h:464-531).
+//   coef kernel (one workgroup):  Ac[a] = sum_k bf_k cos(a th_k),  As[a] = sum_k bf_k sin(a th_k)
+//   bM kernel (one workgroup per row n):
+//       bM[n][c] = sign(m_n) As[|m_n|] T[n][mirror(c)] + Ac[|m_n|] T[n][c]
+//   btheta kernel: with r1 / r2 the row sums of special_rows_kernel,
+//       btheta_k = bf_k sum_n ( -m_n sin(m_n th_k) r1[n] + m_n cos(m_n th_k) r2[n] )
+__global__ __launch_bounds__(256) void special_rev_coef_kernel(
+    int ydeg, int K, const double *__restrict__ theta, const double *__restrict__ bf,
+    double *__restrict__ Ac, double *__restrict__ As) {
+  __shared__ double red[4];
+  double pc[SP_MAX_YDEG + 1], ps[SP_MAX_YDEG + 1];
+  for (int a = 0; a <= ydeg; ++a) pc[a] = ps[a] = 0.0;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    double cn[SP_MAX_YDEG + 1], sn[SP_MAX_YDEG + 1];
+    cheb_fill(ydeg, theta[k], cn, sn);
+    const double b = bf[k];
+    for (int a = 0; a <= ydeg; ++a) {
+      pc[a] += b * cn[a];
+      ps[a] += b * sn[a];
+    }
+  }
+  for (int a = 0; a <= ydeg; ++a) {
+    for (int pass = 0; pass < 2; ++pass) {
+      double v = pass ? ps[a] : pc[a];
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+      __syncthreads();
+      if (threadIdx.x == 0) (pass ? As : Ac)[a] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void special_rev_bM_kernel(
+    int N, const int32_t *__restrict__ m_of, const int32_t *__restrict__ mirror,
+    const double *__restrict__ T, const double *__restrict__ Ac, const double *__restrict__ As,
+    double *__restrict__ bM) {
+  const int n = blockIdx.x;
+  const int m = m_of[n], a = m < 0 ? -m : m;
+  const double cs = Ac[a], ss = m < 0 ? -As[a] : As[a];
+  const double *Tn = T + (size_t)n * N;
+  for (int c = threadIdx.x; c < N; c += 256) bM[(size_t)n * N + c] = ss * Tn[mirror[c]] + cs * Tn[c];
+}
+
+__global__ __launch_bounds__(256) void special_rev_btheta_kernel(
+    int ydeg, int N, const int32_t *__restrict__ m_of, const double *__restrict__ r1,
+    const double *__restrict__ r2, const double *__restrict__ theta,
+    const double *__restrict__ bf, int K, double *__restrict__ btheta) {
+  __shared__ double R1[SP_MAX_YDEG + 1], R2[SP_MAX_YDEG + 1];
+  if (threadIdx.x <= ydeg) {
+    // harmonic a collects the rows with |m_n| = a, in index order
+    const int a = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = 0; n < N; ++n) {
+      const int m = m_of[n];
+      if (m == a || m == -a) {
+        s1 += r1[n];
+        s2 += m * r2[n];
+      }
+    }
+    R1[a] = s1;
+    R2[a] = s2;
+  }
+  __syncthreads();
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  double cn[SP_MAX_YDEG + 1], sn[SP_MAX_YDEG + 1];
+  cheb_fill(ydeg, theta[k], cn, sn);
+  double acc = 0.0;
+  for (int a = 0; a <= ydeg; ++a) acc += -a * sn[a] * R1[a] + cn[a] * R2[a];
+  btheta[k] = bf[k] * acc;
+}
+
 // r1[n] = sum_j T[n,j] M[n,j];  r2[n] = sum_j T[n,j] M[n, mirror(j)]
 // one wave per row n, 4 waves per workgroup
 __global__ __launch_bounds__(256) void special_rows_kernel(
@@ -496,6 +598,44 @@ int sp_special_tensordotRz(sp_handle *h, const double *T_dev,
   SP_LAUNCH_CHECK();
   hipLaunchKernelGGL(special_series_kernel, dim3((K + 255) / 256), dim3(256), 0,
                      st, h->ydeg, r1, r2, theta_dev, K, f_dev);
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}
+
+// ---- reverse mode -----------------------------------------
+int sp_tensordotRz_rev(sp_handle *h, const double *M_dev, const double *theta_dev, int K,
+                       const double *bf_dev, double *bM_dev, double *btheta_dev, void *stream) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || !M_dev || !theta_dev || !bf_dev || !bM_dev || !btheta_dev || K < 0)
+    return SP_ERR_INVALID;
+  if (K == 0) return SP_OK;
+  hipLaunchKernelGGL(tensordotrz_rev_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, h->ydeg,
+                     h->N, h->d_m_of, h->d_mirror, M_dev, theta_dev, bf_dev, bM_dev, btheta_dev);
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}
+
+int sp_special_tensordotRz_rev(sp_handle *h, const double *T_dev, const double *M_dev,
+                               const double *theta_dev, int K, const double *bf_dev,
+                               double *bM_dev, double *btheta_dev, void *stream) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || !T_dev || !M_dev || !theta_dev || !bf_dev || !bM_dev || !btheta_dev || K < 0)
+    return SP_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const int N = h->N;
+  double *r1 = h->d_scratch, *r2 = r1 + N, *Ac = r2 + N, *As = Ac + (SP_MAX_YDEG + 1);
+  hipLaunchKernelGGL(special_rev_coef_kernel, dim3(1), dim3(256), 0, st, h->ydeg, K, theta_dev,
+                     bf_dev, Ac, As);
+  SP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(special_rev_bM_kernel, dim3(N), dim3(256), 0, st, N, h->d_m_of, h->d_mirror,
+                     T_dev, Ac, As, bM_dev);
+  SP_LAUNCH_CHECK();
+  if (K == 0) return SP_OK;
+  hipLaunchKernelGGL(special_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, st, N, h->d_mirror,
+                     T_dev, M_dev, r1, r2);
+  SP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(special_rev_btheta_kernel, dim3((K + 255) / 256), dim3(256), 0, st, h->ydeg,
+                     N, h->d_m_of, r1, r2, theta_dev, bf_dev, K, btheta_dev);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }

@@ -149,6 +149,38 @@ class Engine(object):
         check(self._L.sp_special_tensordotRz(self._h, self._p(T), self._p(M), self._p(theta), K, self._p(f), self._stream()))
         return f
 
+    def tensordotRz_rev(self, M, theta, bf):
+        """Reverse mode of tensordotRz: (bM [K, N], btheta [K])."""
+        M, bf = self.f64(M), self.f64(bf)
+        theta = self.f64(theta).reshape(-1)
+        K = theta.shape[0]
+        assert M.shape == (K, self.N) and bf.shape == (K, self.N)
+        bM, bth = self.empty(K, self.N), self.empty(K)
+        check(self._L.sp_tensordotRz_rev(self._h, self._p(M), self._p(theta), K, self._p(bf),
+                                         self._p(bM), self._p(bth), self._stream()))
+        return bM, bth
+
+    def special_tensordotRz_rev(self, T, M, theta, bf):
+        """Reverse mode of special_tensordotRz: (bM [N, N], btheta [K])."""
+        T, M = self.f64(T), self.f64(M)
+        theta, bf = self.f64(theta).reshape(-1), self.f64(bf).reshape(-1)
+        K = theta.shape[0]
+        assert T.shape == (self.N, self.N) and M.shape == (self.N, self.N) and bf.shape == (K,)
+        bM, bth = self.empty(self.N, self.N), self.empty(K)
+        check(self._L.sp_special_tensordotRz_rev(self._h, self._p(T), self._p(M), self._p(theta), K,
+                                                 self._p(bf), self._p(bM), self._p(bth), self._stream()))
+        return bM, bth
+
+    def rTA1L_rev(self, u, bf):
+        """Reverse mode of rTA1L: bu [udeg] (host)."""
+        u = np.ascontiguousarray(np.asarray(u, dtype=np.float64).reshape(-1)[: self.udeg])
+        bf = np.ascontiguousarray(np.asarray(bf, dtype=np.float64).reshape(-1))
+        if u.shape[0] != self.udeg or bf.shape[0] != self.N:
+            raise ValueError("Vector `u` or `bf` has the wrong size.")
+        bu = np.empty(self.udeg)
+        check(self._L.sp_rTA1L_rev(self._h, hptr(u), hptr(bf), hptr(bu)))
+        return bu
+
     def rTA1(self):
         out = np.empty(self.N)
         check(self._L.sp_rTA1(self._h, hptr(out)))

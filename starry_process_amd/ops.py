@@ -77,6 +77,13 @@ class tensordotRzOp(_BaseOp):
             raise ValueError("theta must be a vector")
         return _out(self.engine.tensordotRz(M, theta), tt)
 
+    def grad(self, inputs, gradients):
+        """[bM, btheta] (ops/wigner/tensordotRz.py:33-34 -> tensordotRzRevOp)."""
+        M, theta = inputs
+        tt = _is_torch(M)
+        bM, bth = self.engine.tensordotRz_rev(M, theta, gradients[0])
+        return [_out(bM, tt), _out(bth, tt)]
+
 
 class special_tensordotRzOp(_BaseOp):
     def __call__(self, T, M, theta):
@@ -89,6 +96,15 @@ class special_tensordotRzOp(_BaseOp):
             raise ValueError("theta must be a vector")
         return _out(self.engine.special_tensordotRz(T, M, theta), tt)
 
+    def grad(self, inputs, gradients):
+        """[zeros(N, N), bM, btheta]: like the reference, no gradient flows to T
+        (ops/wigner/special_tensordotRz.py:29-32 -> special_tensordotRzRevOp)."""
+        T, M, theta = inputs
+        tt = _is_torch(M)
+        bM, bth = self.engine.special_tensordotRz_rev(T, M, theta, gradients[0])
+        zero = bM * 0.0
+        return [_out(zero, tt), _out(bM, tt), _out(bth, tt)]
+
 
 class rTA1Op(_BaseOp):
     def __call__(self):
@@ -100,6 +116,10 @@ class rTA1LOp(_BaseOp):
         if np.ndim(u) != 1:
             raise ValueError("u must be a vector")
         return Eager(self.engine.rTA1L(np.asarray(u, dtype=float)[: self.udeg])[0])
+
+    def grad(self, inputs, gradients):
+        """(bu,) (ops/flux/rTA1L.py:27-28 -> rTA1LRevOp)."""
+        return (Eager(self.engine.rTA1L_rev(np.asarray(inputs[0], dtype=float), np.asarray(gradients[0], dtype=float))),)
 
 
 class AlphaBetaOp(object):

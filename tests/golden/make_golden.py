@@ -27,6 +27,7 @@ Files (L = ydeg):
                     which the eager stand-in cannot represent; the generator evaluates
                     the same expression sequence (calibrate/log_prob.py:37-91) eagerly on
                     the reference's own StarryProcess / cho_factor / cho_solve.
+  rev_L{L}.npz      reverse-mode ops (tensordotRz_rev, special_tensordotRz_rev, rTA1L_rev)
   predict.npz       StarryProcess.predict (sp.py:767-903): conditional mean / covariance
   upstream.npz      upstream-of-path pieces: size / latitude / longitude first
                     moments, log_jac, gauss2beta / beta2gauss, mu / sigma
@@ -264,6 +265,33 @@ def gen_upstream():
     save("upstream.npz", **out)
 
 
+def gen_rev(L, U=2):
+    """Reverse-mode native ops of the reference, through the ops' own
+    grad wiring (ops/wigner/tensordotRz.py:33-34, special_tensordotRz.py, ops/flux/rTA1L.py:27-28)."""
+    N = (L + 1) ** 2
+    rng = np.random.RandomState(300 + L)
+    K = 9
+    out = {}
+    M = rng.randn(K, N)
+    th = rng.uniform(-7, 7, K)
+    bf = rng.randn(K, N)
+    bM, bth = ops.tensordotRzOp(ydeg=L, udeg=U).grad([M, th], [bf])
+    # inputs are re-drawn by the tests from RandomState(300 + L) in this order:
+    # randn(K,N), uniform(-7,7,K), randn(K,N), randn(N,N), randn(N,N), randn(K), randn(N)
+    out.update(seed=np.array(300 + L), K=np.array(K), td_bM=A(bM), td_btheta=A(bth))
+    Tm = rng.randn(N, N)
+    Mm = rng.randn(N, N)
+    bfs = rng.randn(K)
+    res = ops.special_tensordotRzOp(ydeg=L, udeg=U).grad([Tm, Mm, th], [bfs])
+    assert not np.any(A(res[0]))          # the op returns zeros for d/dT (special_tensordotRz.py:30)
+    out.update(sp_bM=A(res[1]), sp_btheta=A(res[2]))
+    us = np.array([[0.0, 0.0], [0.4, 0.2], [0.1, 0.5]])
+    bfu = rng.randn(N)
+    ld = ops.rTA1LOp(ydeg=L, udeg=U)
+    out.update(ld_u=us, ld_bu=np.array([A(ld.grad([u], [bfu])[0]) for u in us]))
+    save("rev_L%d.npz" % L, **out)
+
+
 def gen_predict():
     """StarryProcess.predict for small cases (unnormalised processes only, sp.py:855-858)."""
     mom = np.load(os.path.join(OUT, "moments_L15.npz"))
@@ -390,12 +418,14 @@ def gen_lnlike():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "consts", "moments", "cov", "norm", "lnlike", "upstream", "calibrate", "predict"]
+    which = sys.argv[1:] or ["ops", "consts", "moments", "cov", "norm", "lnlike", "upstream", "calibrate", "predict", "rev"]
     for L in (5, 15, 20):
         if "ops" in which:
             gen_ops(L)
         if "consts" in which:
             gen_consts(L)
+        if "rev" in which:
+            gen_rev(L)
         if "moments" in which or "cov" in which:
             names = ["default", "hilat", "spread"] if L == 15 else ["default"]
             mom = gen_moments(L, names) if "moments" in which else None

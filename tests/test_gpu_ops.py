@@ -294,3 +294,41 @@ def test_allgather_lnlike_single_rank_communicator():
     finally:
         rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+@pytest.mark.parametrize("L", [5, 15, 20])
+def test_reverse_mode_ops(engines, L):
+    """tensordotRz_rev, special_tensordotRz_rev, rTA1L_rev against the
+    reference's own reverse-mode kernels run through the ops' grad wiring
+    (tests/golden/make_golden.py: gen_rev), and against finite differences of the forward ops."""
+    import torch
+    from starry_process_amd.ops import tensordotRzOp, special_tensordotRzOp, rTA1LOp
+
+    g = golden("rev_L%d" % L)
+    N = (L + 1) ** 2
+    rng = np.random.RandomState(int(g["seed"]))
+    K = int(g["K"])
+    M, th, bf = rng.randn(K, N), rng.uniform(-7, 7, K), rng.randn(K, N)
+    Tm, Mm, bfs, bfu = rng.randn(N, N), rng.randn(N, N), rng.randn(K), rng.randn(N)
+    op = tensordotRzOp(ydeg=L, udeg=2)
+    bM, bth = (np.array(x) for x in op.grad([M, th], [bf]))
+    assert np.abs(bM - g["td_bM"]).max() < 1e-13 * np.abs(g["td_bM"]).max()
+    assert np.abs(bth - g["td_btheta"]).max() < 1e-12 * np.abs(g["td_btheta"]).max()
+    # finite difference in theta of <bf, f>
+    eps = 1e-6
+    fp = np.array(op(M, th + eps))
+    fm = np.array(op(M, th - eps))
+    fd = ((fp - fm) * bf).sum(1) / (2 * eps)
+    assert np.abs(fd - bth).max() < 1e-6 * np.abs(bth).max()
+    sop = special_tensordotRzOp(ydeg=L, udeg=2)
+    zT, bMs, bths = (np.array(x) for x in sop.grad([Tm, Mm, th], [bfs]))
+    assert not zT.any()
+    assert np.abs(bMs - g["sp_bM"]).max() < 1e-12 * np.abs(g["sp_bM"]).max()
+    assert np.abs(bths - g["sp_btheta"]).max() < 1e-12 * np.abs(g["sp_btheta"]).max()
+    fd = (np.array(sop(Tm, Mm, th + eps)) - np.array(sop(Tm, Mm, th - eps))) * bfs / (2 * eps)
+    assert np.abs(fd - bths).max() < 1e-6 * np.abs(bths).max()
+    lop = rTA1LOp(ydeg=L, udeg=2)
+    for u, bu_ref in zip(g["ld_u"], g["ld_bu"]):
+        bu = np.array(lop.grad([u], [bfu])[0])
+        # rTA1L itself carries 1e-12 (L<=15) .. 1e-10 (L=20) of summation noise (DESIGN.md 3)
+        assert np.abs(bu - bu_ref).max() < (3e-10 if L <= 15 else 3e-8) * np.abs(bu_ref).max()

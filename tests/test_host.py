@@ -86,6 +86,27 @@ def test_flux_operator_host(L):
     o2 = np.empty((len(us), N))
     _lib.check(lib.sp_rTA1L(h, _lib.hptr(us), len(us), _lib.hptr(o2)))
     assert np.max(np.abs(o2 - g["rTA1L"])) < 1e-13
+    # reverse mode (flux.h:529-557) against the reference's kernel and a finite difference
+    gr = golden("rev_L%d" % L)
+    rng = np.random.RandomState(int(gr["seed"]))
+    K = int(gr["K"])
+    # the generator's draw order (make_golden.py: gen_rev)
+    rng.randn(K, N), rng.uniform(-7, 7, K), rng.randn(K, N), rng.randn(N, N), rng.randn(N, N), rng.randn(K)
+    bfu = rng.randn(N)
+    for u, bu_ref in zip(gr["ld_u"], gr["ld_bu"]):
+        u = np.ascontiguousarray(u)
+        bu = np.empty(2)
+        _lib.check(lib.sp_rTA1L_rev(h, _lib.hptr(u), _lib.hptr(bfu), _lib.hptr(bu)))
+        assert np.abs(bu - bu_ref).max() < (3e-10 if L <= 15 else 3e-8) * np.abs(bu_ref).max()
+        for c in range(2):
+            up, um = u.copy(), u.copy()
+            up[c] += 1e-4   # the forward op carries up to 1e-10 of summation noise at L = 20
+            um[c] -= 1e-4
+            fp, fm = np.empty((1, N)), np.empty((1, N))
+            _lib.check(lib.sp_rTA1L(h, _lib.hptr(up), 1, _lib.hptr(fp)))
+            _lib.check(lib.sp_rTA1L(h, _lib.hptr(um), 1, _lib.hptr(fm)))
+            fd = ((fp - fm)[0] * bfu).sum() / 2e-4
+            assert abs(fd - bu[c]) < 1e-4 * max(1.0, abs(bu[c]))
     lib.sp_destroy(h)
     # udeg = 0 handle: rTA1L degenerates to rTA1 (flux.py:211-221)
     _lib.check(lib.sp_create(L, 0, -1, ctypes.byref(h)))
