@@ -86,13 +86,15 @@ def get_log_prob_ensemble(
 ):
     """log_prob(r, a, b, c, n) = sum over stars of per-star log-likelihoods (+ log_jac),
     each star with its own period / inclination / limb darkening / noise:
-    t (K,) or (S, K); flux (S, K); ferr, p, i scalars or (S,); u (udeg,) or (S, udeg).
+    t (K,) or (S, K); flux (S, K); ferr, p, i scalars or (S,); u (udeg,) or (S, udeg);
+    or t and flux lists of S arrays of different lengths (ragged ensemble).
     Under an initialised torch.distributed job the stars are sharded over the ranks
     (one RCCL all-gather of S doubles per call); every rank returns the same value."""
     from . import ensemble
 
-    flux = np.asarray(flux, dtype=np.float64)
-    S, K = flux.shape
+    if not isinstance(flux, (list, tuple)):     # (lists: light curves of different lengths)
+        flux = np.asarray(flux, dtype=np.float64)
+    S = len(flux)
     ferr2 = np.broadcast_to(np.asarray(ferr, dtype=np.float64) ** 2, (S,))
 
     def log_prob(r, a, b, c, n):

@@ -61,8 +61,10 @@ def sharded_log_likelihood(sp, t, flux, data_cov, p=None, i=None, u=None,
     import torch
     import torch.distributed as dist
 
-    flux = np.asarray(flux, dtype=np.float64)
-    S = flux.shape[0]
+    ragged = isinstance(flux, (list, tuple))   # light curves of different lengths
+    if not ragged:
+        flux = np.asarray(flux, dtype=np.float64)
+    S = len(flux)
     if dist.is_available() and dist.is_initialized():
         rank, world = dist.get_rank(group), dist.get_world_size(group)
     else:
@@ -70,12 +72,18 @@ def sharded_log_likelihood(sp, t, flux, data_cov, p=None, i=None, u=None,
     lo, hi = shard_bounds(S, rank, world)
 
     def cut(x):
+        if isinstance(x, (list, tuple)):
+            return x[lo:hi] if len(x) == S else x
         x = np.asarray(x)
         return x[lo:hi] if x.ndim >= 1 and x.shape[0] == S else x
 
-    t = np.asarray(t, dtype=np.float64)
+    if ragged:
+        tl = cut(t)
+    else:
+        t = np.asarray(t, dtype=np.float64)
+        tl = cut(t) if t.ndim == 2 else t
     local = sp.log_likelihood_ensemble(
-        cut(t) if t.ndim == 2 else t, flux[lo:hi], cut(data_cov),
+        tl, flux[lo:hi], cut(data_cov),
         i=None if i is None else cut(i), p=None if p is None else cut(p),
         u=None if u is None else (cut(u) if np.ndim(u) == 2 else u),
         baseline_mean=cut(baseline_mean), baseline_var=cut(baseline_var))

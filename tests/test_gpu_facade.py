@@ -298,3 +298,23 @@ def test_ragged_ensemble_equals_per_star_calls():
                 dc = data_cov if np.isscalar(data_cov) else data_cov[s]
                 one = float(sp.log_likelihood(ts[s], fs[s], dc, p=ps[s], i=inc[s], baseline_var=1e-7))
                 assert abs(ens[s] - one) <= 1e-10 * abs(one), (kw, s, n, ens[s], one)
+
+
+def test_ragged_ensemble_through_calibrate():
+    """get_log_prob_ensemble with light curves of different lengths = sum of single-star values."""
+    from starry_process_amd import StarryProcess
+    from starry_process_amd.calibrate import get_log_prob_ensemble
+
+    lens = [120, 64, 97]
+    ts, fs, ps = [], [], []
+    for s, n in enumerate(lens):
+        st = synthetic_star(70 + s, 120)
+        ts.append(st["t"][:n].copy())
+        fs.append(st["flux"][:n].copy())
+        ps.append(st["p"])
+    hyper = (20.0, 0.40, 0.27, 0.1, 10.0)
+    f = get_log_prob_ensemble(ts, fs, ferr=1e-3, p=ps, apply_jac=False)
+    tot = f(*hyper)
+    sp = StarryProcess(ydeg=15, r=hyper[0], a=hyper[1], b=hyper[2], c=hyper[3], n=hyper[4])
+    ref = sum(float(sp.log_likelihood(ts[s], fs[s], 1e-6, p=ps[s])) for s in range(3))
+    assert abs(tot / ref - 1) < 1e-10
