@@ -316,5 +316,6 @@ def test_ragged_ensemble_through_calibrate():
     f = get_log_prob_ensemble(ts, fs, ferr=1e-3, p=ps, apply_jac=False)
     tot = f(*hyper)
     sp = StarryProcess(ydeg=15, r=hyper[0], a=hyper[1], b=hyper[2], c=hyper[3], n=hyper[4])
-    ref = sum(float(sp.log_likelihood(ts[s], fs[s], 1e-6, p=ps[s])) for s in range(3))
+    # (baseline_log_var defaults to 0, i.e. a baseline variance of 1, as in the reference)
+    ref = sum(float(sp.log_likelihood(ts[s], fs[s], 1e-6, p=ps[s], baseline_var=1.0)) for s in range(3))
     assert abs(tot / ref - 1) < 1e-10
