@@ -221,6 +221,54 @@ class StarryProcess(object):
             val = -np.inf
         return Eager(val)
 
+    # -- prior samples (sp.py:489-516, 729-765, 1237-1282) -------------------------------
+    # The random numbers are NumPy's: the reference's Theano RandomStream cannot be
+    # reproduced, so these methods are pinned by their moments, not by sample values.
+    def _rng(self, seed):
+        return np.random.RandomState(self._kwargs.get("seed", 0) if seed is None else seed)
+
+    @property
+    def cho_cov_ylm(self):
+        """Lower Cholesky factor of Sigma_y (sp.py:436-441), factored on the device."""
+        L, info = self._engine.cho_factor(self._cov_ylm)
+        L = L.cpu().numpy()
+        return Eager(np.full_like(L, np.nan) if int(info.reshape(-1)[0].item()) else L)
+
+    def sample_ylm(self, t=None, nsamples=1, seed=None):
+        """Samples of the spherical-harmonic coefficients from the prior, shape
+        (nsamples, nylm) (sp.py:503-507).  The time-variable form (``t`` given) needs the
+        reference's SampleYlmTemporalOp, which is outside this package's scope."""
+        if t is not None:
+            raise NotImplementedError("time-variable Ylm samples are not implemented")
+        u = self._rng(seed).randn(self._nylm, int(nsamples))
+        return Eager((self._mean_ylm[:, None] + np.array(self.cho_cov_ylm) @ u).T)
+
+    def sample(self, t, i=defaults["i"], p=defaults["p"], u=defaults["u"][: defaults["udeg"]],
+               nsamples=1, eps=defaults["eps"], seed=None):
+        """Light curves drawn from the prior, shape (nsamples, ntimes) (sp.py:729-765):
+        mean + L z with L the device Cholesky factor of cov(t) + eps I."""
+        t = np.asarray(t, dtype=np.float64).reshape(-1)
+        cov = np.array(self.cov(t, i, p, u))
+        cov[np.diag_indices_from(cov)] += eps
+        L, info = self._engine.cho_factor(cov)
+        L = L.cpu().numpy()
+        if int(info.reshape(-1)[0].item()):
+            L = np.full_like(L, np.nan)
+        U = self._rng(seed).randn(t.shape[0], int(nsamples))
+        return Eager((np.array(self.mean(t, i, p, u))[:, None] + L @ U).T)
+
+    def flux(self, y, t, i=defaults["i"], p=defaults["p"], u=defaults["u"][: defaults["udeg"]]):
+        """Light curves of given spherical-harmonic vectors y (nsamples, nylm)
+        (sp.py:1237-1282), through the device design matrix."""
+        if self._time_variable:
+            raise NotImplementedError("time-variable maps are not implemented")
+        y = np.atleast_2d(np.asarray(y, dtype=np.float64))
+        A = np.array(self._flux.design_matrix(t, i, p, u))      # (ntimes, nylm)
+        flux = (A @ y.T).T
+        if self._normalized:
+            flux = (1.0 + flux) / np.mean(1.0 + flux, axis=-1).reshape(-1, 1) - 1.0
+        return Eager(flux)
+
     # -- conditioning on data (sp.py:767-1002) ---------------------------------------------
     def predict(
         self,

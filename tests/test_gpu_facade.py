@@ -319,3 +319,32 @@ def test_ragged_ensemble_through_calibrate():
     # (baseline_log_var defaults to 0, i.e. a baseline variance of 1, as in the reference)
     ref = sum(float(sp.log_likelihood(ts[s], fs[s], 1e-6, p=ps[s], baseline_var=1.0)) for s in range(3))
     assert abs(tot / ref - 1) < 1e-10
+
+
+def test_prior_samples_and_flux():
+    """sample / sample_ylm / flux (sp.py:489-516, 729-765, 1237-1282): the random stream of the
+    reference cannot be reproduced, so the samples are pinned by their first two moments
+    against the process mean / covariance, and `flux` against the design matrix."""
+    sp = SP(15, normalized=False)
+    t = np.linspace(0, 2.0, 40)
+    n = 4000
+    S = np.array(sp.sample(t, p=0.8, nsamples=n, seed=1))
+    assert S.shape == (n, 40)
+    mean, cov = np.array(sp.mean(t, p=0.8)), np.array(sp.cov(t, p=0.8))
+    sig = np.sqrt(np.diag(cov))
+    assert np.all(np.abs(S.mean(0) - mean) < 5 * sig / np.sqrt(n))
+    emp = np.cov(S.T)
+    assert np.abs(emp - cov).max() < 0.15 * np.abs(cov).max()
+    Y = np.array(sp.sample_ylm(nsamples=3000, seed=2))
+    assert Y.shape == (3000, 256)
+    mom = golden("moments_L15")
+    # l = 0, 1 coefficients: compare the empirical covariance block with Sigma_y
+    blk = np.cov(Y[:, :4].T)
+    assert np.abs(blk - mom["default_cov_ylm"][:4, :4]).max() < 0.15 * np.abs(mom["default_cov_ylm"][:4, :4]).max()
+    L = np.array(sp.cho_cov_ylm)
+    assert np.abs(L @ L.T - mom["default_cov_ylm"]).max() < 1e-13 * np.abs(mom["default_cov_ylm"]).max()
+    # flux of given maps = design matrix product; conditional (fixed inclination) process
+    spc = SP(15, normalized=False, marginalize_over_inclination=False)
+    A = np.array(spc._flux.design_matrix(t, 65.0, 0.8, [0.2, 0.1]))
+    F = np.array(spc.flux(Y[:5], t, i=65.0, p=0.8, u=[0.2, 0.1]))
+    assert np.abs(F - Y[:5] @ A.T).max() < 1e-14 * max(1.0, np.abs(F).max())
