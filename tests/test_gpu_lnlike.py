@@ -218,3 +218,42 @@ def test_full_size_properties(eng, L, K, S, tspan, tau):
     ref = (-0.5 * (y * y).sum(dim=(1, 2)) - torch.log(torch.diagonal(Lv, dim1=1, dim2=2)).sum(1)
            - 0.5 * K * np.log(2 * np.pi)).cpu().numpy()
     assert np.abs(base / ref - 1).max() < 1e-9
+
+
+def test_empty_and_invalid_arguments(eng):
+    """Empty ensembles are a no-op; bad arguments come back as status codes, never as a
+    fault (the C ABI does not throw, include/starry_process_amd.h)."""
+    import ctypes
+    import torch
+    from starry_process_amd import _lib
+    from starry_process_amd.engine import make_stars
+
+    e = eng(5)
+    L = _lib.lib()
+    rta1 = e.f64(e.rTA1L([0.0, 0.0]))
+    tab, mv = e.kernel_table(rta1, 300)
+    st = synthetic_star(0, 50)
+    t, f = e.f64(st["t"][None, :]), e.f64(st["flux"][None, None, :])
+    stars = e.stars_to_device(make_stars(1, period=1.0, data_var=1e-6))
+    ws = e.workspace(1, 50, 1)
+    out = e.empty(1)
+    stream = e._stream()
+
+    def call(S, K, M, covpts=300, tabp=tab, norm_order=20):
+        return L.sp_lnlike_ensemble(e._h, S, K, M, e._p(t), e._p(f), None, e._p(stars), 0, covpts,
+                                    e._p(tabp) if tabp is not None else None, e._p(mv), e._p(rta1), 0, 1,
+                                    norm_order, ctypes.c_double(0.023), e._p(ws), e._p(out), None, stream)
+
+    assert call(0, 50, 1) == 0                     # empty ensemble
+    assert call(1, 0, 1) == -1                     # K < 1
+    assert call(1, 50, 0) == -1                    # M < 1
+    assert call(-1, 50, 1) == -1
+    assert call(1, 50, 1, norm_order=1000) == -1
+    assert call(1, 50, 1, tabp=None) == -1         # marginal branch without a kernel table
+    assert call(1, 50, 1, covpts=123) == -4        # table built for another lag grid: SP_ERR_STATE
+    assert call(1, 50, 1) == 0
+    torch.cuda.synchronize()
+    assert np.isfinite(out.cpu().numpy()[0])
+    assert L.sp_lnlike_workspace_bytes(e._h, 1, 0, 1) == -1
+    assert L.sp_cho_factor(e._h, None, 4, 4, 16, 1, None, stream) == -1
+    assert _lib.lib().sp_strerror(-4).decode().startswith("constants")
