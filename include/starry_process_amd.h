@@ -237,7 +237,7 @@ long sp_lnlike_workspace_bytes(sp_handle *h, int S, int K, int M);
  * NULL (then stars[s].data_var is used).  lnlike_dev [S]; status_dev [S] (may
  * be NULL).  workspace_dev must hold sp_lnlike_workspace_bytes(S,K,M) bytes.
  * Ragged ensembles: stars[s].nobs (see sp_star).  Limits: the row-sum kernel keeps
- * one star's phases and times in LDS, so K <= about 8,800 at covpts = 300
+ * one star's phases and times in LDS, so K <= about 8,700 at covpts = 300
  * (SP_ERR_INVALID beyond); S is bounded by the workspace only.  All launches go to
  * `stream`; nothing is synchronised.                                              */
 int sp_lnlike_ensemble(sp_handle *h, int S, int K, int M, const double *t_dev,
