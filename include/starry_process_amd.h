@@ -258,6 +258,15 @@ int sp_cholesky_lnlike_batched(sp_handle *h, int S, int K, int M,
                                void *workspace_dev, double *lnlike_dev,
                                uint32_t *status_dev, void *stream);
 
+/* ---- fp64 NT product on the matrix cores (the kernel behind a13 / a17, exposed) -------
+ *   C[b] = beta * C[b] + alpha * A[b] . B[b]^T,   beta in {0, 1}
+ * A: M x K (lda), B: N x K (ldb), C: M x N (ldc), row-major, `batch` matrices strideA /
+ * strideB / strideC doubles apart; lower_only != 0 (M == N): only the 64 x 64 tiles on
+ * or below the diagonal are touched.                                                 */
+int sp_gemm_nt(sp_handle *h, const double *A_dev, long lda, long strideA, const double *B_dev,
+               long ldb, long strideB, double *C_dev, long ldc, long strideC, int M, int N,
+               int K, double alpha, int beta, int lower_only, int batch, void *stream);
+
 /* ---- reverse-mode ops ------------------------------------------
  * The native gradient kernels of the reference, one entry point each:
  *   tensordotRzRevOp          ops/wigner/tensordotRz_rev.py:9-29, wigner.h:344-404

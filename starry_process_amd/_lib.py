@@ -77,6 +77,7 @@ PROTOTYPES = {
     "sp_tensordotRz_rev": (_I, [_V, _V, _V, _I, _V, _V, _V, _V]),
     "sp_special_tensordotRz_rev": (_I, [_V, _V, _V, _V, _I, _V, _V, _V, _V]),
     "sp_rTA1L_rev": (_I, [_V, _V, _V, _V]),
+    "sp_gemm_nt": (_I, [_V, _V, _L, _L, _V, _L, _L, _V, _L, _L, _I, _I, _I, _D, _I, _I, _I, _V]),
     "sp_gp_condition": (_I, [_V, _I, _I, _V, _V, _V, _V, _V, _V, _V]),
     "sp_alpha_beta": (_I, [_D, _I, c_double_p, c_double_p, c_double_p, c_double_p]),
     "sp_set_marginal_constants": (_I, [_V, _V, _V]),

@@ -37,7 +37,11 @@ def get_log_prob(
     marginalize_over_inclination=True,
     u=[0.0, 0.0],
     device=None,
+    upstream="reference",
 ):
+    """``upstream``: "reference" (the reference's moment algorithm on the host, ~25-75 ms per
+    call) or "device" (the same integrals by quadrature of rotations on the GPU, < 1 ms;
+    see upstream_device.py for how the two compare)."""
     t = np.asarray(t, dtype=np.float64).reshape(-1)
     K = len(t)
     free_flux = flux is None
@@ -57,7 +61,7 @@ def get_log_prob(
             ydeg=ydeg, r=r, a=a, b=b, c=c, n=n, normalized=normalized,
             marginalize_over_inclination=marginalize_over_inclination, covpts=K - 1,
             # the reference callable has no z > zmax guard (log_prob.py:53-91)
-            normalization_zmax=np.inf, device=device,
+            normalization_zmax=np.inf, device=device, upstream=upstream,
         )
         ll = float(sp.log_likelihood(t, fl, ferr ** 2, i=i, p=p, u=u, baseline_mean=m,
                                      baseline_var=10.0 ** v))
@@ -83,6 +87,7 @@ def get_log_prob_ensemble(
     marginalize_over_inclination=True,
     covpts=None,
     device=None,
+    upstream="reference",
 ):
     """log_prob(r, a, b, c, n) = sum over stars of per-star log-likelihoods (+ log_jac),
     each star with its own period / inclination / limb darkening / noise:
@@ -102,7 +107,7 @@ def get_log_prob_ensemble(
         sp = StarryProcess(ydeg=ydeg, r=float(r), a=float(a), b=float(b), c=float(c), n=float(n),
                            normalized=normalized,
                            marginalize_over_inclination=marginalize_over_inclination,
-                           device=device, **kw)
+                           device=device, upstream=upstream, **kw)
         lnl = ensemble.sharded_log_likelihood(sp, t, flux, ferr2, i=i, p=p, u=u,
                                               baseline_mean=baseline_mean,
                                               baseline_var=10.0 ** baseline_log_var)

@@ -872,6 +872,17 @@ int sp_lnlike_ensemble(sp_handle *h, int S, int K, int M, const double *t_dev,
   return SP_OK;
 }
 
+int sp_gemm_nt(sp_handle *h, const double *A_dev, long lda, long strideA, const double *B_dev,
+               long ldb, long strideB, double *C_dev, long ldc, long strideC, int M, int N,
+               int K, double alpha, int beta, int lower_only, int batch, void *stream) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || !A_dev || !B_dev || !C_dev || M < 0 || N < 0 || K < 0 || batch < 0 || lda < K ||
+      ldb < K || ldc < N || (beta != 0 && beta != 1))
+    return SP_ERR_INVALID;
+  return sp_launch_gemm_nt(A_dev, lda, strideA, B_dev, ldb, strideB, C_dev, ldc, strideC, M, N, K,
+                           alpha, beta, lower_only, batch, (hipStream_t)stream);
+}
+
 int sp_gp_condition(sp_handle *h, int K, int Ks, const double *Ktt_dev, const double *Kst_dev,
                     double *Kss_dev, const double *r_dev, double *mu_dev, int32_t *info_dev,
                     void *stream) {

@@ -302,6 +302,18 @@ class Engine(object):
         check(self._L.sp_cho_solve(self._h, self._p(Lb), K, K, K * K, self._p(bb), nrhs, B, self._stream()))
         return bb.reshape(shape)
 
+    def gemm_nt(self, A, B, C=None, alpha=1.0, lower_only=False):
+        """alpha A B^T (+ C): A [M, K], B [N, K] device tensors -> [M, N] (in place on C if given)."""
+        A, B = self.f64(A).contiguous(), self.f64(B).contiguous()
+        M, K = A.shape
+        N = B.shape[0]
+        assert B.shape[1] == K
+        beta = 0 if C is None else 1
+        out = self.empty(M, N) if C is None else C
+        check(self._L.sp_gemm_nt(self._h, self._p(A), K, 0, self._p(B), K, 0, self._p(out), N, 0, M, N,
+                                 K, float(alpha), beta, int(bool(lower_only)), 1, self._stream()))
+        return out
+
     def gp_condition(self, Ktt, Kst, Kss, r):
         """mu = K_st K_tt^-1 r and the posterior covariance K_ss - K_st K_tt^-1 K_st^T
         (device tensors; Kss is not modified).  Returns (mu, Kpost, info)."""

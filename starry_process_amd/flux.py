@@ -31,9 +31,15 @@ class FluxIntegral(object):
         self._nylm = (self._ydeg + 1) ** 2
         self._marginalize_over_inclination = bool(marginalize_over_inclination)
         self._covpts = int(covpts)
-        self._mean_ylm = np.ascontiguousarray(np.asarray(mean_ylm, dtype=np.float64).reshape(-1))
-        self._cov_ylm = np.ascontiguousarray(np.asarray(cov_ylm, dtype=np.float64))
         self._engine = get_engine(self._ydeg, self._udeg, kwargs.get("device"))
+        # the moments may already live on the device (upstream_device.py): no round trip
+        self._dev_moments = None
+        if hasattr(mean_ylm, "is_cuda") and hasattr(cov_ylm, "is_cuda"):
+            self._dev_moments = (mean_ylm.contiguous(), cov_ylm.contiguous())
+            self._mean_ylm = self._cov_ylm = None
+        else:
+            self._mean_ylm = np.ascontiguousarray(np.asarray(mean_ylm, dtype=np.float64).reshape(-1))
+            self._cov_ylm = np.ascontiguousarray(np.asarray(cov_ylm, dtype=np.float64))
         self._check_i = CheckBoundsOp(name="i", lower=0, upper=90.0 + 1e-4)
         self._check_p = CheckBoundsOp(name="p", lower=0, upper=np.inf)
         self._bind()
@@ -42,7 +48,10 @@ class FluxIntegral(object):
     def _bind(self):
         e = self._engine
         if getattr(e, "_moments_owner", None) is not self:
-            e.set_moments(self._mean_ylm, self._cov_ylm)
+            if self._dev_moments is not None:
+                e.set_moments_dev(*self._dev_moments)
+            else:
+                e.set_moments(self._mean_ylm, self._cov_ylm)
             e._moments_owner = self
 
     def _ingest(self, t, i, p, u):

@@ -91,20 +91,37 @@ class StarryProcess(object):
         self._marginalize_over_inclination = bool(marginalize_over_inclination)
         self._r, self._dr, self._a, self._b, self._c, self._n = r, dr, a, b, c, n
 
-        if mean_ylm is None or cov_ylm is None:
-            from .upstream import ylm_moments
-
-            mean_ylm, cov_ylm = ylm_moments(r=r, dr=dr, a=a, b=b, c=c, n=n, ydeg=self._ydeg,
-                                             **{k: v for k, v in kwargs.items() if k != "ydeg"})
-        self._mean_ylm = np.asarray(mean_ylm, dtype=np.float64).reshape(-1)
-        self._cov_ylm = np.asarray(cov_ylm, dtype=np.float64)
-        if self._mean_ylm.shape != (self._nylm,) or self._cov_ylm.shape != (self._nylm, self._nylm):
-            raise ValueError("mean_ylm / cov_ylm have the wrong shape for ydeg=%d" % self._ydeg)
-
         self._engine = get_engine(self._ydeg, self._udeg, kwargs.get("device"))
+        dev_moments = None
+        if mean_ylm is None or cov_ylm is None:
+            # upstream="reference" (default): the reference's algorithm on the host, comparable
+            # digit by digit on the same host; upstream="device": the same integrals by exact
+            # quadrature of rotations on the GPU (upstream_device.py), ~50x faster and free of
+            # the reference's rounding noise in the high degrees
+            how = kwargs.get("upstream", "reference")
+            ukw = {k: v for k, v in kwargs.items() if k not in ("ydeg", "upstream")}
+            if how == "device":
+                from .upstream_device import ylm_moments_device
+
+                dev_moments = ylm_moments_device(self._engine, r=r, dr=dr, a=a, b=b, c=c, n=n, **ukw)
+            elif how == "reference":
+                from .upstream import ylm_moments
+
+                mean_ylm, cov_ylm = ylm_moments(r=r, dr=dr, a=a, b=b, c=c, n=n, ydeg=self._ydeg, **ukw)
+            else:
+                raise ValueError("upstream must be 'reference' or 'device'")
+        self._dev_moments = dev_moments
+        if dev_moments is None:
+            self._host_moments = (np.asarray(mean_ylm, dtype=np.float64).reshape(-1),
+                                  np.asarray(cov_ylm, dtype=np.float64))
+            if self._host_moments[0].shape != (self._nylm,) or self._host_moments[1].shape != (self._nylm, self._nylm):
+                raise ValueError("mean_ylm / cov_ylm have the wrong shape for ydeg=%d" % self._ydeg)
+        else:
+            self._host_moments = None      # copied back only if somebody asks (properties below)
+
         self._flux = FluxIntegral(
-            self._mean_ylm,
-            self._cov_ylm,
+            dev_moments[0] if dev_moments is not None else self._host_moments[0],
+            dev_moments[1] if dev_moments is not None else self._host_moments[1],
             udeg=self._udeg,
             marginalize_over_inclination=self._marginalize_over_inclination,
             covpts=self._covpts,
@@ -112,6 +129,14 @@ class StarryProcess(object):
             device=kwargs.get("device"),
         )
         self._z = None
+
+    def _moments_np(self):
+        if self._host_moments is None:
+            self._host_moments = tuple(x.cpu().numpy() for x in self._dev_moments)
+        return self._host_moments
+
+    _mean_ylm = property(lambda self: self._moments_np()[0])
+    _cov_ylm = property(lambda self: self._moments_np()[1])
 
     # -- hyperparameters (read-only views, sp.py:286-367) -------------------------
     a = property(lambda self: self._a)

@@ -1,0 +1,103 @@
+"""
+Upstream of the hot path ON THE DEVICE ("next #1"): hyperparameters
+(r, dr, a, b, c, n) -> (mu_y, Sigma_y), evaluated as what the integrals of the
+reference ARE -- expectations of rotated spot expansions,
+
+    mu_y    = pi c n  E[ Ry(lambda) Rx(phi) s ]
+    Sigma_y = (pi c)^2 n ( E[ (Ry Rx s)(Ry Rx s)^T ] - E[.] E[.]^T ) + diag(eps),
+
+with cos(phi) ~ Beta(alpha, beta) (either sign of phi) and lambda uniform on the
+circle (latitude.py:199-212 / longitude.py:19-24: the polynomial Wigner matrices
+with Euler angles (pi/2, phi, -pi/2) and (0, lambda, 0) are Rx(phi) and Ry(lambda);
+the reference's own tests integrate exactly this numerically, tests/test_latitude.py).
+
+Instead of closed-form moment matrices, eigen-square-roots and polynomial Wigner
+tensors with entries up to 1e8 (integrals.py:109-156), the expectations are taken by
+EXACT quadrature of actual rotations:
+  * every surviving integrand is a polynomial of degree <= 2 ydeg in x = cos(phi)
+    (the terms odd in phi cancel between +phi and -phi), so ydeg + 2 Gauss-Jacobi
+    nodes for the weight x^(alpha-1) (1-x)^(beta-1) integrate it exactly;
+  * in lambda it is a trigonometric polynomial of degree <= 2 ydeg: 2 ydeg + 3
+    equispaced angles integrate it exactly.
+The (2 (ydeg + 2)) x (2 ydeg + 3) ~ 1100 rotations are applied by the path's own
+kernels (sp_Rx, sp_dotRx, sp_tensordotRz; Ry = Rx(-pi/2) Rz Rx(pi/2)), the second
+moment is one product on the matrix cores (sp_gemm_nt).  The result stays on the
+device for sp_set_ylm_moments_dev.
+
+Numerically this is well conditioned, which the reference's route is not: its Sigma_y
+carries rounding noise of 1e-3 max|Sigma_y| in the l >= 12 rows that differs from CPU to
+CPU.  Against the reference fixtures the two agree to 2e-12 in mu_y and,
+in Sigma_y, to 1e-12 for l <= 4, 1e-10 for l = 8, 1e-8 for l = 12, 1.3e-6 for l = 15 --
+the same per-degree profile as reference-vs-reference on two hosts.  ``upstream.py``
+(the reference's algorithm, bit-comparable on the same host) stays the default.
+"""
+import numpy as np
+from scipy.special import roots_jacobi
+
+from .defaults import defaults
+from .ops import CheckBoundsOp
+from .upstream import ab_to_alphabeta, size_moments
+
+__all__ = ["ylm_moments_device", "quadrature_nodes"]
+
+
+def quadrature_nodes(ydeg, alpha, beta):
+    """(phi [P], w_phi [P], lam [Q]): latitude angles with their weights (sum 1) and the
+    equispaced longitudes (weight 1 / Q each)."""
+    nq = ydeg + 2
+    t, w = roots_jacobi(nq, beta - 1.0, alpha - 1.0)   # weight (1 - t)^(beta-1) (1 + t)^(alpha-1)
+    x = 0.5 * (1.0 + t)                                 # cos(phi) in (0, 1)
+    w = w / w.sum()
+    phi = np.arccos(x)
+    nl = 2 * ydeg + 3
+    return (np.concatenate([phi, -phi]), 0.5 * np.concatenate([w, w]),
+            2.0 * np.pi * np.arange(nl) / nl)
+
+
+def ylm_moments_device(engine, r=defaults["r"], dr=defaults["dr"], a=defaults["a"],
+                       b=defaults["b"], c=defaults["c"], n=defaults["n"], **kwargs):
+    """(mu_y [N], Sigma_y [N, N]) as device tensors of ``engine``'s GPU."""
+    e = engine
+    ydeg, N = e.ydeg, e.N
+    n = CheckBoundsOp(name="n", lower=0, upper=np.inf)(n)
+    skw = {k: kwargs[k] for k in ("spts", "eps4", "smoothing", "sfac", "cutoff") if k in kwargs}
+    s1, eigS = size_moments(r, dr, ydeg, **skw)        # first moment [N], factor of the second [N, m]
+    alpha, beta = ab_to_alphabeta(a, b, **kwargs)
+    phi, wphi, lam = quadrature_nodes(ydeg, alpha, beta)
+    P, Q = phi.shape[0], lam.shape[0]
+    # vectors to rotate: the size first moment and the columns of the second-moment factor
+    # (one and the same vector when dr is None)
+    # (size.py:121-134 embeds the (ydeg + 1)-column factor in an N x N matrix of zeros)
+    cols = eigS.T[np.abs(eigS).sum(axis=0) > 0.0] if dr is not None else s1[None, :]
+    m = cols.shape[0]
+    first_is_col = dr is None
+    vecs = cols if first_is_col else np.vstack([s1[None, :], cols])      # [mv, N]
+    mv = vecs.shape[0]
+    # sqrt of the joint weights, with the contrast scale g = pi c sqrt(n) folded in:
+    #   Sigma_y = sum (g sqrt(W) row)^T (g sqrt(W) row) - m1 m1^T,   m1 = g mom1,   mu_y = sqrt(n) m1
+    g = np.pi * float(c) * np.sqrt(float(n))
+    sw = g * np.sqrt(wphi / Q)
+    # rows (k, j): g sqrt(W_k) vecs_j, rotated about x by phi_k   (row vectors: v^T R)
+    M0 = e.f64(np.ascontiguousarray(sw[:, None, None] * vecs[None, :, :]))   # [P, mv, N]
+    Rphi, _ = e.Rx(phi, deriv=False)
+    V = e.dotRx(M0, Rphi)                                                # [P, mv, N]
+    # rotation about y by lambda_q:  Rx(pi/2), Rz(lambda), Rx(-pi/2)
+    Rq, _ = e.Rx(np.array([0.5 * np.pi, -0.5 * np.pi]), deriv=False)
+    U = e.dotRx(V.reshape(P * mv, N), Rq[0])                             # [P mv, N]
+    U = U.unsqueeze(0).expand(Q, P * mv, N).reshape(Q * P * mv, N).contiguous()
+    th = e.f64(np.repeat(lam, P * mv))
+    U = e.tensordotRz(U, th)
+    A = e.dotRx(U, Rq[1]).reshape(Q, P, mv, N)                           # g sqrt(W) Ry Rx v
+    # first moment: sum_k W_k (.) = sum_k sqrt(W_k) (sqrt(W_k) row)
+    swd = e.f64(np.ascontiguousarray(np.tile(np.sqrt(wphi / Q), Q)))[None, :]   # [1, Q P]
+    A1 = A[:, :, 0, :].reshape(Q * P, N).t().contiguous()                # [N, Q P]
+    m1 = e.gemm_nt(A1, swd)                                              # [N, 1] = g mom1
+    # second moment: sum over rotations and factor columns of row^T row, minus m1 m1^T
+    A2 = (A if first_is_col else A[:, :, 1:, :]).reshape(Q * P * m, N).t().contiguous()
+    cov = e.gemm_nt(A2, A2)                                              # [N, N]
+    e.gemm_nt(m1, m1, C=cov, alpha=-1.0)
+    lamd = np.ones(N) * kwargs.get("epsy", defaults["epsy"])
+    lamd[15 ** 2:] = kwargs.get("epsy15", defaults["epsy15"])
+    cov.diagonal().add_(e.f64(lamd))
+    mean = m1[:, 0] * float(np.sqrt(float(n)))
+    return mean, cov
