@@ -868,3 +868,44 @@ class OracleProcess(object):
         if np.isnan(lnlike):
             lnlike = -np.inf
         return float(lnlike)
+
+
+# ---------------------------------------------------------------------------
+# Upstream moments by exact quadrature of rotations: CPU counterpart of
+# starry_process_amd/upstream_device.py (same nodes, same sequence of rotations, the C
+# restatements of Rx / dotRx / tensordotRz above).  It is an independent check of what
+# the reference's integrals (latitude.py:199-212, longitude.py:19-24, contrast.py:18-33)
+# ARE, and the checker of the device version.
+def ylm_moments_quadrature(size_first, size_factor_cols, alpha, beta, c, n, ydeg,
+                           epsy=1e-12, epsy15=1e-9, refine=1):
+    """size_first [N]; size_factor_cols [m, N] (columns of the size second-moment factor;
+    pass size_first[None, :] for a fixed spot radius).  Returns (mu_y, Sigma_y)."""
+    from scipy.special import roots_jacobi
+
+    N = (ydeg + 1) ** 2
+    nq = refine * (ydeg + 2)
+    t, w = roots_jacobi(nq, beta - 1.0, alpha - 1.0)
+    x = 0.5 * (1.0 + t)
+    w = w / w.sum()
+    phis = np.concatenate([np.arccos(x), -np.arccos(x)])
+    wphi = 0.5 * np.concatenate([w, w])
+    nl = refine * (2 * ydeg + 3)
+    lams = 2.0 * np.pi * np.arange(nl) / nl
+    Rp, Rm = Rx(ydeg, 0.5 * np.pi)[0], Rx(ydeg, -0.5 * np.pi)[0]
+    vecs = np.vstack([_f64(size_first)[None, :], _f64(size_factor_cols)])
+    mom1 = np.zeros(N)
+    mom2 = np.zeros((N, N))
+    for ph, wk in zip(phis, wphi):
+        V = dotRx(ydeg, vecs, Rx(ydeg, ph)[0])
+        U = dotRx(ydeg, V, Rp)
+        for j in range(vecs.shape[0]):
+            A = dotRx(ydeg, tensordotRz(ydeg, np.repeat(U[j:j + 1], nl, axis=0), lams), Rm)
+            if j == 0:
+                mom1 += (wk / nl) * A.sum(axis=0)
+            else:
+                mom2 += (wk / nl) * (A.T @ A)
+    mean = np.pi * c * n * mom1
+    cov = (np.pi * c) ** 2 * n * (mom2 - np.outer(mom1, mom1))
+    lam = np.ones(N) * epsy
+    lam[15 ** 2:] = epsy15
+    return mean, cov + np.diag(lam)

@@ -98,3 +98,23 @@ def test_likelihood_and_calibrate_with_device_upstream():
     assert abs(f(*g["default_hyper"]) / float(g["default"]) - 1) < 1e-4
     with pytest.raises(ValueError):
         StarryProcess(ydeg=15, upstream="nope")
+
+
+@pytest.mark.parametrize("L,name", [(5, "default"), (15, "default"), (15, "hilat"), (15, "spread")])
+def test_device_equals_cpu_quadrature(L, name):
+    """Same nodes, same rotations, on the CPU (oracle.ylm_moments_quadrature): the device
+    result must agree to rounding -- this pins the device kernels free of the reference's noise."""
+    from oracle import sp_oracle as orc
+    from starry_process_amd import upstream
+
+    g = golden("moments_L%d" % L)
+    hp = g[name + "_hyper"]
+    r, dr, a, b, c, n = hp
+    dr = None if np.isnan(dr) else dr
+    mu, S = _moments(L, hp)
+    s1, eigS = upstream.size_moments(r, dr, L)
+    cols = eigS.T[np.abs(eigS).sum(axis=0) > 0.0] if dr is not None else s1[None, :]
+    alpha, beta = upstream.ab_to_alphabeta(a, b)
+    mu_o, S_o = orc.ylm_moments_quadrature(s1, cols, alpha, beta, c, n, L)
+    assert np.abs(mu - mu_o).max() < 1e-13 * np.abs(mu_o).max()
+    assert np.abs(S - S_o).max() < 1e-12 * np.abs(S_o).max()

@@ -96,3 +96,23 @@ def test_bounds():
         upstream.ylm_moments(a=1.5, ydeg=5)
     with pytest.raises(ValueError):
         upstream.ylm_moments(n=-1.0, ydeg=5)
+
+
+def test_moments_are_expectations_of_rotations():
+    """The integrals of the reference, evaluated by exact quadrature of actual rotations on the
+    CPU (oracle.ylm_moments_quadrature, the checker of upstream_device.py): identical to the
+    reference's closed forms where those are well conditioned (ydeg = 5: 1e-12), and within
+    the reference's own rounding noise in the top degrees at ydeg = 15."""
+    from oracle import sp_oracle as orc
+
+    for L, tol_mu, tol_lo, tol_all in ((5, 1e-12, 1e-11, 1e-11), (15, 1e-9, 1e-7, 5e-2)):
+        g = golden("moments_L%d" % L)
+        hp = _hyper(g["default_hyper"])
+        s1, _ = upstream.size_moments(hp["r"], None, L)
+        alpha, beta = upstream.ab_to_alphabeta(hp["a"], hp["b"])
+        mu, S = orc.ylm_moments_quadrature(s1, s1[None, :], alpha, beta, hp["c"], hp["n"], L)
+        mr, Sr = g["default_mean_ylm"], g["default_cov_ylm"]
+        scale = np.abs(Sr).max()
+        assert np.abs(mu - mr).max() < tol_mu * np.abs(mr).max()
+        assert np.abs(S - Sr)[:25].max() < tol_lo * scale
+        assert np.abs(S - Sr).max() < tol_all * scale
