@@ -174,6 +174,26 @@ def main():
         torch.cuda.synchronize()
         pcie_rate = S * nrep / (time.perf_counter() - t1)
 
+    # the hyperparameter-level step (mu_y, Sigma_y from r, a, b, c, n) is outside the timed
+    # region by definition of the metric; its cost is reported beside it
+    upstream_ms = None
+    if world == 1 and rank == 0:
+        from starry_process_amd.upstream_device import ylm_moments_device
+        from starry_process_amd import upstream as host_upstream
+
+        ylm_moments_device(e, r=20.0, a=0.40, b=0.27, c=0.1, n=10.0)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for k in range(10):
+            ylm_moments_device(e, r=20.0 + 0.01 * k, a=0.40, b=0.27, c=0.1, n=10.0)
+        torch.cuda.synchronize()
+        dev_ms = 1e2 * (time.perf_counter() - t2)
+        host_upstream.ylm_moments(r=20.0, a=0.40, b=0.27, c=0.1, n=10.0, ydeg=YDEG)
+        t2 = time.perf_counter()
+        for k in range(2):
+            host_upstream.ylm_moments(r=20.0 + 0.01 * k, a=0.40, b=0.27, c=0.1, n=10.0, ydeg=YDEG)
+        upstream_ms = {"device_quadrature": dev_ms, "host_reference_algorithm": 5e2 * (time.perf_counter() - t2)}
+
     if rank == 0:
         evals = world * S * args.steps
         achieved = (kern_flops / (kern_ms * 1e-3)) / 1e12 if kern_ms > 0 else 0.0
@@ -205,6 +225,7 @@ def main():
             "parity_ok": ok,
             "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
             "pcie_inclusive_evals_per_s": pcie_rate,
+            "upstream_ms_per_sample": upstream_ms,
             "roofline": {
                 "kernel": "gemm_nt_kernel (Cholesky trailing update, v_mfma_f64_16x16x4_f64)",
                 "bound": "mfma",
