@@ -95,8 +95,15 @@ def main():
         if rank == 0:
             print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # SP_BENCH_FORCE_DIST=1: take the multi-GPU code path (RCCL communicator, all-gather,
+    # barriers, max over ranks) with however many ranks there are, even one -- lets a
+    # single-GPU box exercise it
+    use_dist = world > 1 or os.environ.get("SP_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from starry_process_amd.engine import get_engine, make_stars
@@ -117,27 +124,27 @@ def main():
     ws = e.workspace(S, K, 1)
     out = e.empty(S)
     status = torch.zeros(S, dtype=torch.int32, device=e.device)
-    gathered = e.empty(world * S) if world > 1 else None
+    gathered = e.empty(world * S) if use_dist else None
 
     def step():
         e.set_moments_dev(mu_d, Sig_d)
         tab, mv = e.kernel_table(rta1_d, COVPTS)
         e.lnlike_ensemble(t_d, f_d, stars_d, covpts=COVPTS, tab=tab, meanvar=mv,
                           normalized=True, out=out, status=status, workspace=ws)
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, out)
             return gathered.sum()
         return out.sum()
 
     e.set_moments(mu, Sig)  # first call allocates / uploads the lag grid
-    if world > 1:
+    if use_dist:
         # communicator set-up (lazy in RCCL) must not land in the timed region even with --warmup 0
         dist.all_gather_into_tensor(gathered, out)
     for _ in range(args.warmup):
         step()
     nsyrk = (K + 63) // 64  # upper bound on timed launches per step
     e.profile_begin(args.steps * nsyrk)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -145,11 +152,11 @@ def main():
         total = step()
     host_enqueue = time.perf_counter() - t0
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     launches, kern_ms, kern_flops = e.profile_end()
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=e.device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -247,7 +254,7 @@ def main():
             if ok_ref.any():
                 line["max_rel_err_vs_oracle"] = float(np.max(np.abs(lnl[:n][ok_ref] / ref_vals[:n][ok_ref] - 1)))
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
