@@ -221,6 +221,32 @@ int sp_cho_solve(sp_handle *h, const double *L_dev, int K, long ldl,
                  long strideL, double *b_dev, int nrhs, int batch,
                  void *stream);
 
+/* One triangular sweep: trans = 0 solves L x = b (the reference's
+ * Solve(A_structure="lower_triangular")(L, b), math.py:98), trans = 1 solves
+ * L^T x = b (Solve("upper_triangular")(L.T, .), math.py:99).  Only the lower
+ * triangle of L is read.  b_dev as in sp_cho_solve, overwritten.             */
+int sp_tri_solve(sp_handle *h, const double *L_dev, int K, long ldl,
+                 long strideL, double *b_dev, int nrhs, int batch, int trans,
+                 void *stream);
+/* Reverse mode of one triangular solve c = A^-1 b (Solve.L_op, math.py:40-72),
+ * A = L (trans = 0) or A = L^T (trans = 1):
+ *   b_bar = A^-T c_bar,   A_bar = -tril(b_bar c^T)  (triu for trans = 1).
+ * c_dev, cbar_dev, bbar_dev: [batch, K, nrhs]; Abar_dev: [batch, K, K].        */
+int sp_solve_rev(sp_handle *h, const double *L_dev, int K, long ldl,
+                 long strideL, const double *c_dev, const double *cbar_dev,
+                 int nrhs, int batch, int trans, double *Abar_dev,
+                 double *bbar_dev, void *stream);
+/* Reverse mode of the lower Cholesky factorisation (L_op of the Theano/Aesara
+ * slinalg.Cholesky the reference's math.py:75 subclasses; Murray 2016):
+ *   Phi = tril(L^T L_bar), diagonal halved;  S = L^-T Phi L^-1;
+ *   C_bar = tril(S + S^T) - diag(S).
+ * L_dev must carry zeros above the diagonal (as sp_cho_factor leaves it);
+ * Lbar_dev, Cbar_dev: [batch, K, K] contiguous.  A NaN factor (not positive
+ * definite, on_error="nan") gives an all-NaN C_bar.                           */
+int sp_cholesky_rev(sp_handle *h, const double *L_dev, int K, long ldl,
+                    long strideL, const double *Lbar_dev, int batch,
+                    double *Cbar_dev, void *stream);
+
 /* ---- a16-a19 + fused driver: log-likelihood of an ensemble ---------------- */
 /* Size in bytes of the device workspace sp_lnlike_ensemble needs.            */
 long sp_lnlike_workspace_bytes(sp_handle *h, int S, int K, int M);

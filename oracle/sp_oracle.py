@@ -746,6 +746,33 @@ def cho_solve(L, b):
     return _solve_tri(L.T, _solve_tri(L, b, True), False)
 
 
+# reverse mode of the two
+def solve_L_op(A, b, c, c_bar, lower):
+    """(A_bar, b_bar) of c = A^-1 b for triangular A (Solve.L_op, math.py:40-72:
+    b_bar = A^-T c_bar, A_bar = -tri(b_bar c^T))."""
+    b_bar = _solve_tri(A.T, c_bar, not lower)
+    A_bar = -np.outer(b_bar, c) if c.ndim == 1 else -b_bar.dot(c.T)
+    return (np.tril(A_bar) if lower else np.triu(A_bar)), b_bar
+
+
+def cholesky_L_op(L, L_bar):
+    """C_bar of L = cholesky(C), lower.  The reference inherits this from the Theano /
+    Aesara ``slinalg.Cholesky`` it subclasses (math.py:75; theano-pymc 1.1.2 / aesara 2.x,
+    not vendored, absent here); restated from its published formula (I. Murray,
+    "Differentiation of the Cholesky decomposition", arXiv:1602.07527, eq. for the
+    blocked-free reverse mode):
+        Phi = tril(L^T L_bar) with the diagonal halved,  S = L^-T Phi L^-1,
+        C_bar = tril(S + S^T) - diag(S);  NaN when the factor is NaN (on_error="nan").
+    Pinned by finite differences in tests/test_linalg_rev.py."""
+    if np.any(np.isnan(L)):
+        return np.full(L.shape, np.nan)
+    P = np.tril(L.T.dot(L_bar))
+    P[np.diag_indices_from(P)] *= 0.5
+    X = scipy.linalg.solve_triangular(L.T, P.T, lower=False)      # L^-T Phi^T
+    S = scipy.linalg.solve_triangular(L.T, X.T, lower=False)      # L^-T Phi L^-1
+    return np.tril(S + S.T) - np.diag(np.diag(S))
+
+
 # ---------------------------------------------------------------------------
 # a16, a19, a20: the whole evaluation
 # ---------------------------------------------------------------------------

@@ -787,6 +787,67 @@ int sp_cho_solve(sp_handle *h, const double *L_dev, int K, long ldl, long stride
                              (hipStream_t)stream);
 }
 
+int sp_tri_solve(sp_handle *h, const double *L_dev, int K, long ldl, long strideL, double *b_dev,
+                 int nrhs, int batch, int trans, void *stream) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || !L_dev || !b_dev || K < 1 || ldl < K || nrhs < 0 || batch < 0) return SP_ERR_INVALID;
+  if (nrhs == 0 || batch == 0) return SP_OK;
+  if (batch > 65535) return SP_ERR_INVALID;
+  return sp_launch_tri_solve(L_dev, K, ldl, strideL, b_dev, (long)K * nrhs, nrhs, 1, nrhs, batch,
+                             trans ? 2 : 1, (hipStream_t)stream);
+}
+
+int sp_solve_rev(sp_handle *h, const double *L_dev, int K, long ldl, long strideL,
+                 const double *c_dev, const double *cbar_dev, int nrhs, int batch, int trans,
+                 double *Abar_dev, double *bbar_dev, void *stream) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || !L_dev || !c_dev || !cbar_dev || !Abar_dev || !bbar_dev || K < 1 || ldl < K ||
+      nrhs < 1 || batch < 0 || batch > 65535)
+    return SP_ERR_INVALID;
+  if (batch == 0) return SP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const long sb = (long)K * nrhs;
+  int rc;
+  // b_bar = A^-T c_bar: the transposed system (math.py:55-63)
+  SP_HIP(hipMemcpyAsync(bbar_dev, cbar_dev, sizeof(double) * (size_t)batch * sb,
+                        hipMemcpyDeviceToDevice, st));
+  if ((rc = sp_launch_tri_solve(L_dev, K, ldl, strideL, bbar_dev, sb, nrhs, 1, nrhs, batch,
+                                trans ? 1 : 2, st)))
+    return rc;
+  // A_bar = -b_bar c^T, restricted to the triangle A lives on (math.py:65-69)
+  if ((rc = sp_launch_gemm_nt(bbar_dev, nrhs, sb, c_dev, nrhs, sb, Abar_dev, K, (long)K * K, K, K,
+                              nrhs, -1.0, 0, 0, batch, st)))
+    return rc;
+  return sp_launch_tri_mask(Abar_dev, K, batch, trans ? 1 : 0, 1.0, st);
+}
+
+int sp_cholesky_rev(sp_handle *h, const double *L_dev, int K, long ldl, long strideL,
+                    const double *Lbar_dev, int batch, double *Cbar_dev, void *stream) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || !L_dev || !Lbar_dev || !Cbar_dev || K < 1 || ldl < K || batch < 0 || batch > 65535)
+    return SP_ERR_INVALID;
+  if (batch == 0) return SP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const long kk = (long)K * K;
+  const size_t mb = align_up(sizeof(double) * (size_t)batch * kk);
+  void *ws = nullptr;
+  int rc = ensure_big(h, 3 * mb, &ws);
+  if (rc) return rc;
+  double *Lt = at<double>(ws, 0), *Lbt = at<double>(ws, mb), *P = at<double>(ws, 2 * mb);
+  // P = L^T L_bar
+  if ((rc = sp_launch_transpose(L_dev, ldl, strideL, Lt, K, batch, st))) return rc;
+  if ((rc = sp_launch_transpose(Lbar_dev, K, kk, Lbt, K, batch, st))) return rc;
+  if ((rc = sp_launch_gemm_nt(Lt, K, kk, Lbt, K, kk, P, K, kk, K, K, K, 1.0, 0, 0, batch, st)))
+    return rc;
+  // Phi = tril(P) with the diagonal halved
+  if ((rc = sp_launch_tri_mask(P, K, batch, 0, 0.5, st))) return rc;
+  // S = L^-T Phi L^-1: solve L^T X = Phi^T with P read as its own transpose (X^T = Phi L^-1
+  // lands in P row-major), then L^T S = X^T
+  if ((rc = sp_launch_tri_solve(L_dev, K, ldl, strideL, P, kk, 1, K, K, batch, 2, st))) return rc;
+  if ((rc = sp_launch_tri_solve(L_dev, K, ldl, strideL, P, kk, K, 1, K, batch, 2, st))) return rc;
+  return sp_launch_chol_rev_finish(P, L_dev, ldl, strideL, Cbar_dev, K, batch, st);
+}
+
 long sp_lnlike_workspace_bytes(sp_handle *h, int S, int K, int M) {
   if (!h || S < 0 || K < 1 || M < 1) return SP_ERR_INVALID;
   return (long)make_layout(h, S, K, M, true).total;

@@ -212,21 +212,25 @@ __global__ __launch_bounds__(256) void pad_out_kernel(const double *__restrict__
 // per workgroup; b is [K, nrhs] row-major per matrix.  Blocked substitution:
 // the 64x64 diagonal blocks are solved by one wavefront with lane shuffles, the
 // off-diagonal updates are one row (forward) / one column (backward) per thread.
+//
+// mode: 0 both sweeps, 1 forward only (L y = b), 2 backward only (L^T x = b) -- the two
+// Solve ops of math.py:97-100 taken one at a time, which their reverse mode needs
+// (math.py:40-72).  Element (i, rhs) of a right-hand side lives at B[i * rs + rhs * cs].
 __global__ __launch_bounds__(256) void cho_solve_kernel(
     const double *__restrict__ Lall, int K, long ldl, long strideL,
-    double *__restrict__ Ball, int nrhs) {
+    double *__restrict__ Ball, long strideB, long rs, long cs, int mode) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int Kr = ((K + 63) / 64) * 64;
   double *x = lds;        // Kr
   double *sL = lds + Kr;  // 64 * DLD
   const double *L = Lall + (size_t)blockIdx.y * strideL;
-  double *B = Ball + (size_t)blockIdx.y * K * nrhs + blockIdx.x;
+  double *B = Ball + (size_t)blockIdx.y * strideB + (size_t)blockIdx.x * cs;
   const int tid = threadIdx.x, lane = tid & 63;
-  for (int i = tid; i < Kr; i += 256) x[i] = i < K ? B[(size_t)i * nrhs] : 0.0;
+  for (int i = tid; i < Kr; i += 256) x[i] = i < K ? B[(size_t)i * rs] : 0.0;
   const int nb = Kr / 64;
   __syncthreads();
   // forward: L y = b
-  for (int blk = 0; blk < nb; ++blk) {
+  for (int blk = 0; blk < nb && mode != 2; ++blk) {
     const int c0 = blk * 64, n = K - c0 < 64 ? K - c0 : 64;
     for (int e = tid; e < 64 * 64; e += 256) {
       const int r = e >> 6, c = e & 63;
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(256) void cho_solve_kernel(
     __syncthreads();
   }
   // backward: L^T x = y
-  for (int blk = nb - 1; blk >= 0; --blk) {
+  for (int blk = nb - 1; blk >= 0 && mode != 1; --blk) {
     const int c0 = blk * 64, n = K - c0 < 64 ? K - c0 : 64;
     for (int e = tid; e < 64 * 64; e += 256) {
       const int r = e >> 6, c = e & 63;
@@ -282,7 +286,56 @@ __global__ __launch_bounds__(256) void cho_solve_kernel(
     }
     __syncthreads();
   }
-  for (int i = tid; i < K; i += 256) B[(size_t)i * nrhs] = x[i];
+  for (int i = tid; i < K; i += 256) B[(size_t)i * rs] = x[i];
+}
+
+// out = in^T per matrix (K x K, row-major; out has leading dimension K), 64 x 64 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_kernel(const double *__restrict__ in, long ldi,
+                                                        long stridei, double *__restrict__ out,
+                                                        int K) {
+  __shared__ double tile[64][65];
+  const double *A = in + (size_t)blockIdx.z * stridei;
+  double *O = out + (size_t)blockIdx.z * K * K;
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  const int c = threadIdx.x & 63, r4 = threadIdx.x >> 6;
+  for (int r = r4; r < 64; r += 4)
+    tile[r][c] = (i0 + r < K && j0 + c < K) ? A[(size_t)(i0 + r) * ldi + j0 + c] : 0.0;
+  __syncthreads();
+  for (int r = r4; r < 64; r += 4)
+    if (j0 + r < K && i0 + c < K) O[(size_t)(j0 + r) * K + i0 + c] = tile[c][r];
+}
+
+// keep one triangle of every K x K matrix, scale its diagonal:  A <- tri(A), diag *= dscale
+// (tril / triu of Solve.L_op, math.py:66-69; tril_and_halve_diagonal of Cholesky.L_op)
+__global__ __launch_bounds__(256) void tri_mask_kernel(double *__restrict__ A, int K, int upper,
+                                                       double dscale) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)K * K) return;
+  const int i = e / K, j = e % K;
+  double *p = A + (size_t)blockIdx.y * K * K + e;
+  if (i == j)
+    *p *= dscale;
+  else if ((j > i) != (upper != 0))
+    *p = 0.0;
+}
+
+// C_bar = tril(S + S^T) - diag(S); all NaN when the factor itself is NaN (on_error = "nan")
+__global__ __launch_bounds__(256) void chol_rev_finish_kernel(const double *__restrict__ S,
+                                                              const double *__restrict__ L, long ldl,
+                                                              long strideL, double *__restrict__ out,
+                                                              int K) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)K * K) return;
+  const int i = e / K, j = e % K;
+  const double *Sb = S + (size_t)blockIdx.y * K * K;
+  double v = 0.0;
+  if (i > j)
+    v = Sb[(size_t)i * K + j] + Sb[(size_t)j * K + i];
+  else if (i == j)
+    v = Sb[e];
+  const double l00 = L[(size_t)blockIdx.y * strideL];
+  if (l00 != l00) v = __builtin_nan("");
+  out[(size_t)blockIdx.y * K * K + e] = v;
 }
 
 // Sustained fp64 MFMA rate of the device (debug phase 5): every wavefront issues
@@ -570,15 +623,47 @@ int sp_launch_pad_out(const double *sys, int Kp, double *A, int K, long lda,
   return SP_OK;
 }
 
-int sp_launch_cho_solve(const double *L, int K, long ldl, long strideL, double *B,
-                        int nrhs, int batch, hipStream_t st) {
+int sp_launch_tri_solve(const double *L, int K, long ldl, long strideL, double *B,
+                        long strideB, long rs, long cs, int nrhs, int batch, int mode,
+                        hipStream_t st) {
   const int Kr = ((K + 63) / 64) * 64;
   const size_t lds = sizeof(double) * ((size_t)Kr + 64 * DLD);
   if (lds > 150 * 1024) return SP_ERR_INVALID;
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cho_solve_kernel),
                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
   hipLaunchKernelGGL(cho_solve_kernel, dim3(nrhs, batch), dim3(256), lds, st, L, K,
-                     ldl, strideL, B, nrhs);
+                     ldl, strideL, B, strideB, rs, cs, mode);
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}
+
+int sp_launch_cho_solve(const double *L, int K, long ldl, long strideL, double *B,
+                        int nrhs, int batch, hipStream_t st) {
+  return sp_launch_tri_solve(L, K, ldl, strideL, B, (long)K * nrhs, nrhs, 1, nrhs, batch, 0, st);
+}
+
+int sp_launch_transpose(const double *in, long ldi, long stridei, double *out, int K, int batch,
+                        hipStream_t st) {
+  const int nt = (K + 63) / 64;
+  hipLaunchKernelGGL(transpose_kernel, dim3(nt, nt, batch), dim3(256), 0, st, in, ldi, stridei, out,
+                     K);
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}
+
+int sp_launch_tri_mask(double *A, int K, int batch, int upper, double dscale, hipStream_t st) {
+  const long n = (long)K * K;
+  hipLaunchKernelGGL(tri_mask_kernel, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, st, A,
+                     K, upper, dscale);
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}
+
+int sp_launch_chol_rev_finish(const double *S, const double *L, long ldl, long strideL, double *out,
+                              int K, int batch, hipStream_t st) {
+  const long n = (long)K * K;
+  hipLaunchKernelGGL(chol_rev_finish_kernel, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0,
+                     st, S, L, ldl, strideL, out, K);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }

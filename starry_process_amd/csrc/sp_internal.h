@@ -114,6 +114,13 @@ int sp_launch_polar_moments(sp_handle *h, const double *mu_src, const double *co
 //   A: Mrows x Kd (lda), B: Nrows x Kd (ldb), C: Mrows x Nrows (ldc)
 //   beta is 0 or 1;  lower_only: only tiles with tile_i >= tile_j are touched
 //   Mrows, Nrows multiples of 64; Kd multiple of 4.
+int sp_launch_tri_solve(const double *L, int K, long ldl, long strideL, double *B, long strideB,
+                        long rs, long cs, int nrhs, int batch, int mode, hipStream_t st);
+int sp_launch_transpose(const double *in, long ldi, long stridei, double *out, int K, int batch,
+                        hipStream_t st);
+int sp_launch_tri_mask(double *A, int K, int batch, int upper, double dscale, hipStream_t st);
+int sp_launch_chol_rev_finish(const double *S, const double *L, long ldl, long strideL, double *out,
+                              int K, int batch, hipStream_t st);
 int sp_launch_gemm_nt(const double *A, long lda, long strideA, const double *B,
                       long ldb, long strideB, double *C, long ldc, long strideC,
                       int Mrows, int Nrows, int Kd, double alpha, int beta,

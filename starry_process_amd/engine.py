@@ -302,6 +302,45 @@ class Engine(object):
         check(self._L.sp_cho_solve(self._h, self._p(Lb), K, K, K * K, self._p(bb), nrhs, B, self._stream()))
         return bb.reshape(shape)
 
+    def tri_solve(self, L, b, trans=False):
+        """L^-1 b (trans False) or L^-T b (trans True); shapes as in cho_solve."""
+        L = self.f64(L)
+        b = self.f64(b).clone()
+        Lb = L if L.dim() == 3 else L.unsqueeze(0)
+        B, K, _ = Lb.shape
+        shape = b.shape
+        bb = b.reshape(B, K, -1).contiguous()
+        check(self._L.sp_tri_solve(self._h, self._p(Lb), K, K, K * K, self._p(bb), bb.shape[2], B,
+                                   int(bool(trans)), self._stream()))
+        return bb.reshape(shape)
+
+    def solve_rev(self, L, c, c_bar, trans=False):
+        """Reverse mode of c = A^-1 b, A = L or L^T: returns (A_bar, b_bar)."""
+        L = self.f64(L)
+        Lb = (L if L.dim() == 3 else L.unsqueeze(0)).contiguous()
+        B, K, _ = Lb.shape
+        c = self.f64(c)
+        shape = c.shape
+        cb = c.reshape(B, K, -1).contiguous()
+        gb = self.f64(c_bar).reshape(B, K, -1).contiguous()
+        nrhs = cb.shape[2]
+        Abar = self.empty(B, K, K)
+        bbar = self.empty(B, K, nrhs)
+        check(self._L.sp_solve_rev(self._h, self._p(Lb), K, K, K * K, self._p(cb), self._p(gb), nrhs,
+                                   B, int(bool(trans)), self._p(Abar), self._p(bbar), self._stream()))
+        return (Abar if L.dim() == 3 else Abar[0]), bbar.reshape(shape)
+
+    def cholesky_rev(self, L, L_bar):
+        """Reverse mode of L = cholesky(C): C_bar from L and L_bar ([K, K] or [B, K, K])."""
+        L = self.f64(L)
+        Lb = (L if L.dim() == 3 else L.unsqueeze(0)).contiguous()
+        B, K, _ = Lb.shape
+        gb = self.f64(L_bar).reshape(B, K, K).contiguous()
+        out = self.empty(B, K, K)
+        check(self._L.sp_cholesky_rev(self._h, self._p(Lb), K, K, K * K, self._p(gb), B, self._p(out),
+                                      self._stream()))
+        return out if L.dim() == 3 else out[0]
+
     def gemm_nt(self, A, B, C=None, alpha=1.0, lower_only=False):
         """alpha A B^T (+ C): A [M, K], B [N, K] device tensors -> [M, N] (in place on C if given)."""
         A, B = self.f64(A).contiguous(), self.f64(B).contiguous()

@@ -292,6 +292,33 @@ def gen_rev(L, U=2):
     save("rev_L%d.npz" % L, **out)
 
 
+def gen_linalg_rev():
+    """Solve.L_op of the reference (math.py:40-72) executed eagerly: lower and upper systems,
+    vector and matrix right-hand sides.  The Cholesky L_op is inherited
+    from Theano / Aesara, absent here: the oracle restates it and is pinned by finite
+    differences instead (tests/test_linalg_rev.py)."""
+    rng = np.random.RandomState(77)
+    K, M = 37, 3
+    B = rng.randn(K, K)
+    C = B.dot(B.T) + K * np.eye(K)
+    L = A(ref.math.cho_factor(C))
+    out = dict(C=C, L=L)
+    for tag, struct, lower, Amat in (("lower", "lower_triangular", True, L),
+                                     ("upper", "upper_triangular", False, L.T.copy())):
+        for rhs, shape in (("vec", (K,)), ("mat", (K, M))):
+            op = ref.math.Solve(A_structure=struct, lower=lower)
+            b = rng.randn(*shape)
+            c_bar = rng.randn(*shape)
+            c = A(op(Amat, b))
+            A_bar, b_bar = op.L_op([ref.compat.tt.as_tensor_variable(Amat), ref.compat.tt.as_tensor_variable(b)],
+                                   [ref.compat.tt.as_tensor_variable(c)],
+                                   [ref.compat.tt.as_tensor_variable(c_bar)])
+            key = "%s_%s_" % (tag, rhs)
+            out.update({key + "b": b, key + "c": c, key + "c_bar": c_bar,
+                        key + "A_bar": A(A_bar), key + "b_bar": A(b_bar)})
+    save("linalg_rev.npz", **out)
+
+
 def gen_predict():
     """StarryProcess.predict for small cases (unnormalised processes only, sp.py:855-858)."""
     mom = np.load(os.path.join(OUT, "moments_L15.npz"))
@@ -418,7 +445,7 @@ def gen_lnlike():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "consts", "moments", "cov", "norm", "lnlike", "upstream", "calibrate", "predict", "rev"]
+    which = sys.argv[1:] or ["ops", "consts", "moments", "cov", "norm", "lnlike", "upstream", "calibrate", "predict", "rev", "linalg_rev"]
     for L in (5, 15, 20):
         if "ops" in which:
             gen_ops(L)
@@ -441,3 +468,5 @@ if __name__ == "__main__":
         gen_calibrate()
     if "predict" in which:
         gen_predict()
+    if "linalg_rev" in which:
+        gen_linalg_rev()
