@@ -262,10 +262,9 @@ long sp_lnlike_workspace_bytes(sp_handle *h, int S, int K, int M);
  * t_dev [S,K]; flux_dev [S,M,K]; diag_dev [S,K] per-cadence data variances or
  * NULL (then stars[s].data_var is used).  lnlike_dev [S]; status_dev [S] (may
  * be NULL).  workspace_dev must hold sp_lnlike_workspace_bytes(S,K,M) bytes.
- * Ragged ensembles: stars[s].nobs (see sp_star).  Limits: the row-sum kernel keeps
- * one star's phases and times in LDS, so K <= about 8,700 at covpts = 300
- * (SP_ERR_INVALID beyond); S is bounded by the workspace only.  All launches go to
- * `stream`; nothing is synchronised.                                              */
+ * Ragged ensembles: stars[s].nobs (see sp_star).  Limits: S and K are bounded by
+ * the workspace only (checked against the oracle up to K = 20,000,
+ * tools/big_k.py).  All launches go to `stream`; nothing is synchronised.       */
 int sp_lnlike_ensemble(sp_handle *h, int S, int K, int M, const double *t_dev,
                        const double *flux_dev, const double *diag_dev,
                        const sp_star *stars_dev, int conditional, int covpts,

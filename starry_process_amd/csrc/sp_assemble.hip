@@ -113,47 +113,51 @@ __device__ __forceinline__ void load_tables(const double *__restrict__ tab, int 
 }
 
 // Row sums of the raw covariance.  grid (ceil(K/64), S), 256 threads: thread
-// (r = tid & 63, q = tid >> 6) sums columns j = q, q+4, ... of row r.
+// (r = tid & 63, q = tid >> 6) sums columns j = q, q+4, ... of row r.  The
+// columns' phases (and times) pass through LDS in chunks of `chunk` (= K when
+// one star's fit, which is every configuration of BASELINE.json).
 template <bool FROM_MATRIX>
 __global__ __launch_bounds__(256) void rowsum_kernel(
-    int K, const double *__restrict__ theta, const double *__restrict__ t,
+    int K, int chunk, const double *__restrict__ theta, const double *__restrict__ t,
     const sp_star *__restrict__ stars, int covpts, const double *__restrict__ tab,
     const double *__restrict__ meanvar, const double *__restrict__ xp,
-    int temporal, const double *__restrict__ raw, double *__restrict__ rowsum) {
+    int temporal, const double *raw, double *__restrict__ rowsum) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int s = blockIdx.y, np = covpts + 4;
   const sp_star st = stars[s];
   double *s_tab = lds;            // 5 * np (unused when FROM_MATRIX)
-  double *s_th = lds + (FROM_MATRIX ? 0 : 5 * np);  // K
-  double *s_t = s_th + K;         // K
-  double *s_red = s_t + K;        // 256
-  if (!FROM_MATRIX) {
-    load_tables(tab + (size_t)st.table * 5 * np, np, xp, s_tab);
-    for (int j = threadIdx.x; j < K; j += 256) s_th[j] = theta[(size_t)s * K + j];
-  }
-  if (temporal != SP_TEMPORAL_NONE)
-    for (int j = threadIdx.x; j < K; j += 256) s_t[j] = t[(size_t)s * K + j];
-  __syncthreads();
+  double *s_th = lds + (FROM_MATRIX ? 0 : 5 * np);  // chunk
+  double *s_t = s_th + chunk;     // chunk
+  double *s_red = s_t + chunk;    // 256
+  if (!FROM_MATRIX) load_tables(tab + (size_t)st.table * 5 * np, np, xp, s_tab);
   const int r = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + r;
   const int nobs = star_nobs(st, K);
+  const bool tk = temporal != SP_TEMPORAL_NONE;
+  const bool live = i < nobs;
+  const double thi = (live && !FROM_MATRIX) ? theta[(size_t)s * K + i] : 0.0;
+  const double ti = (live && tk) ? t[(size_t)s * K + i] : 0.0;
+  SplineGen g{s_tab, s_tab + 4 * np, 6.283185307179586 / covpts,
+              1.0 / (6.283185307179586 / covpts), covpts};
   double acc = 0.0;
-  if (i < nobs) {
+  for (int c0 = 0; c0 < nobs; c0 += chunk) {
+    const int n = nobs - c0 < chunk ? nobs - c0 : chunk;
+    if (c0) __syncthreads();
+    if (!FROM_MATRIX)
+      for (int j = threadIdx.x; j < n; j += 256) s_th[j] = theta[(size_t)s * K + c0 + j];
+    if (tk)
+      for (int j = threadIdx.x; j < n; j += 256) s_t[j] = t[(size_t)s * K + c0 + j];
+    __syncthreads();
+    if (!live) continue;
     if (FROM_MATRIX) {
-      const double *row = raw + ((size_t)s * K + i) * K;
-      const double ti = temporal != SP_TEMPORAL_NONE ? s_t[i] : 0.0;
-      for (int j = q; j < nobs; j += 4)
-        acc += row[j] * temporal_factor(temporal, ti, temporal != SP_TEMPORAL_NONE ? s_t[j] : 0.0, st.tau);
+      const double *row = raw + ((size_t)s * K + i) * K + c0;
+      for (int j = q; j < n; j += 4)
+        acc += row[j] * temporal_factor(temporal, ti, tk ? s_t[j] : 0.0, st.tau);
     } else if (nobs == 1) {
       acc = q == 0 ? meanvar[2 * st.table + 1] : 0.0;
     } else {
-      SplineGen g{s_tab, s_tab + 4 * np, 6.283185307179586 / covpts,
-                  1.0 / (6.283185307179586 / covpts), covpts};
-      const double thi = s_th[i];
-      const double ti = temporal != SP_TEMPORAL_NONE ? s_t[i] : 0.0;
-      for (int j = q; j < nobs; j += 4)
-        acc += g(thi, s_th[j]) *
-               temporal_factor(temporal, ti, temporal != SP_TEMPORAL_NONE ? s_t[j] : 0.0, st.tau);
+      for (int j = q; j < n; j += 4)
+        acc += g(thi, s_th[j]) * temporal_factor(temporal, ti, tk ? s_t[j] : 0.0, st.tau);
     }
   }
   s_red[threadIdx.x] = acc;
@@ -349,16 +353,21 @@ int sp_launch_rowsum(int S, int K, const double *theta, const double *t,
                      const double *meanvar, const double *xp, int temporal,
                      const double *raw, double *rowsum, hipStream_t st) {
   const int np = covpts + 4;
-  const size_t lds = sizeof(double) * ((raw ? 0 : 5 * (size_t)np) + 2 * (size_t)K + 256);
+  const size_t fixed = sizeof(double) * ((raw ? 0 : 5 * (size_t)np) + 256);
+  if (fixed + sizeof(double) * 2 * 64 > attr_lds_limit) return SP_ERR_INVALID;
+  // columns per LDS pass: all of them when they fit (K <= 4096 keeps every BASELINE
+  // configuration at one pass and at the occupancy it was measured with)
+  const int chunk = K < 4096 ? K : 4096;
+  const size_t lds = fixed + sizeof(double) * 2 * (size_t)chunk;
   if (lds > attr_lds_limit) return SP_ERR_INVALID;
   dim3 grid((K + 63) / 64, S);
   if (raw) {
     allow_big_lds(rowsum_kernel<true>);
-    hipLaunchKernelGGL(rowsum_kernel<true>, grid, dim3(256), lds, st, K, theta, t,
+    hipLaunchKernelGGL(rowsum_kernel<true>, grid, dim3(256), lds, st, K, chunk, theta, t,
                        stars, covpts, tab, meanvar, xp, temporal, raw, rowsum);
   } else {
     allow_big_lds(rowsum_kernel<false>);
-    hipLaunchKernelGGL(rowsum_kernel<false>, grid, dim3(256), lds, st, K, theta,
+    hipLaunchKernelGGL(rowsum_kernel<false>, grid, dim3(256), lds, st, K, chunk, theta,
                        t, stars, covpts, tab, meanvar, xp, temporal, raw, rowsum);
   }
   SP_LAUNCH_CHECK();

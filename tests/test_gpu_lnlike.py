@@ -257,3 +257,23 @@ def test_empty_and_invalid_arguments(eng):
     assert L.sp_lnlike_workspace_bytes(e._h, 1, 0, 1) == -1
     assert L.sp_cho_factor(e._h, None, 4, 4, 16, 1, None, stream) == -1
     assert _lib.lib().sp_strerror(-4).decode().startswith("constants")
+
+
+def test_beyond_one_lds_pass_of_columns(eng):
+    """K = 5000 > 4096: the row-sum kernel stages the columns' phases and times through LDS in
+    more than one pass; irregular cadence, time-variable kernel, against the oracle."""
+    from starry_process_amd import StarryProcess
+    from starry_process_amd import temporal as tmod
+
+    mom = golden("moments_L15")
+    mu, Sig = mom["default_mean_ylm"], mom["default_cov_ylm"]
+    K = 5000
+    rng = np.random.RandomState(50)
+    t = np.sort(rng.uniform(0, 25, K))
+    flux = 1e-2 * np.sin(2 * np.pi * t / 1.7) + 1e-3 * rng.randn(K)
+    for kw, okw in ((dict(), dict()),
+                    (dict(tau=3.0, temporal_kernel=tmod.Matern32Kernel),
+                     dict(tau=3.0, temporal_kernel=orc.Matern32Kernel))):
+        v = float(StarryProcess(ydeg=15, mean_ylm=mu, cov_ylm=Sig, **kw).log_likelihood(t, flux, 1e-6, p=1.7))
+        r = float(orc.OracleProcess(mu, Sig, ydeg=15, **okw).log_likelihood(t, flux, 1e-6, p=1.7))
+        assert abs(v - r) < 1e-8 * abs(r), (v, r)
