@@ -107,12 +107,9 @@ __global__ __launch_bounds__(256) void trsm_quad_kernel(double *sys, long ld, lo
                                                         const double *__restrict__ LT_all,
                                                         int batch, int ntiles) {
   __shared__ __attribute__((aligned(16))) double sLT[64 * 64 + 64];
-  // XCD-aware decode as in sp_gemm.hip: all row tiles of one star on one XCD
-  const int b = blockIdx.x;
-  const int xcd = b & 7, slot = b >> 3;
-  const int mtx = (slot / ntiles) * 8 + xcd;
-  if (mtx >= batch) return;
-  const int tile = slot % ntiles;
+  // XCD-aware decode as in sp_gemm.hip (sp_tile.h)
+  int mtx, tile;
+  if (!sp_xcd_decode(blockIdx.x, batch, ntiles, mtx, tile)) return;
   const int tid = threadIdx.x;
   const int lrow = tile * 64 + (tid >> 2), q = tid & 3;
   const bool valid = lrow < nrows;
@@ -412,7 +409,7 @@ static int launch_trsm(double *sys, long ld, long stride, int S, int r1, int c0,
   const int nrows = Kp - r1;
   if (nrows <= 0) return SP_OK;
   const int ntiles = (nrows + 63) / 64;
-  const long nblk = 8L * ((S + 7) / 8) * ntiles;
+  const long nblk = sp_xcd_grid(S, ntiles);
   hipLaunchKernelGGL(trsm_quad_kernel, dim3((unsigned)nblk), dim3(256), 0, st, sys, ld, stride,
                      r1, c0, nrows, LT, S, ntiles);
   SP_LAUNCH_CHECK();

@@ -14,8 +14,9 @@
 // 32-lane half) are bank-conflict free with ds_read_b64.
 //
 // Workgroup -> tile mapping is XCD-aware: blockIdx.x % 8 selects the XCD
-// (round-robin dispatch), and all tiles of one matrix are given to one XCD so
-// that the row panels every tile re-reads stay in that XCD's 4 MiB L2.
+// (round-robin dispatch), and each XCD is given a contiguous run of (matrix, tile)
+// items -- whole matrices when the batch is a multiple of 8 -- so that the row
+// panels neighbouring tiles re-read stay in that XCD's 4 MiB L2 (sp_xcd_decode).
 #include <cstdlib>
 
 #include "sp_internal.h"
@@ -119,12 +120,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
   __shared__ __attribute__((aligned(16))) double smem[NLDS];
   double *sA = smem, *sB = smem + GT * LDW;
 
-  // XCD-aware decode: blocks b and b+8 share an XCD
-  const int b = blockIdx.x;
-  const int xcd = b & 7, slot = b >> 3;
-  const int mtx = (slot / ntiles) * 8 + xcd;
-  if (mtx >= batch) return;
-  const int tile = slot % ntiles;
+  // XCD-aware decode: blocks b and b+8 share an XCD (sp_tile.h)
+  int mtx, tile;
+  if (!sp_xcd_decode(blockIdx.x, batch, ntiles, mtx, tile)) return;
   int ti, tj;
   if (lower_only) {
     ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
@@ -267,7 +265,7 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
   const int ntm = (Mrows + GT - 1) / GT, ntn = (Nrows + GT - 1) / GT;
   if (lower_only && ntm != ntn) return SP_ERR_INVALID;
   const int ntiles = lower_only ? ntm * (ntm + 1) / 2 : ntm * ntn;
-  const long nblk = 8L * ((batch + 7) / 8) * ntiles;
+  const long nblk = sp_xcd_grid(batch, ntiles);
   if (nblk > 0x7fffffffL) return SP_ERR_INVALID;
   static int variant = -1;
   if (variant < 0) {
