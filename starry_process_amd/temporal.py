@@ -12,15 +12,21 @@ import numpy as np
 __all__ = ["ExpSquaredKernel", "Matern32Kernel", "kernel_id"]
 
 
+def _lags(t1, t2):
+    """|t1_i - t2_j| for every pair, as a (len(t1), len(t2)) array."""
+    return np.abs(np.subtract.outer(np.ravel(t1), np.ravel(t2)))
+
+
 def ExpSquaredKernel(t1, t2, tau):
-    dt = np.abs(np.reshape(t1, (-1, 1)) - np.reshape(t2, (1, -1)))
-    return np.exp(-(dt ** 2) / (2 * tau))
+    """exp(-dt^2 / (2 tau)): ``tau`` enters linearly, as in the reference (not tau^2)."""
+    lag = _lags(t1, t2)
+    return np.exp(-0.5 * lag * lag / tau)
 
 
 def Matern32Kernel(t1, t2, tau):
-    dt = np.abs(np.reshape(t1, (-1, 1)) - np.reshape(t2, (1, -1)))
-    x = np.sqrt(3) * dt / tau
-    return (1 + x) * np.exp(-x)
+    """(1 + s) exp(-s), s = sqrt(3) dt / tau."""
+    s = _lags(t1, t2) * (np.sqrt(3) / tau)
+    return (1 + s) * np.exp(-s)
 
 
 def kernel_id(kernel):
