@@ -57,21 +57,28 @@ typedef double dd2 __attribute__((ext_vector_type(2)));
 
 struct SplineGen {
   const double *tab;   // LDS: {a0, a1, a2, a3} interleaved per segment (32 B, 16-B aligned)
-  const double *xp;    // LDS: lag grid
   double dx, inv_dx;
   int covpts;
   __device__ __forceinline__ double operator()(double thi, double thj) const {
     const double x = fabs(thi - thj);
     const double q = x * inv_dx;
-    long idx = (long)q;
-    if (fabs(q - rint(q)) < 1.0e-9) idx = (long)floor(x / dx);
+    // 0 <= x <= 2 pi, so the int64 index of the reference fits 32 bits (one v_cvt_i32_f64)
+    int idx = (int)q;
+    // x0 = (x - xp[idx + 1]) / dx with xp[k] = (k - 1) dx (flux.py:312-314): q - idx, equal to
+    // 3e-14 absolute on [0, 1) and one LDS read shorter.  It also tells how close q is to an
+    // integer: within 1e-9 of one the exact quotient decides the index.
+    double x0 = q - (double)idx;
+    if (fabs(x0 - 0.5) > 0.5 - 1.0e-9) {
+      idx = (int)floor(x / dx);
+      x0 = q - (double)idx;
+    }
     idx = idx < 0 ? 0 : (idx > covpts ? covpts : idx);
-    const double x0 = (x - xp[idx + 1]) * inv_dx;
     // two 16-byte LDS reads fetch the four coefficients of the segment
     const dd2 c01 = *reinterpret_cast<const dd2 *>(tab + 4 * idx);
     const dd2 c23 = *reinterpret_cast<const dd2 *>(tab + 4 * idx + 2);
-    // a0 + a1 x0 + a2 x0^2 + a3 x0^3 in Horner form
-    return c01.x + x0 * (c01.y + x0 * (c23.x + x0 * c23.y));
+    // a0 + a1 x0 + a2 x0^2 + a3 x0^3 in Horner form (the value, unlike the index, only has
+    // to agree to rounding: fused multiply-adds)
+    return __builtin_fma(x0, __builtin_fma(x0, __builtin_fma(x0, c23.y, c23.x), c01.y), c01.x);
   }
 };
 
@@ -104,12 +111,12 @@ __global__ __launch_bounds__(256) void spline_index_kernel(
 __device__ __forceinline__ void load_tables(const double *__restrict__ tab, int np,
                                             const double *__restrict__ xp,
                                             double *s_tab) {
-  // s_tab: [np][4] = {a0, a1, a2, a3} per segment, then xp[np]
+  // s_tab: [np][4] = {a0, a1, a2, a3} per segment (the lag grid itself is not needed:
+  // xp[k] = (k - 1) dx, SplineGen)
   for (int i = threadIdx.x; i < 4 * np; i += blockDim.x) {
     const int seg = i >> 2, k = i & 3;
     s_tab[i] = tab[(1 + k) * np + seg];
   }
-  for (int i = threadIdx.x; i < np; i += blockDim.x) s_tab[4 * np + i] = xp[i];
 }
 
 // Row sums of the raw covariance.  grid (ceil(K/64), S), 256 threads: thread
@@ -125,8 +132,8 @@ __global__ __launch_bounds__(256) void rowsum_kernel(
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int s = blockIdx.y, np = covpts + 4;
   const sp_star st = stars[s];
-  double *s_tab = lds;            // 5 * np (unused when FROM_MATRIX)
-  double *s_th = lds + (FROM_MATRIX ? 0 : 5 * np);  // chunk
+  double *s_tab = lds;            // 4 * np (unused when FROM_MATRIX)
+  double *s_th = lds + (FROM_MATRIX ? 0 : 4 * np);  // chunk
   double *s_t = s_th + chunk;     // chunk
   double *s_red = s_t + chunk;    // 256
   if (!FROM_MATRIX) load_tables(tab + (size_t)st.table * 5 * np, np, xp, s_tab);
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(256) void rowsum_kernel(
   const bool live = i < nobs;
   const double thi = (live && !FROM_MATRIX) ? theta[(size_t)s * K + i] : 0.0;
   const double ti = (live && tk) ? t[(size_t)s * K + i] : 0.0;
-  SplineGen g{s_tab, s_tab + 4 * np, 6.283185307179586 / covpts,
+  SplineGen g{s_tab, 6.283185307179586 / covpts,
               1.0 / (6.283185307179586 / covpts), covpts};
   double acc = 0.0;
   for (int c0 = 0; c0 < nobs; c0 += chunk) {
@@ -155,9 +162,11 @@ __global__ __launch_bounds__(256) void rowsum_kernel(
         acc += row[j] * temporal_factor(temporal, ti, tk ? s_t[j] : 0.0, st.tau);
     } else if (nobs == 1) {
       acc = q == 0 ? meanvar[2 * st.table + 1] : 0.0;
+    } else if (!tk) {
+      for (int j = q; j < n; j += 4) acc += g(thi, s_th[j]);
     } else {
       for (int j = q; j < n; j += 4)
-        acc += g(thi, s_th[j]) * temporal_factor(temporal, ti, tk ? s_t[j] : 0.0, st.tau);
+        acc += g(thi, s_th[j]) * temporal_factor(temporal, ti, s_t[j], st.tau);
     }
   }
   s_red[threadIdx.x] = acc;
@@ -243,8 +252,8 @@ __global__ __launch_bounds__(256) void assemble_kernel(
     tj = blockIdx.x % ntr;
   }
   const int i0 = ti * 64, j0 = tj * 64;
-  double *s_tab = lds;                                  // 5 np
-  double *s_thi = lds + (FROM_MATRIX ? 0 : 5 * np);     // 64 each below
+  double *s_tab = lds;                                  // 4 np
+  double *s_thi = lds + (FROM_MATRIX ? 0 : 4 * np);     // 64 each below
   double *s_thj = s_thi + 64, *s_ti = s_thj + 64, *s_tj = s_ti + 64;
   double *s_qi = s_tj + 64, *s_qj = s_qi + 64;
   if (!FROM_MATRIX) load_tables(tab + (size_t)st.table * 5 * np, np, xp, s_tab);
@@ -262,7 +271,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(
     s_qj[l] = (ok && normalized) ? qv[(size_t)s * K + j] : 0.0;
   }
   __syncthreads();
-  SplineGen g{s_tab, s_tab + 4 * np, 6.283185307179586 / covpts,
+  SplineGen g{s_tab, 6.283185307179586 / covpts,
               1.0 / (6.283185307179586 / covpts), covpts};
   const int nobs = star_nobs(st, K);
   const double var1 = (!FROM_MATRIX && nobs == 1) ? meanvar[2 * st.table + 1] : 0.0;
@@ -353,7 +362,7 @@ int sp_launch_rowsum(int S, int K, const double *theta, const double *t,
                      const double *meanvar, const double *xp, int temporal,
                      const double *raw, double *rowsum, hipStream_t st) {
   const int np = covpts + 4;
-  const size_t fixed = sizeof(double) * ((raw ? 0 : 5 * (size_t)np) + 256);
+  const size_t fixed = sizeof(double) * ((raw ? 0 : 4 * (size_t)np) + 256);
   if (fixed + sizeof(double) * 2 * 64 > attr_lds_limit) return SP_ERR_INVALID;
   // columns per LDS pass: all of them when they fit (K <= 4096 keeps every BASELINE
   // configuration at one pass and at the occupancy it was measured with)
@@ -393,7 +402,7 @@ int sp_launch_assemble(int S, int K, int M, int Kp, int system,
                        const double *diag, int add_noise, const double *flux,
                        double *out, long ldo, long strideo, hipStream_t st) {
   const int np = covpts + 4;
-  const size_t lds = sizeof(double) * ((raw ? 0 : 5 * (size_t)np) + 6 * 64);
+  const size_t lds = sizeof(double) * ((raw ? 0 : 4 * (size_t)np) + 6 * 64);
   if (lds > attr_lds_limit) return SP_ERR_INVALID;
   const int ntr = ((system ? Kp : K) + 63) / 64;
   const int ntiles = system ? ntr * (ntr + 1) / 2 : ntr * ntr;
