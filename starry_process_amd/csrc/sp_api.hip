@@ -443,6 +443,8 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
   {
     const char *e4 = getenv("SP_FUSE_DIAG");
     h->fuse_diag = e4 ? atoi(e4) : 2;  // 0 off, 1 block-column updates, 2 + bulk updates
+    const char *e5 = getenv("SP_EAGER");
+    h->eager = e5 ? atoi(e5) : 1;
     const char *e3 = getenv("SP_GROUPS");
     h->groups = e3 ? atoi(e3) : 1;
     const char *e2 = getenv("SP_SUPER");

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void diag_kernel(double *__restrict__ sys, lon
 __global__ __launch_bounds__(256) void trsm_quad_kernel(double *sys, long ld, long stride,
                                                         int r1, int c0, int nrows,
                                                         const double *__restrict__ LT_all,
-                                                        int batch, int ntiles) {
+                                                        int batch, int ntiles, int neager) {
   __shared__ __attribute__((aligned(16))) double sLT[64 * 64 + 64];
   // XCD-aware decode as in sp_gemm.hip (sp_tile.h)
   int mtx, tile;
@@ -126,6 +126,52 @@ __global__ __launch_bounds__(256) void trsm_quad_kernel(double *sys, long ld, lo
   lt_store(lt, sLT, sLT + 4096);
   __syncthreads();
   quad_solve_store(x, sLT, sLT + 4096, prow, valid);
+  if (tile >= neager) return;
+  // Eager update of a coming diagonal block.  The first `neager` row tiles of this panel are
+  // the rows of the pivot blocks still to be factored before the next trailing update reaches
+  // them; each takes its share D_ii -= X_i X_i^T now, from the rows it has just solved, so
+  // that when block i's turn comes its workgroup finds it up to date and factors it at once
+  // (skip00 in gemm_nt_kernel).  The rank-64 product costs this workgroup ~2 us inside a
+  // launch that is bound by the other tiles' traffic; it used to cost the workgroup on the
+  // critical path the whole left-looking product, one operand slice latency after another.
+  constexpr int XW = 65;   // padded row: 64 * 65 doubles = the L_d^T image + diagonal, reused
+  __syncthreads();
+  double *sX = sLT;
+  {
+    double *row = sX + (tid >> 2) * XW + 2 * q;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      row[8 * i] = x[2 * i];
+      row[8 * i + 1] = x[2 * i + 1];
+    }
+  }
+  __syncthreads();
+  // (fetching the tile before the solve instead, to hide its latency, costs a wavefront of
+  //  occupancy -- 156 VGPRs -- and measures no faster)
+  const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fk = lane >> 4;
+  const int d0 = r1 + tile * 64;
+  double *D = sys + (size_t)mtx * stride + (size_t)d0 * ld + d0;
+  d4 acc[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      acc[n][r] = D[(size_t)(16 * wave + fk + 4 * r) * ld + 16 * n + fr];
+  const double *pa = sX + (16 * wave + fr) * XW + fk;
+  const double *pb = sX + fr * XW + fk;
+#pragma unroll
+  for (int kk = 0; kk < 64; kk += 4) {
+    const double a = -pa[kk];
+    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, pb[kk], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, pb[16 * XW + kk], acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, pb[32 * XW + kk], acc[2], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, pb[48 * XW + kk], acc[3], 0, 0, 0);
+  }
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      D[(size_t)(16 * wave + fk + 4 * r) * ld + 16 * n + fr] = acc[n][r];
 }
 
 // lnlike = -1/2 sum_m |y_m|^2 - M sum_i log L_ii - K M / 2 log(2 pi)
@@ -378,7 +424,7 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, double *sink,
 // same rows; lower-triangle tiles only.  Timed for bench.py when profiling is on.
 static int bulk_update(sp_handle *h, double *sys, long ld, long stride, int S, int c0,
                        int cfrom, int Kp, int kd, hipStream_t st, int fuse_nact = 0,
-                       double *invL = nullptr, int32_t *info = nullptr) {
+                       double *invL = nullptr, int32_t *info = nullptr, int skip00 = 0) {
   // fuse_nact > 0: tile (0, 0) is the diagonal block of the next panel and its
   // workgroup factors it on the spot (hidden behind the other tiles)
   const int n = Kp - cfrom;
@@ -388,7 +434,7 @@ static int bulk_update(sp_handle *h, double *sys, long ld, long stride, int S, i
   if (timed) SP_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
   int rc = fuse_nact > 0
                ? sp_launch_gemm_nt_diag(X, ld, stride, X, ld, stride, T, ld, stride, n, n, kd,
-                                        -1.0, 1, S, fuse_nact, invL, info, st)
+                                        -1.0, 1, S, fuse_nact, invL, info, st, skip00)
                : sp_launch_gemm_nt(X, ld, stride, X, ld, stride, T, ld, stride, n, n, kd, -1.0,
                                    1, 1, S, st);
   if (rc != SP_OK) return rc;
@@ -404,20 +450,22 @@ static int bulk_update(sp_handle *h, double *sys, long ld, long stride, int S, i
 }
 
 // rows r1..Kp-1 of panel column c0: X = P L_d^-T in place (LT = diag_block's output)
+// neager: leading row tiles that also update their own diagonal block (trsm_quad_kernel)
 static int launch_trsm(double *sys, long ld, long stride, int S, int r1, int c0, int Kp,
-                       const double *LT, hipStream_t st) {
+                       const double *LT, hipStream_t st, int neager = 0) {
   const int nrows = Kp - r1;
   if (nrows <= 0) return SP_OK;
   const int ntiles = (nrows + 63) / 64;
   const long nblk = sp_xcd_grid(S, ntiles);
   hipLaunchKernelGGL(trsm_quad_kernel, dim3((unsigned)nblk), dim3(256), 0, st, sys, ld, stride,
-                     r1, c0, nrows, LT, S, ntiles);
+                     r1, c0, nrows, LT, S, ntiles, neager);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }
 
 static int diag_and_solve(double *sys, long ld, long stride, int S, int K, int Kp, int j,
-                          int32_t *info, double *invL, hipStream_t st, bool have_diag = false) {
+                          int32_t *info, double *invL, hipStream_t st, bool have_diag = false,
+                          int neager = 0) {
   const int c0 = j * SP_NB;
   const int nact = K - c0 < SP_NB ? K - c0 : SP_NB;
   // diagonal block: L_d (and L_d^T for the solve)
@@ -427,7 +475,7 @@ static int diag_and_solve(double *sys, long ld, long stride, int S, int K, int K
     SP_LAUNCH_CHECK();
   }
   // rows below the active block: X = P L_d^-T, in place
-  return launch_trsm(sys, ld, stride, S, c0 + nact, c0, Kp, invL, st);
+  return launch_trsm(sys, ld, stride, S, c0 + nact, c0, Kp, invL, st, neager);
 }
 
 // In-place factorisation of S padded systems (Kp x Kp, ld = Kp): the leading
@@ -447,7 +495,7 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
   // panels per super-panel: wider super-panels raise the arithmetic intensity of the
   // trailing update (k = 64 w) at the price of more left-looking work per block column;
   // measured: w = 4, 6, 8 equal at K = 1000 (16 panels), w = 8 +3 % at K = 3000 (47 panels)
-  const int w = (h && h->superpanel > 0) ? h->superpanel : (nsteps >= 32 ? 8 : 4);
+  const int w = (h && h->superpanel > 0) ? h->superpanel : (nsteps >= 16 ? 8 : 4);
   // launches are issued breadth-first over the groups so that the groups'
   // streams advance together (the host enqueues ~3-8 us per launch)
   for (int s0 = 0; s0 < nsteps; s0 += w) {
@@ -457,6 +505,15 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
       for (int g = 0; g < ngroups; ++g) {
         const sp_chol_group &G = grp[g];
         const int nact = K - c0 < SP_NB ? K - c0 : SP_NB;
+        // pivot blocks after j that are factored before a trailing update reaches them
+        // (the rest of this super-panel, and the next one's first block when the trailing
+        // update factors it): their diagonal tiles are kept up to date by the panel solves
+        int neager = 0;
+        if (h && h->fuse_diag && h->eager) {
+          int last = s0 + w - (h->fuse_diag > 1 ? 0 : 1);
+          if (last > nsteps - 1) last = nsteps - 1;
+          neager = last > j ? last - j : 0;
+        }
         if (q > 0 && h && h->fuse_diag) {
           // left-looking update of block column j by panels s0..j-1; the tile-(0,0)
           // workgroup goes on to factor the diagonal block (fused), so only the
@@ -465,9 +522,9 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
           double *T = G.sys + (size_t)c0 * ld + c0;
           int rc = sp_launch_gemm_nt_diag(A, ld, stride, A, ld, stride, T, ld, stride, Kp - c0,
                                           SP_NB, q * SP_NB, -1.0, 0, G.S, nact, G.invL, G.info,
-                                          G.st);
+                                          G.st, h->eager ? 1 : 0);
           if (rc != SP_OK) return rc;
-          rc = launch_trsm(G.sys, ld, stride, G.S, c0 + nact, c0, Kp, G.invL, G.st);
+          rc = launch_trsm(G.sys, ld, stride, G.S, c0 + nact, c0, Kp, G.invL, G.st, neager);
           if (rc != SP_OK) return rc;
           continue;
         }
@@ -482,7 +539,7 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
         // fused bulk update of the previous super-panel (if fusing is on)
         const bool have_diag = q == 0 && s0 > 0 && h && h->fuse_diag > 1;
         int rc = diag_and_solve(G.sys, ld, stride, G.S, K, Kp, j, G.info, G.invL, G.st,
-                                have_diag);
+                                have_diag, neager);
         if (rc != SP_OK) return rc;
       }
     }
@@ -492,7 +549,7 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
       for (int g = 0; g < ngroups; ++g) {
         int rc = bulk_update(h, grp[g].sys, ld, stride, grp[g].S, cS, cE, Kp, w * SP_NB,
                              grp[g].st, (h && h->fuse_diag > 1) ? nactE : 0, grp[g].invL,
-                             grp[g].info);
+                             grp[g].info, (h && h->fuse_diag > 1 && h->eager) ? 1 : 0);
         if (rc != SP_OK) return rc;
       }
     }

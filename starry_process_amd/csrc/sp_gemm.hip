@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
     const double *__restrict__ B, long ldb, long strideB, double *C,
     long ldc, long strideC, int Mrows, int Nrows, int Kd, double alpha,
     int beta, int lower_only, int batch, int ntm, int ntn, int ntiles, int nact,
-    double *invL_all, int32_t *info) {
+    double *invL_all, int32_t *info, int skip00) {
   // Padded LDS row of BK + 1 doubles.  hipcc fuses the per-k-step fragment reads
   // into ds_read2_b64, which is banked mod 32 dwords in 16-lane groups: an ODD
   // row length puts the 16 rows of a group on 16 distinct bank pairs.  (An even
@@ -168,13 +168,22 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
   const bool vecA = ((lda & 1) == 0) && ((reinterpret_cast<uintptr_t>(Ab) & 15) == 0);
   const bool vecB = ((ldb & 1) == 0) && ((reinterpret_cast<uintptr_t>(Bb) & 15) == 0);
 
+  // skip00: the diagonal block of the next panel already carries every update (the panel
+  // solves applied them eagerly, trsm_quad_kernel): its workgroup goes straight to the
+  // factorisation
+  const int Kloop = (FUSE == 1 && skip00 && ti == 0 && tj == 0) ? 0 : Kd;
   PanelRegs<BK> ra, rb;
-  if (FAST) {
-    stage_load_fast<BK>(Ab, lda, row0, 0, ra);
-    stage_load_fast<BK>(Bb, ldb, col0, 0, rb);
+  if (Kloop > 0) {
+    if (FAST) {
+      stage_load_fast<BK>(Ab, lda, row0, 0, ra);
+      stage_load_fast<BK>(Bb, ldb, col0, 0, rb);
+    } else {
+      stage_load<BK>(Ab, lda, row0, Mrows, 0, Kd, vecA, ra);
+      stage_load<BK>(Bb, ldb, col0, Nrows, 0, Kd, vecB, rb);
+    }
   } else {
-    stage_load<BK>(Ab, lda, row0, Mrows, 0, Kd, vecA, ra);
-    stage_load<BK>(Bb, ldb, col0, Nrows, 0, Kd, vecB, rb);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(ra.v) / sizeof(ra.v[0])); ++i) ra.v[i] = rb.v[i] = d2{0.0, 0.0};
   }
   if (ABL == 2 || ABL == 3) {
     stage_store<BK>(ra, alpha, sA);
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
     __syncthreads();
   }
   double fa = ra.v[0].x, fb0 = rb.v[0].x, fb1 = rb.v[0].y, fb2 = rb.v[1].x, fb3 = rb.v[1].y;
-  for (int k0 = 0; k0 < Kd; k0 += BK) {
+  for (int k0 = 0; k0 < Kloop; k0 += BK) {
     if (ABL < 2 || ABL == 4) {
       stage_store<BK>(ra, alpha, sA);
       stage_store<BK>(rb, 1.0, sB);
@@ -259,7 +268,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
 static int launch_gemm(const double *A, long lda, long strideA, const double *B, long ldb,
                        long strideB, double *C, long ldc, long strideC, int Mrows, int Nrows,
                        int Kd, double alpha, int beta, int lower_only, int batch, int fuse,
-                       int nact, double *invL, int32_t *info, hipStream_t st) {
+                       int nact, double *invL, int32_t *info, hipStream_t st, int skip00 = 0) {
   if (Mrows <= 0 || Nrows <= 0 || batch <= 0) return SP_OK;
   if (Kd < 0) return SP_ERR_INVALID;
   const int ntm = (Mrows + GT - 1) / GT, ntn = (Nrows + GT - 1) / GT;
@@ -278,11 +287,11 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
 #define SP_GO_FAST(FD)                                                                       \
   hipLaunchKernelGGL((gemm_nt_kernel<32, false, FD, 0, true>), dim3((unsigned)nblk), dim3(256), 0, \
                      st, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd,  \
-                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info)
+                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00)
 #define SP_GO(BK, DC, FD)                                                              \
   hipLaunchKernelGGL((gemm_nt_kernel<BK, DC, FD>), dim3((unsigned)nblk), dim3(256), 0, st, \
                      A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd, \
-                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info)
+                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00)
   static int abl = -1;
   if (abl < 0) {
     const char *e = getenv("SP_GEMM_ABL");
@@ -291,7 +300,7 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
 #define SP_GO_ABL(N)                                                                          \
   hipLaunchKernelGGL((gemm_nt_kernel<32, false, 0, N>), dim3((unsigned)nblk), dim3(256), 0, st, \
                      A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd,       \
-                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info)
+                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00)
   if (abl > 0 && !fuse) {
     switch (abl) {
       case 1: SP_GO_ABL(1); break;
@@ -308,7 +317,7 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
   } else if (fast && variant == 2 && (Kd % 64) == 0) {
     hipLaunchKernelGGL((gemm_nt_kernel<64, false, 0, 0, true>), dim3((unsigned)nblk), dim3(256), 0,
                        st, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd,
-                       alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info);
+                       alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00);
   } else {
     switch (variant) {
       case 1: SP_GO(32, true, 0); break;
@@ -335,8 +344,8 @@ int sp_launch_gemm_nt(const double *A, long lda, long strideA, const double *B, 
 int sp_launch_gemm_nt_diag(const double *A, long lda, long strideA, const double *B, long ldb,
                            long strideB, double *C, long ldc, long strideC, int Mrows,
                            int Nrows, int Kd, double alpha, int lower_only, int batch,
-                           int nact, double *invL, int32_t *info, hipStream_t st) {
+                           int nact, double *invL, int32_t *info, hipStream_t st, int skip00) {
   return launch_gemm(A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd,
-                     alpha, 1, lower_only, batch, 1, nact, invL, info, st);
+                     alpha, 1, lower_only, batch, 1, nact, invL, info, st, skip00);
 }
 

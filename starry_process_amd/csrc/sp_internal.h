@@ -45,6 +45,7 @@ struct sp_handle {
   int superpanel;               // panels per super-panel (SP_SUPER; 0 = chosen from K)
   int groups;                   // concurrent star groups (SP_GROUPS, default 1)
   int fuse_diag;                // fuse the diagonal-block factorisation into the block-column update
+  int eager;                    // panel solves keep the coming diagonal blocks up to date (SP_EAGER)
   std::vector<hipStream_t> gstream;
   std::vector<hipEvent_t> gdone;
   hipEvent_t gfork;
@@ -129,7 +130,8 @@ int sp_launch_gemm_nt(const double *A, long lda, long strideA, const double *B,
 int sp_launch_gemm_nt_diag(const double *A, long lda, long strideA, const double *B, long ldb,
                            long strideB, double *C, long ldc, long strideC, int Mrows,
                            int Nrows, int Kd, double alpha, int lower_only, int batch,
-                           int nact, double *invL, int32_t *info, hipStream_t st);
+                           int nact, double *invL, int32_t *info, hipStream_t st,
+                           int skip00 = 0);
 
 // per-star scratch of the factorisation (doubles): the L_d^T image of the current panel
 #define SP_LT_DOUBLES 4096
