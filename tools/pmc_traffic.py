@@ -10,8 +10,9 @@ counters are in KiB; on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of
 wide coalesced streaming reads, so it is doubled; WRITE_SIZE is exact.  (The
 C-tile reads of this kernel are 8 B per lane, a width the guide lists as
 uncalibrated; the doubled figure is therefore an upper estimate of the read
-side.)  Bulk launches = the gemm_nt_kernel dispatches with lower-triangle
-grids, i.e. the three largest distinct grid sizes of a K=1000, w=4 run.
+side.)  Bulk launches = the gemm_nt_kernel dispatches with the lower-triangle
+grid of the trailing update: at K = 1000 with super-panels of 8 there is one per
+step, n = 512 (36 lower tiles x 64 stars), a grid no block-column update has.
 """
 import collections
 import csv
@@ -32,21 +33,13 @@ def load(d, counter):
 
 fetch = load(sys.argv[1], 'FETCH_SIZE')
 write = load(sys.argv[2], 'WRITE_SIZE')
-# expected bulk grids for S = 64 stars, K = 1000 (Kp = 1024), super-panels of 4:
-# trailing sizes n = 768, 512, 256 -> lower tiles 78, 36, 10, x 64 stars x 256 threads
-grids = [78 * 64 * 256, 36 * 64 * 256, 10 * 64 * 256]
+# bulk grid for S = 64 stars, K = 1000 (Kp = 1024), super-panels of 8: trailing size
+# n = 512 -> 36 lower tiles x 64 stars x 256 threads (block-column updates have <= 15 x 64)
+grids = [36 * 64 * 256]
 
 
 def bulk_only(d):
-    """The third bulk grid (10 tiles x 64) is shared with the block-column update of
-    panel 6 (10 row tiles); among the gemm_nt_kernel dispatches the bulk launch is the
-    one that follows the block-column update of panel 11 (5 row tiles x 64 stars x 256)."""
-    out, prev = [], None
-    for g, v in d.values():
-        if g in grids[:2] or (g == grids[2] and prev == 5 * 64 * 256):
-            out.append(v)
-        prev = g
-    return out
+    return [v for g, v in d.values() if g in grids]
 
 
 sel_f = bulk_only(fetch)
@@ -55,7 +48,7 @@ n = min(len(sel_f), len(sel_w))
 fetch_b = 2.0 * 1024.0 * sum(sel_f[:n]) / n
 write_b = 1024.0 * sum(sel_w[:n]) / n
 res = {
-    "kernel": "gemm_nt_kernel (bulk rank-256 trailing update, lower tiles)",
+    "kernel": "gemm_nt_kernel (bulk rank-512 trailing update of n = 512, lower tiles)",
     "launches_averaged": n,
     "grid_sizes": grids,
     "FETCH_SIZE_KiB_per_launch_raw": sum(sel_f[:n]) / n,
