@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""HBM traffic of the dominant kernel (the rank-256 bulk trailing update) from
+"""HBM traffic of the dominant kernel (the bulk trailing update, rank 512 at K = 1000) from
 two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE cannot share a pass on
 gfx950: TCC has 4 slots, FETCH_SIZE takes 3, WRITE_SIZE 2).
 
