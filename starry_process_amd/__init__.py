@@ -7,11 +7,16 @@ from .temporal import ExpSquaredKernel, Matern32Kernel  # noqa: E402,F401
 
 def __getattr__(name):
     # heavy modules (torch, the HIP library) load on first use
-    if name == "StarryProcess":
-        from .sp import StarryProcess
+    if name in ("StarryProcess", "StarryProcessSum"):
+        from . import sp
 
-        return StarryProcess
-    if name in ("ops", "flux", "sp", "engine", "ensemble", "upstream", "hostconst", "calibrate"):
+        return getattr(sp, name)
+    if name in ("gauss2beta", "beta2gauss"):
+        from . import upstream
+
+        return getattr(upstream, name)
+    if name in ("ops", "flux", "sp", "engine", "ensemble", "upstream", "upstream_device", "hostconst",
+                "calibrate", "math"):
         import importlib
 
         return importlib.import_module("." + name, __name__)

@@ -30,7 +30,7 @@ from .flux import FluxIntegral
 from .ops import AlphaBetaOp, CheckBoundsOp, Eager
 from .temporal import kernel_id
 
-__all__ = ["StarryProcess"]
+__all__ = ["StarryProcess", "StarryProcessSum"]
 
 
 def _neg_inf_if_nan(x):
@@ -153,6 +153,15 @@ class StarryProcess(object):
     marginalize_over_inclination = property(lambda self: self._marginalize_over_inclination)
     mean_ylm = property(lambda self: Eager(self._mean_ylm))
     cov_ylm = property(lambda self: Eager(self._cov_ylm))
+
+    # -- sums of processes (sp.py:1190-1197, 1335-1400) -------------------------------
+    def __add__(self, other):
+        return StarryProcessSum(self, other)
+
+    def __radd__(self, other):
+        if isinstance(other, (int, float)) and other == 0:
+            return self          # so that sum([sp1, sp2, ...]) works
+        return self.__add__(other)
 
     def log_jac(self):
         """Log |Jacobian| of the (a, b) -> (mu, sigma) transform (sp.py:1004-1050)."""
@@ -436,3 +445,38 @@ class StarryProcess(object):
             meanvar=mv, rta1=rta1, temporal=self._temporal, normalized=self._normalized,
             norm_order=self._normN, zmax=self._normzmax)
         return Eager(_neg_inf_if_nan(out.cpu().numpy()))
+
+
+class StarryProcessSum(StarryProcess):
+    """Sum of independent processes (several spot populations on one star): the moments of
+    the spherical-harmonic vectors add (sp.py:1335-1400); everything downstream -- flux mean
+    and covariance, log-likelihood, prediction -- is the base class on the summed moments."""
+
+    def __init__(self, first, second):
+        if not isinstance(second, StarryProcess):
+            raise AssertionError("Can only add instances of `StarryProcess` to each other.")
+        for name, what in (("_ydeg", "ydeg"), ("_udeg", "udeg"), ("_normalized", "normalized"),
+                           ("_marginalize_over_inclination", "marginalize_over_inclination"),
+                           ("_covpts", "covpts")):
+            assert getattr(first, name) == getattr(second, name), "Mismatch in `%s`." % what
+        assert not first._time_variable and not second._time_variable, (
+            "Sums of `StarryProcess` instances not implemented for time-variable surfaces.")
+        kwargs = dict(first._kwargs)
+        kwargs.pop("upstream", None)
+        StarryProcess.__init__(
+            self,
+            mean_ylm=first._mean_ylm + second._mean_ylm,
+            cov_ylm=first._cov_ylm + second._cov_ylm,
+            marginalize_over_inclination=first._marginalize_over_inclination,
+            normalized=first._normalized,
+            covpts=first._covpts,
+            **kwargs,
+        )
+        # hyperparameters are those of the children, not of the sum
+        self._r = self._dr = self._a = self._b = self._c = self._n = None
+        self._children = []
+        for child in (first, second):
+            self._children += getattr(child, "_children", [child])
+
+    def log_jac(self):
+        raise NotImplementedError("the latitude Jacobian is defined per child process")

@@ -319,6 +319,30 @@ def gen_linalg_rev():
     save("linalg_rev.npz", **out)
 
 
+def gen_sum():
+    """Sum of two processes (sp.py:1190-1197, 1335-1400; the reference's tests/test_sum.py):
+    `default` + `hilat` populations, ydeg 15.  The children's moments are the ones already in
+    moments_L15.npz (checked), so the fixture only holds what the SUM gives."""
+    mom = np.load(os.path.join(OUT, "moments_L15.npz"))
+    out = {}
+    rng = np.random.RandomState(21)
+    t = np.linspace(0, 2, 120)
+    flux = 1e-2 * np.sin(2 * np.pi * t / 0.7) + 1e-3 * rng.randn(t.size)
+    out.update(t=t, flux=flux)
+    for tag, kw in (("marg_norm", dict()),
+                    ("cond_raw", dict(marginalize_over_inclination=False, normalized=False))):
+        sp1 = SP(ydeg=15, **HYPER["default"], **kw)
+        sp2 = SP(ydeg=15, **HYPER["hilat"], **kw)
+        assert np.array_equal(A(sp1._mean_ylm), mom["default_mean_ylm"])
+        assert np.array_equal(A(sp2._cov_ylm), mom["hilat_cov_ylm"])
+        sp = sp1 + sp2
+        assert sum([sp1, sp2])._children == sp._children
+        out[tag + "_lnlike"] = np.array(float(sp.log_likelihood(t, flux, 1e-6, i=50.0, p=0.7, u=[0.3, 0.1])))
+        out[tag + "_cov"] = A(sp.cov(t[:40], i=50.0, p=0.7, u=[0.3, 0.1]))
+        out[tag + "_mean"] = A(sp.mean(t[:40], i=50.0, p=0.7, u=[0.3, 0.1]))
+    save("sum.npz", **out)
+
+
 def gen_predict():
     """StarryProcess.predict for small cases (unnormalised processes only, sp.py:855-858)."""
     mom = np.load(os.path.join(OUT, "moments_L15.npz"))
@@ -445,7 +469,7 @@ def gen_lnlike():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "consts", "moments", "cov", "norm", "lnlike", "upstream", "calibrate", "predict", "rev", "linalg_rev"]
+    which = sys.argv[1:] or ["ops", "consts", "moments", "cov", "norm", "lnlike", "upstream", "calibrate", "predict", "rev", "linalg_rev", "sum"]
     for L in (5, 15, 20):
         if "ops" in which:
             gen_ops(L)
@@ -470,3 +494,5 @@ if __name__ == "__main__":
         gen_predict()
     if "linalg_rev" in which:
         gen_linalg_rev()
+    if "sum" in which:
+        gen_sum()

@@ -348,3 +348,32 @@ def test_prior_samples_and_flux():
     A = np.array(spc._flux.design_matrix(t, 65.0, 0.8, [0.2, 0.1]))
     F = np.array(spc.flux(Y[:5], t, i=65.0, p=0.8, u=[0.2, 0.1]))
     assert np.abs(F - Y[:5] @ A.T).max() < 1e-14 * max(1.0, np.abs(F).max())
+
+
+def test_sum_of_processes():
+    """sp1 + sp2 (sp.py:1190-1197, 1335-1400; the reference's tests/test_sum.py) against the
+    executed reference (tests/golden/sum.npz): children from the fixture moments, so nothing
+    upstream of the path enters the comparison."""
+    from starry_process_amd import StarryProcess, StarryProcessSum
+
+    mom = golden("moments_L15")
+    g = golden("sum")
+    for tag, kw in (("marg_norm", dict()),
+                    ("cond_raw", dict(marginalize_over_inclination=False, normalized=False))):
+        sp1 = StarryProcess(ydeg=15, mean_ylm=mom["default_mean_ylm"], cov_ylm=mom["default_cov_ylm"], **kw)
+        sp2 = StarryProcess(ydeg=15, mean_ylm=mom["hilat_mean_ylm"], cov_ylm=mom["hilat_cov_ylm"], **kw)
+        sp = sp1 + sp2
+        assert isinstance(sp, StarryProcessSum) and sp._children == [sp1, sp2]
+        assert sum([sp1, sp2])._children == [sp1, sp2]
+        assert (sp + sp1)._children == [sp1, sp2, sp1]
+        args = dict(i=50.0, p=0.7, u=[0.3, 0.1])
+        ll = float(sp.log_likelihood(g["t"], g["flux"], 1e-6, **args))
+        assert abs(ll - float(g[tag + "_lnlike"])) < 1e-8 * abs(float(g[tag + "_lnlike"]))
+        cov = np.array(sp.cov(g["t"][:40], **args))
+        assert np.abs(cov - g[tag + "_cov"]).max() < 1e-10 * np.abs(g[tag + "_cov"]).max()
+        mean = np.array(sp.mean(g["t"][:40], **args))
+        assert np.abs(mean - g[tag + "_mean"]).max() < 1e-12 + 1e-10 * np.abs(g[tag + "_mean"]).max()
+    with pytest.raises(AssertionError):
+        sp1 + StarryProcess(ydeg=15, mean_ylm=mom["default_mean_ylm"], cov_ylm=mom["default_cov_ylm"])
+    with pytest.raises(AssertionError):
+        sp1 + 3

@@ -264,3 +264,18 @@ def test_zmax_guard_and_bounds():
         _proc(5).log_likelihood(st["t"], st["flux"], 1e-6, p=-1.0)
     # non-PD -> NaN Cholesky -> -inf (math.py:82-91, sp.py:1186-1188)
     assert _proc(5).log_likelihood(st["t"], st["flux"], -1.0) == -np.inf
+
+
+def test_sum_of_processes_oracle():
+    """The moments of independent processes add (sp.py:1383-1384): the oracle on the summed
+    fixture moments against the reference's own sp1 + sp2 (tests/golden/sum.npz)."""
+    mom = golden("moments_L15")
+    g = golden("sum")
+    mu = mom["default_mean_ylm"] + mom["hilat_mean_ylm"]
+    Sig = mom["default_cov_ylm"] + mom["hilat_cov_ylm"]
+    args = dict(i=50.0, p=0.7, u=[0.3, 0.1])
+    for tag, kw in (("marg_norm", dict()),
+                    ("cond_raw", dict(marginalize_over_inclination=False, normalized=False))):
+        o = orc.OracleProcess(mu, Sig, ydeg=15, **kw)
+        ll = float(o.log_likelihood(g["t"], g["flux"], 1e-6, **args))
+        assert abs(ll - float(g[tag + "_lnlike"])) < 1e-10 * abs(float(g[tag + "_lnlike"]))
