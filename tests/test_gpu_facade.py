@@ -377,3 +377,31 @@ def test_sum_of_processes():
         sp1 + StarryProcess(ydeg=15, mean_ylm=mom["default_mean_ylm"], cov_ylm=mom["default_cov_ylm"])
     with pytest.raises(AssertionError):
         sp1 + 3
+
+
+@pytest.mark.parametrize("marginalize_over_inclination", [True, False])
+def test_lnlike_array(marginalize_over_inclination):
+    """The reference's own end-to-end check (tests/test_lnlike.py:57-97): draw a light curve
+    from the process at the default hyperparameters, scan the latitude parameter b over [0, 1]
+    and require the likelihood to peak within 0.10 of the truth.  Hyperparameters -> moments on
+    the device (upstream="device"), 100 evaluations of the K = 1000 likelihood."""
+    from starry_process_amd import StarryProcess
+    from starry_process_amd.defaults import defaults
+
+    kw = dict(marginalize_over_inclination=marginalize_over_inclination, normalized=False,
+              upstream="device")
+    params = dict(r=defaults["r"], a=defaults["a"], b=defaults["b"], c=defaults["c"], n=defaults["n"])
+    t = np.linspace(0, 1, 1000)
+    gp = StarryProcess(**params, **kw)
+    flux = np.array(gp.sample(t, p=defaults["p"], i=defaults["i"], seed=42)).reshape(-1)
+    flux_err = 1e-3
+    rng = np.random.RandomState(42)
+    flux = flux + rng.randn(t.size) * flux_err
+    b_arr = np.linspace(0.0, 1.0, 100)
+    ll = np.empty(b_arr.size)
+    for k, b in enumerate(b_arr):
+        p2 = dict(params, b=b)
+        ll[k] = float(StarryProcess(**p2, **kw).log_likelihood(t, flux, flux_err ** 2, p=defaults["p"],
+                                                              i=defaults["i"]))
+    assert np.isfinite(np.nanmax(ll))
+    assert abs(b_arr[np.nanargmax(ll)] - defaults["b"]) < 0.10
