@@ -79,8 +79,12 @@ struct LtRegs {
 };
 __device__ __forceinline__ void lt_load(LtRegs &R, const double *LT) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
-    R.v[i] = *reinterpret_cast<const d2v *>(LT + 2 * (threadIdx.x + 256 * i));
+  for (int i = 0; i < 8; ++i) {
+    // row k of the image is zero left of the diagonal (lt[k][c] = L_ck / L_cc, c >= k): those
+    // pairs are not fetched -- the image is a third of a solve workgroup's traffic
+    const int e = 2 * (threadIdx.x + 256 * i), k = e >> 6, c = e & 63;
+    R.v[i] = (c + 1 >= k) ? *reinterpret_cast<const d2v *>(LT + e) : d2v{0.0, 0.0};
+  }
 }
 // sLT[64 * 64] gets the image with a zero diagonal, sRd[64] the diagonal (1 / L_kk)
 __device__ __forceinline__ void lt_store(const LtRegs &R, double *sLT, double *sRd) {
