@@ -79,8 +79,8 @@ def cpu_baseline(nstars, timeout=240.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--cpu-stars", type=int, default=128)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
