@@ -14,10 +14,11 @@
 //     one per lane, by substitution against the leaf.  fp64 VALU and fp64 MFMA
 //     have the same peak on gfx950, so nothing is lost by leaving the matrix
 //     cores here; the leaf is a latency chain of ~130 cycles per column.
-//   update: block column w is brought up to date by wavefront w itself as soon
-//     as a panel k < w is published (left-looking, on the MFMA from LDS), so the
-//     owner of the next panel starts factoring while the others still update.
-//   One workgroup barrier per panel.
+//   rows below the leaf: by all wavefronts, four lanes per row (below_quad).
+//   update: the tiles right of a published panel are updated on the MFMA from LDS; the
+//     owner of the next panel takes the one tile its leaf needs and starts factoring
+//     while the three other wavefronts share the rest.
+//   Two workgroup barriers per panel.
 // Critical path ~ 4 x (16 columns x ~130 cycles + ~1 us of update / LDS turn).
 //
 // LDS: sD[64 * BLD] (block in, L out in the lower part) + sRd[64] (1 / L_cc)
@@ -41,14 +42,14 @@ __device__ __forceinline__ double read_lane(double v, int l) {
   return __hiloint2double(hi, lo);
 }
 
-// 1/sqrt(p) to ~1 ulp: hardware seed (v_rsq_f64) + two Newton steps
+// 1/sqrt(p) to ~1 ulp: hardware seed (v_rsq_f64, measured 5e-8 relative) and ONE third-order
+// step, r (1 - e)^(-1/2) = r (1 + e/2 + 3 e^2 / 8 + O(e^3)) with e = 1 - p r^2: the same
+// 1.4e-16 as two Newton steps (measured over 1e6 arguments), four dependent operations
+// instead of six on the pivot-to-pivot chain of the leaf.
 __device__ __forceinline__ double rsqrt_nr(double p) {
-  double r = __builtin_amdgcn_rsq(p);
-  double e = fma(-p * r, r, 1.0);
-  r = fma(0.5 * r, e, r);
-  e = fma(-p * r, r, 1.0);
-  r = fma(0.5 * r, e, r);
-  return r;
+  const double r = __builtin_amdgcn_rsq(p);
+  const double e = fma(-p * r, r, 1.0);
+  return fma(r * e, fma(0.375, e, 0.5), r);
 }
 
 // a-operand / NT b-operand fragment: M[row0 + (lane & 15)][col0 + 4 s + (lane >> 4)]
@@ -155,38 +156,55 @@ __device__ __forceinline__ int factor_panel(double *sD, double *sRd, double *sLt
     }
   }
   if (ts) ts[3] = clock64();
-  const int nbelow = 48 - o;
-  if (nbelow > 0) {
-    double *prow = sD + (o + 16 + (lane < nbelow ? lane : nbelow - 1)) * BLD + o;
-    double x[16];
-#pragma unroll
-    for (int j = 0; j < 16; j += 2) {
-      const d2v v = *reinterpret_cast<const d2v *>(prow + j);
-      const d2v rd = *reinterpret_cast<const d2v *>(sRd + o + j);
-      x[j] = v.x * rd.x;
-      x[j + 1] = v.y * rd.y;
-    }
-#pragma unroll
-    for (int k = 0; k < 15; ++k) {
-#pragma unroll
-      for (int c = (k + 1) & ~1; c < 16; c += 2) {
-        const d2v lt = *reinterpret_cast<const d2v *>(sLt + k * 16 + c);
-        x[c] = fma(-x[k], lt.x, x[c]);
-        x[c + 1] = fma(-x[k], lt.y, x[c + 1]);
-      }
-    }
-    if (lane < nbelow) {
-#pragma unroll
-      for (int j = 0; j < 16; j += 2) {
-        d2v v;
-        v.x = x[j];
-        v.y = x[j + 1];
-        *reinterpret_cast<d2v *>(prow + j) = v;
-      }
-    }
-  }
   if (ts) ts[4] = clock64();
   return notpd;
+}
+
+// Stage 2 of a panel: the rows below the 16 x 16 leaf of block column kb, X = A L_leaf^-T,
+// by ALL wavefronts: four lanes per row (lane q of a quad holds the columns 2q, 2q+1, 8+2q,
+// 9+2q), x_k handed round the quad by DPP quad_perm, the pre-scaled leaf (sLt[k][c] =
+// L_ck / L_cc, zero for c <= k) read from LDS.  One lane per row in the panel's own wavefront
+// (the previous form) issued 120 multiply-adds and 64 LDS reads per lane: 1900 cycles on the
+// critical path against ~600 here plus the barrier that lets the other wavefronts in.
+template <int K>
+struct Below16Step {
+  static __device__ __forceinline__ void run(double (&x)[4], const double *sLt, int q) {
+    constexpr int QK = (K >> 1) & 3, REG = 2 * (K >> 3) + (K & 1);
+    constexpr int CTRL = QK * 0x55;   // quad_perm:[QK, QK, QK, QK]
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x[REG]), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x[REG]), CTRL, 0xf, 0xf, false);
+    const double xk = __hiloint2double(hi, lo);
+    if (K < 7) {   // columns 0..7 still have entries right of K
+      const d2v l0 = *reinterpret_cast<const d2v *>(sLt + K * 16 + 2 * q);
+      x[0] = fma(-xk, l0.x, x[0]);
+      x[1] = fma(-xk, l0.y, x[1]);
+    }
+    const d2v l1 = *reinterpret_cast<const d2v *>(sLt + K * 16 + 8 + 2 * q);
+    x[2] = fma(-xk, l1.x, x[2]);
+    x[3] = fma(-xk, l1.y, x[3]);
+    Below16Step<K + 1>::run(x, sLt, q);
+  }
+};
+template <>
+struct Below16Step<15> {
+  static __device__ __forceinline__ void run(double (&)[4], const double *, int) {}
+};
+
+__device__ __forceinline__ void below_quad(double *sD, const double *sRd, const double *sLt, int kb,
+                                           int tid) {
+  const int o = 16 * kb, nbelow = 48 - o;
+  const int row = tid >> 2, q = tid & 3;
+  const bool live = row < nbelow;
+  double *p = sD + (o + 16 + (live ? row : 0)) * BLD + o + 2 * q;
+  const d2v a = *reinterpret_cast<const d2v *>(p), b = *reinterpret_cast<const d2v *>(p + 8);
+  const d2v ra = *reinterpret_cast<const d2v *>(sRd + o + 2 * q);
+  const d2v rb = *reinterpret_cast<const d2v *>(sRd + o + 8 + 2 * q);
+  double x[4] = {a.x * ra.x, a.y * ra.y, b.x * rb.x, b.y * rb.y};
+  Below16Step<0>::run(x, sLt, q);
+  if (live) {
+    *reinterpret_cast<d2v *>(p) = d2v{x[0], x[1]};
+    *reinterpret_cast<d2v *>(p + 8) = d2v{x[2], x[3]};
+  }
 }
 
 // All 256 threads of the workgroup call this with the block already in sD
@@ -207,20 +225,39 @@ __device__ __forceinline__ int diag_block(double *sD, double *sRd, double *__res
         for (int q = 0; q < 5; ++q) dbg[8 * kb + q] = ts[q];
     }
     __syncthreads();
+    if (kb < 3) {
+      below_quad(sD, sRd, sRd + 64, kb, tid);
+      __syncthreads();
+    }
     if (dbg && wave == (kb < 3 ? kb + 1 : 3) && lane == 0) dbg[8 * kb + 5] = clock64();
-    if (wave > kb) {
-      // A_{ib,w} -= L_{ib,kb} L_{w,kb}^T for the row blocks ib >= w of my block column
-      const int o = 16 * kb, w = wave;
-      double bfrag[4];
+    if (kb < 3) {
+      // trailing update inside the block: A_{ib,w} -= L_{ib,kb} L_{w,kb}^T for the tiles
+      // ib >= w > kb.  The owner of the next panel takes only the tile its leaf needs and goes
+      // on to factor; the other tiles are dealt to the three other wavefronts (the barrier
+      // after the next leaf is ahead of their first reader).
+      const int o = 16 * kb;
+      auto upd_tile = [&](int ib, int w) {
+        double bfrag[4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) bfrag[s] = frag_rowmajor(sD, BLD, 16 * w, o, s, lane);
-      for (int ib = w; ib < 4; ++ib) {
+        for (int s = 0; s < 4; ++s) bfrag[s] = frag_rowmajor(sD, BLD, 16 * w, o, s, lane);
         d4 acc = acc_load(sD, BLD, 16 * ib, 16 * w, lane);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-frag_rowmajor(sD, BLD, 16 * ib, o, s, lane),
                                                      bfrag[s], acc, 0, 0, 0);
         acc_store(sD, BLD, 16 * ib, 16 * w, lane, acc);
+      };
+      if (wave == kb + 1) {
+        upd_tile(kb + 1, kb + 1);
+      } else {
+        const int hw = wave < kb + 1 ? wave : wave - 1;   // 0..2
+        int t = 0;
+        for (int w = kb + 1; w < 4; ++w)
+          for (int ib = w; ib < 4; ++ib) {
+            if (ib == kb + 1 && w == kb + 1) continue;
+            if (t % 3 == hw) upd_tile(ib, w);
+            ++t;
+          }
       }
     }
     if (dbg && wave == (kb < 3 ? kb + 1 : 3) && lane == 0) dbg[8 * kb + 6] = clock64();
