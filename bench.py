@@ -170,14 +170,20 @@ def main():
     if world == 1:
         t_h, f_h = t_d.cpu().pin_memory(), f_d.cpu().pin_memory()
         out_h = torch.empty(S, dtype=torch.float64).pin_memory()
-        nrep = max(3, min(10, args.steps))
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(nrep):
+        nrep = max(3, min(20, args.steps))
+
+        def fed_step():
             t_d.copy_(t_h, non_blocking=True)
             f_d.copy_(f_h, non_blocking=True)
             step()
             out_h.copy_(out, non_blocking=True)
+
+        for _ in range(2):          # first use of the pinned buffers maps them (tens of ms, once)
+            fed_step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(nrep):
+            fed_step()
         torch.cuda.synchronize()
         pcie_rate = S * nrep / (time.perf_counter() - t1)
 
