@@ -16,6 +16,12 @@ One "step" = one hyperparameter sample of an MCMC / nested-sampling loop:
   -> covariance assembly + Cholesky + solve + reduction for every star
                                             (sp_lnlike_ensemble)
   -> N > 1: RCCL all-gather of the per-star log-likelihoods (torch.distributed).
+Consecutive steps are independent samples (the walkers / live points a sampler
+evaluates per iteration), so --in-flight F of them (default 3) are kept in flight:
+step i runs on stream i mod F with its own library handle, workspace and outputs.
+The latency-bound phases of one step (diagonal blocks, panel solves) then overlap
+the throughput-bound phases of its neighbours (assembly, trailing updates); every
+step still does all of its work, and K steps are timed between the same barriers.
 All inputs are resident in HBM when the timed region starts.  (mu_y, Sigma_y) come
 from tests/golden (the upstream integrals are outside the hot path).
 
@@ -81,6 +87,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--in-flight", type=int, default=3,
+                    help="independent steps kept in flight on separate streams / handles")
     ap.add_argument("--cpu-stars", type=int, default=128)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -106,7 +114,7 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from starry_process_amd.engine import get_engine, make_stars
+    from starry_process_amd.engine import engine_slots, get_engine, make_stars
     from starry_process_amd.synthetic import synthetic_star
 
     mom = np.load(os.path.join(ROOT, "tests", "golden", "moments_L15.npz"))
@@ -121,48 +129,86 @@ def main():
     stars_d = e.stars_to_device(make_stars(S, period=[s["p"] for s in sts], data_var=1e-6))
     mu_d, Sig_d = e.f64(mu), e.f64(Sig)
     rta1_d = e.f64(e.rTA1L([0.0, 0.0]))          # one flux operator: u = [0, 0]
-    ws = e.workspace(S, K, 1)
-    out = e.empty(S)
-    status = torch.zeros(S, dtype=torch.int32, device=e.device)
-    gathered = e.empty(world * S) if use_dist else None
 
-    def step():
-        e.set_moments_dev(mu_d, Sig_d)
-        tab, mv = e.kernel_table(rta1_d, COVPTS)
-        e.lnlike_ensemble(t_d, f_d, stars_d, covpts=COVPTS, tab=tab, meanvar=mv,
-                          normalized=True, out=out, status=status, workspace=ws)
+    # one slot per step in flight: library handle, stream, workspace, outputs (the inputs
+    # above are read-only and shared)
+    F = max(1, args.in_flight)
+    slots = []
+    for ek, stream in engine_slots(YDEG, UDEG, local_rank, F):
+        ek.set_moments(mu, Sig)  # first call allocates / uploads the lag grid
+        slots.append(dict(e=ek, stream=stream, ws=ek.workspace(S, K, 1),
+                          out=ek.empty(S), status=torch.zeros(S, dtype=torch.int32, device=ek.device),
+                          gathered=ek.empty(world * S) if use_dist else None))
+    torch.cuda.synchronize()
+
+    def run_step(c):
+        ek = c["e"]
+        ek.set_moments_dev(mu_d, Sig_d)
+        tab, mv = ek.kernel_table(rta1_d, COVPTS)
+        ek.lnlike_ensemble(t_d, f_d, stars_d, covpts=COVPTS, tab=tab, meanvar=mv,
+                           normalized=True, out=c["out"], status=c["status"], workspace=c["ws"])
         if use_dist:
-            dist.all_gather_into_tensor(gathered, out)
-            return gathered.sum()
-        return out.sum()
+            dist.all_gather_into_tensor(c["gathered"], c["out"])
+            return c["gathered"].sum()
+        return c["out"].sum()
 
-    e.set_moments(mu, Sig)  # first call allocates / uploads the lag grid
+    def step(i=0):
+        c = slots[i % F]
+        with torch.cuda.stream(c["stream"]):
+            return run_step(c)
+
     if use_dist:
         # communicator set-up (lazy in RCCL) must not land in the timed region even with --warmup 0
-        dist.all_gather_into_tensor(gathered, out)
-    for _ in range(args.warmup):
-        step()
+        dist.all_gather_into_tensor(slots[0]["gathered"], slots[0]["out"])
+    for i in range(max(args.warmup, F if args.warmup else 0)):
+        step(i)
     nsyrk = (K + 63) // 64  # upper bound on timed launches per step
-    e.profile_begin(args.steps * nsyrk)
+    for c in slots:
+        c["e"].profile_begin((args.steps // F + 1) * nsyrk)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        total = step()
+    for i in range(args.steps):
+        total = step(i)
     host_enqueue = time.perf_counter() - t0
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    launches, kern_ms, kern_flops = e.profile_end()
+    launches, kern_ms, kern_flops = 0, 0.0, 0.0
+    for c in slots:
+        a, b, f = c["e"].profile_end()
+        launches, kern_ms, kern_flops = launches + a, kern_ms + b, kern_flops + f
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=e.device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # the same steps one at a time on one stream (not `value`): what a strictly sequential
+    # caller gets, and the trailing update's rate when it has the GPU to itself
+    one = None
+    if world == 1:
+        c0 = slots[0]
+        nrep = max(10, min(50, args.steps))
+        for _ in range(5):
+            run_step(c0)
+        c0["e"].profile_begin(nrep * nsyrk)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(nrep):
+            run_step(c0)
+        torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t1
+        a, b, f = c0["e"].profile_end()
+        one = {"evals_per_s": S * nrep / dt1, "ms_per_step": 1e3 * dt1 / nrep,
+               "trailing_update_TFLOPs": (f / (b * 1e-3)) / 1e12 if b > 0 else 0.0}
+        one["trailing_update_frac"] = one["trailing_update_TFLOPs"] / FP64_PEAK_TFLOPS
+
+    out, status = slots[0]["out"], slots[0]["status"]
+    slots_agree = all(torch.equal(c["out"], out) for c in slots[1:])   # same inputs, same bits
     lnl = out.cpu().numpy()
-    ok = bool(np.all(np.isfinite(lnl))) and not bool(status.cpu().numpy().any())
+    ok = bool(np.all(np.isfinite(lnl))) and not bool(status.cpu().numpy().any()) and slots_agree
 
     # PCIe-inclusive rate (never `value`): the same step fed from pinned host buffers
     # (t, flux up, log-likelihoods down) -- what a caller without resident data would see
@@ -175,7 +221,7 @@ def main():
         def fed_step():
             t_d.copy_(t_h, non_blocking=True)
             f_d.copy_(f_h, non_blocking=True)
-            step()
+            run_step(slots[0])
             out_h.copy_(out, non_blocking=True)
 
         for _ in range(2):          # first use of the pinned buffers maps them (tens of ms, once)
@@ -234,8 +280,11 @@ def main():
                 "workload": "cfg3: ydeg=15, K=1000, 64 stars per GPU batched, marginalize_over_inclination, "
                             "normalized, covpts=300 (cfg4 = the same at 8 GPUs: 512 stars, RCCL all-gather)",
                 "stars_per_gpu": S, "ydeg": YDEG, "K": K, "parallelism": "stars sharded %d-way" % world,
+                "steps_in_flight": F,
             },
             "parity_ok": ok,
+            "steps_in_flight": F,
+            "one_step_at_a_time": one,
             "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
             "pcie_inclusive_evals_per_s": pcie_rate,
             "upstream_ms_per_sample": upstream_ms,
@@ -250,6 +299,13 @@ def main():
                 "launches": launches,
                 "avg_launch_ms": kern_ms / max(launches, 1),
                 "algorithmic_flops_per_launch": kern_flops / max(launches, 1),
+                # with F > 1 the launches of F steps share the GPU: a launch's duration then
+                # includes the time its workgroups wait for CUs held by the other steps' kernels,
+                # and `frac` is that launch's share of the machine, not the kernel's efficiency;
+                # the same kernel with the GPU to itself (one step at a time, measured in this run):
+                "steps_in_flight": F,
+                "frac_alone": one["trailing_update_frac"] if one else None,
+                "achieved_alone": one["trailing_update_TFLOPs"] if one else None,
             },
         }
         if not args.no_cpu and world == 1:   # reported at N = 1 only (rank 0 would hold the others up)

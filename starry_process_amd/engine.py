@@ -416,6 +416,24 @@ class Engine(object):
 _engines = {}
 
 
+def engine_slots(ydeg=15, udeg=2, device=None, depth=3):
+    """``depth`` independent (Engine, torch.cuda.Stream) pairs on one GPU, for keeping several
+    INDEPENDENT evaluations in flight (the walkers / live points a sampler evaluates per
+    iteration): run evaluation i inside ``with torch.cuda.stream(stream_i)`` on ``engine_i``,
+    each with its own workspace and outputs.  One evaluation alone leaves most of the GPU idle
+    during its latency-bound phases (diagonal blocks, panel solves); with three in flight those
+    overlap the neighbours' assembly and trailing updates: 1.02 -> 0.75 ms per 64-star step
+    (bench.py).  A handle is not re-entrant, hence one per slot; slot 0 is the
+    process-wide engine of ``get_engine``."""
+    torch = _torch()
+    first = get_engine(ydeg, udeg, device)
+    out = []
+    for k in range(max(1, int(depth))):
+        e = first if k == 0 else Engine(first.ydeg, first.udeg, first.device_index)
+        out.append((e, torch.cuda.Stream(device=e.device)))
+    return out
+
+
 def get_engine(ydeg=15, udeg=2, device=None):
     """Process-wide engine cache keyed by (ydeg, udeg, device)."""
     torch = _torch()

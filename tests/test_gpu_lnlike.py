@@ -277,3 +277,45 @@ def test_beyond_one_lds_pass_of_columns(eng):
         v = float(StarryProcess(ydeg=15, mean_ylm=mu, cov_ylm=Sig, **kw).log_likelihood(t, flux, 1e-6, p=1.7))
         r = float(orc.OracleProcess(mu, Sig, ydeg=15, **okw).log_likelihood(t, flux, 1e-6, p=1.7))
         assert abs(v - r) < 1e-8 * abs(r), (v, r)
+
+
+def test_steps_in_flight(eng):
+    """engine_slots: three independent evaluations enqueued on three (handle, stream) pairs before
+    anything is synchronised give, each, exactly the bits of the same evaluation run alone."""
+    import torch
+    from starry_process_amd.engine import engine_slots, make_stars
+
+    S, K = 8, 300
+    mom = golden("moments_L15")
+    slots = engine_slots(15, 2, None, 3)
+    assert slots[0][0] is eng(15) and len({id(e) for e, _ in slots}) == 3
+    sts = [synthetic_star(s, K) for s in range(S)]
+    e0 = slots[0][0]
+    t_d = e0.f64(np.array([s["t"] for s in sts]))
+    f_d = e0.f64(np.array([s["flux"] for s in sts])[:, None, :])
+    stars = e0.stars_to_device(make_stars(S, period=[s["p"] for s in sts], data_var=1e-6))
+    rta1 = e0.f64(e0.rTA1L([0.0, 0.0]))
+    sets = [("default", 1.0), ("hilat", 1.0), ("spread", 1.0)]
+    torch.cuda.synchronize()
+
+    def evaluate(e, name, out):
+        e.set_moments(mom[name + "_mean_ylm"], mom[name + "_cov_ylm"])
+        tab, mv = e.kernel_table(rta1, 300)
+        e.lnlike_ensemble(t_d, f_d, stars, covpts=300, tab=tab, meanvar=mv, normalized=True, out=out,
+                          workspace=e.workspace(S, K, 1))
+
+    alone = []
+    for name, _ in sets:
+        out = e0.empty(S)
+        evaluate(e0, name, out)
+        torch.cuda.synchronize()
+        alone.append(out.clone())
+    outs = [e.empty(S) for e, _ in slots]
+    for rep in range(3):
+        for (e, stream), (name, _), out in zip(slots, sets, outs):
+            with torch.cuda.stream(stream):
+                evaluate(e, name, out)
+    torch.cuda.synchronize()
+    for a, b in zip(alone, outs):
+        assert torch.equal(a, b)
+    assert len({float(a[0]) for a in alone}) == 3          # three different processes
