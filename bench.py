@@ -206,7 +206,8 @@ def main():
         one["trailing_update_frac"] = one["trailing_update_TFLOPs"] / FP64_PEAK_TFLOPS
 
     out, status = slots[0]["out"], slots[0]["status"]
-    slots_agree = all(torch.equal(c["out"], out) for c in slots[1:])   # same inputs, same bits
+    nran = min(F, args.steps + (max(args.warmup, F) if args.warmup else 0))   # slots that ran
+    slots_agree = all(torch.equal(c["out"], out) for c in slots[1:nran])   # same inputs, same bits
     lnl = out.cpu().numpy()
     ok = bool(np.all(np.isfinite(lnl))) and not bool(status.cpu().numpy().any()) and slots_agree
 
