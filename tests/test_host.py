@@ -135,3 +135,51 @@ def test_bad_arguments_are_rejected():
     assert L.sp_create(0, 2, -1, ctypes.byref(h)) == -1
     assert L.sp_create(15, 9, -1, ctypes.byref(h)) == -1
     assert L.sp_index_tables(-1, None, None, None, None, None) == -1
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/starry_process_amd.h is the drop-in boundary: it must compile as C (no C++, no
+    torch types) and a C program must be able to link libsp_hip.so and call it.  Only host
+    entry points are exercised (no GPU here)."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if gcc is None or not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("needs gcc and the built library")
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "starry_process_amd.h"
+int main(void) {
+  int32_t l_of[36], m_of[36], mirror[36], m0[6], blk[7];
+  if (sp_version() <= 0) return 1;
+  if (sp_index_tables(5, l_of, m_of, mirror, m0, blk) != 0) return 2;
+  if (l_of[35] != 5 || m_of[35] != 5 || m0[5] != 30) return 3;
+  double al, be, dal, dbe;
+  if (sp_alpha_beta(1e-3, 20, &al, &be, &dal, &dbe) != 0) return 4;
+  sp_handle *h = 0;
+  if (sp_create(5, 2, -1, &h) != 0) return 5;          /* host-only handle */
+  double r[36];
+  if (sp_rTA1(h, r) != 0) return 6;
+  if (sp_lnlike_workspace_bytes(h, 1, 10, 1) <= 0) return 7;
+  sp_star st = {1.0, 0.5, 0.0, 0.0, 0.0, 1e-6, 0, 0};
+  if (sizeof(st) != 56) return 8;
+  sp_destroy(h);
+  printf("abi ok %d %.17g %.17g\n", sp_version(), al, r[0]);
+  return 0;
+}
+''')
+    exe = tmp_path / "abi"
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    cmd = [gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", inc, str(src), "-o", str(exe),
+           "-L", libdir, "-l:libsp_hip.so", "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined"]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    env = dict(os.environ)
+    import torch
+
+    tl = os.path.join(os.path.dirname(torch.__file__), "lib")
+    env["LD_LIBRARY_PATH"] = tl + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True, env=env, timeout=120)
+    assert out.stdout.startswith("abi ok")
