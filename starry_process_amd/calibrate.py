@@ -16,12 +16,17 @@ callable (log_prob.py:93-102):  [flux,] r, a, b, c, n [, m] [, v] [, i].
 ``get_log_prob_ensemble`` is the per-star generalisation (own period /
 inclination / limb darkening / noise per light curve, one covariance each),
 sharded over the ranks of a ``torch.distributed`` job when one is initialised.
+
+``EnsembleLogProb`` is the same quantity for MANY hyperparameter samples at once
+(the positions of all walkers / live points of an iteration -- emcee's
+``vectorize=True``): the data stay on the GPU, the moments come from the device
+upstream, and ``depth`` samples are kept in flight on separate streams.
 """
 import numpy as np
 
 from .sp import StarryProcess
 
-__all__ = ["get_log_prob", "get_log_prob_ensemble"]
+__all__ = ["get_log_prob", "get_log_prob_ensemble", "EnsembleLogProb"]
 
 
 def get_log_prob(
@@ -117,3 +122,107 @@ def get_log_prob_ensemble(
         return ll + float(sp.log_jac()) if apply_jac else ll
 
     return log_prob
+
+
+class EnsembleLogProb(object):
+    """log_prob for a batch of hyperparameter samples, same value per sample as
+    ``get_log_prob_ensemble(..., upstream="device")``.
+
+        lp = EnsembleLogProb(t, flux, ferr=1e-3, p=periods)          # data -> GPU, once
+        values = lp(samples)                                          # samples (n, 5): r, a, b, c, n
+
+    Per sample: moments by quadrature on the device (upstream_device.py) -> kernel table ->
+    one batched likelihood call for this rank's stars; nothing is copied back or synchronised
+    until every sample is enqueued, and sample k runs on stream k mod ``depth`` with its own
+    library handle and workspace (engine.engine_slots), so that the latency-bound phases of
+    one sample overlap the throughput-bound phases of its neighbours.  Under an initialised
+    ``torch.distributed`` job the stars are sharded over the ranks and the per-sample sums are
+    combined with ONE all-reduce for the whole batch."""
+
+    def __init__(self, t, flux, ferr=1.0e-3, p=1.0, i=None, u=None, ydeg=15, baseline_log_var=0.0,
+                 baseline_mean=0.0, apply_jac=True, normalized=True,
+                 marginalize_over_inclination=True, covpts=None, device=None, depth=3):
+        import torch
+        import torch.distributed as dist
+
+        from . import ensemble
+        from .defaults import defaults
+        from .engine import engine_slots, make_stars
+
+        flux = np.asarray(flux, dtype=np.float64)
+        if flux.ndim != 2:
+            raise ValueError("flux must be (S, K); ragged ensembles: get_log_prob_ensemble")
+        S, K = flux.shape
+        self._dist = dist.is_available() and dist.is_initialized()
+        rank, world = (dist.get_rank(), dist.get_world_size()) if self._dist else (0, 1)
+        lo, hi = ensemble.shard_bounds(S, rank, world)
+        self.S, self.K, self._n_local = S, K, hi - lo
+        udeg = defaults["udeg"]
+        t = np.asarray(t, dtype=np.float64)
+        t = np.broadcast_to(t, (S, K)) if t.ndim == 1 else t
+        per = lambda x, d: np.broadcast_to(np.asarray(d if x is None else x, dtype=np.float64), (S,))[lo:hi]
+        pp, ii = per(p, defaults["p"]), per(i, defaults["i"])
+        if np.any(pp < -1e-6):
+            raise ValueError("p out of bounds")
+        if np.any(ii * np.pi / 180 < -1e-6) or np.any(ii * np.pi / 180 > 0.5 * np.pi + 1e-6):
+            raise ValueError("i out of bounds")
+        uu = np.asarray(defaults["u"][:udeg] if u is None else u, dtype=np.float64)
+        if uu.ndim == 1:
+            utab, table = uu[None, :udeg], np.zeros(hi - lo, dtype=np.int32)
+        else:
+            utab, table = np.unique(uu[lo:hi, :udeg], axis=0, return_inverse=True)
+            table = table.astype(np.int32).reshape(-1)
+        stars = make_stars(hi - lo, period=pp, inc_deg=ii, tau=0.0,
+                           baseline_var=np.full(hi - lo, 10.0 ** baseline_log_var),
+                           baseline_mean=per(baseline_mean, 0.0),
+                           data_var=per(np.asarray(ferr, dtype=np.float64) ** 2, 1.0), table=table)
+        self._slots = engine_slots(ydeg, udeg, device, depth)
+        e0 = self._slots[0][0]
+        self._t = e0.f64(np.ascontiguousarray(t[lo:hi]))
+        self._flux = e0.f64(np.ascontiguousarray(flux[lo:hi, None, :]))
+        self._stars = e0.stars_to_device(stars)
+        self._rta1 = e0.f64(e0.rTA1L(utab))
+        self._ws = [e.workspace(max(hi - lo, 1), K, 1) for e, _ in self._slots]
+        self._kw = dict(conditional=not marginalize_over_inclination, normalized=bool(normalized),
+                        covpts=defaults["covpts"] if covpts is None else int(covpts))
+        self._marg = bool(marginalize_over_inclination)
+        self._ydeg, self._apply_jac = int(ydeg), bool(apply_jac)
+        torch.cuda.synchronize(e0.device)
+
+    def __call__(self, samples):
+        import torch
+        import torch.distributed as dist
+
+        from .upstream import log_jac
+        from .upstream_device import ylm_moments_device
+
+        samples = np.atleast_2d(np.asarray(samples, dtype=np.float64))
+        if samples.shape[1] != 5:
+            raise ValueError("samples must be (n, 5): r, a, b, c, n")
+        ns, nl = samples.shape[0], self._n_local
+        e0 = self._slots[0][0]
+        outs = e0.empty(ns, max(nl, 1))
+        torch.cuda.synchronize(e0.device)
+        if nl:
+            for k, (r, a, b, c, n) in enumerate(samples):
+                e, stream = self._slots[k % len(self._slots)]
+                with torch.cuda.stream(stream):
+                    mean, cov = ylm_moments_device(e, r=r, a=a, b=b, c=c, n=n)
+                    e.set_moments_dev(mean, cov)
+                    tab = mv = None
+                    if self._marg:
+                        tab, mv = e.kernel_table(self._rta1, self._kw["covpts"])
+                    e.lnlike_ensemble(self._t, self._flux, self._stars, tab=tab, meanvar=mv,
+                                      rta1=self._rta1, out=outs[k], workspace=self._ws[k % len(self._slots)],
+                                      **self._kw)
+        torch.cuda.synchronize(e0.device)
+        vals = outs[:, :nl]
+        vals = torch.where(torch.isnan(vals), torch.full_like(vals, -float("inf")), vals)
+        total = vals.sum(dim=1)
+        if self._dist:
+            # -inf + finite = -inf survives the sum; a NaN cannot appear (no +inf terms)
+            dist.all_reduce(total, op=dist.ReduceOp.SUM)
+        total = total.cpu().numpy()
+        if self._apply_jac:
+            total = total + np.array([float(log_jac(a, b)) for _, a, b, _, _ in samples])
+        return total

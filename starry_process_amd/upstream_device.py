@@ -82,10 +82,17 @@ def ylm_moments_device(engine, r=defaults["r"], dr=defaults["dr"], a=defaults["a
     Rphi, _ = e.Rx(phi, deriv=False)
     V = e.dotRx(M0, Rphi)                                                # [P, mv, N]
     # rotation about y by lambda_q:  Rx(pi/2), Rz(lambda), Rx(-pi/2)
-    Rq, _ = e.Rx(np.array([0.5 * np.pi, -0.5 * np.pi]), deriv=False)
+    Rq = getattr(e, "_Rx_quarter_turns", None)          # constant: once per engine
+    if Rq is None:
+        Rq, _ = e.Rx(np.array([0.5 * np.pi, -0.5 * np.pi]), deriv=False)
+        e._Rx_quarter_turns = Rq
     U = e.dotRx(V.reshape(P * mv, N), Rq[0])                             # [P mv, N]
     U = U.unsqueeze(0).expand(Q, P * mv, N).reshape(Q * P * mv, N).contiguous()
-    th = e.f64(np.repeat(lam, P * mv))
+    key = (P * mv, Q)
+    cache = e.__dict__.setdefault("_lam_rows", {})
+    th = cache.get(key)                                   # the longitudes, row by row: constant
+    if th is None:
+        th = cache[key] = e.f64(np.repeat(lam, P * mv))
     U = e.tensordotRz(U, th)
     A = e.dotRx(U, Rq[1]).reshape(Q, P, mv, N)                           # g sqrt(W) Ry Rx v
     # first moment: sum_k W_k (.) = sum_k sqrt(W_k) (sqrt(W_k) row)

@@ -405,3 +405,32 @@ def test_lnlike_array(marginalize_over_inclination):
                                                               i=defaults["i"]))
     assert np.isfinite(np.nanmax(ll))
     assert abs(b_arr[np.nanargmax(ll)] - defaults["b"]) < 0.10
+
+
+def test_ensemble_log_prob_many_samples():
+    """calibrate.EnsembleLogProb (data resident, samples in flight on separate streams) gives,
+    sample by sample, the value of get_log_prob_ensemble(upstream="device")."""
+    from starry_process_amd.calibrate import EnsembleLogProb, get_log_prob_ensemble
+
+    S, K = 6, 150
+    sts = [synthetic_star(s, K) for s in range(S)]
+    t = np.array([s["t"] for s in sts])
+    flux = np.array([s["flux"] for s in sts])
+    p = np.array([s["p"] for s in sts])
+    inc = np.linspace(30.0, 80.0, S)
+    samples = np.array([[20.0, 0.40, 0.27, 0.10, 10.0], [15.0, 0.62, 0.11, 0.20, 5.0],
+                        [25.0, 0.30, 0.50, 0.05, 20.0], [12.0, 0.10, 0.90, 0.15, 3.0],
+                        [20.0, 0.40, 0.27, 0.10, 10.0], [30.0, 0.80, 0.05, 0.02, 40.0],
+                        [18.0, 0.55, 0.35, 0.12, 8.0]])
+    for kw in (dict(), dict(marginalize_over_inclination=False, normalized=False, i=inc)):
+        one = get_log_prob_ensemble(t, flux, ferr=1e-3, p=p, upstream="device", **kw)
+        many = EnsembleLogProb(t, flux, ferr=1e-3, p=p, depth=3, **kw)
+        ref = np.array([one(*s) for s in samples])
+        got = many(samples)
+        assert got.shape == (len(samples),)
+        fin = np.isfinite(ref)                        # (z > zmax or a failed factorisation: -inf)
+        assert fin.sum() >= 4 and np.array_equal(fin, np.isfinite(got))
+        assert np.array_equal(got[~fin], ref[~fin])
+        assert np.abs(got[fin] - ref[fin]).max() < 1e-12 * np.abs(ref[fin]).max()
+        assert got[0] == got[4]                       # same sample on different slots: same bits
+        assert np.abs(many(samples[:2]) - ref[:2]).max() < 1e-12 * np.abs(ref[:2]).max()
