@@ -247,6 +247,16 @@ int sp_cholesky_rev(sp_handle *h, const double *L_dev, int K, long ldl,
                     long strideL, const double *Lbar_dev, int batch,
                     double *Cbar_dev, void *stream);
 
+/* How the blocked factorisation spends its launches (both give the same factor to rounding):
+ *   0 (default)  two launches per 64-column panel -- the shortest critical path: for ONE
+ *                evaluation at a time;
+ *   1            one launch per panel (update + solve + next diagonal block together): a
+ *                longer critical path but 18 % fewer bytes through HBM -- for several
+ *                independent evaluations in flight on separate handles / streams, where the
+ *                GPU is saturated and traffic is what counts.
+ * The environment variable SP_ONELAUNCH sets the initial value.                          */
+int sp_set_panel_mode(sp_handle *h, int one_launch);
+
 /* ---- a16-a19 + fused driver: log-likelihood of an ensemble ---------------- */
 /* Size in bytes of the device workspace sp_lnlike_ensemble needs.            */
 long sp_lnlike_workspace_bytes(sp_handle *h, int S, int K, int M);

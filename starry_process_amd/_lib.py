@@ -98,6 +98,7 @@ PROTOTYPES = {
     "sp_tri_solve": (_I, [_V, _V, _I, _L, _L, _V, _I, _I, _I, _V]),
     "sp_solve_rev": (_I, [_V, _V, _I, _L, _L, _V, _V, _I, _I, _I, _V, _V, _V]),
     "sp_cholesky_rev": (_I, [_V, _V, _I, _L, _L, _V, _I, _V, _V]),
+    "sp_set_panel_mode": (_I, [_V, _I]),
     "sp_lnlike_workspace_bytes": (_L, [_V, _I, _I, _I]),
     "sp_lnlike_ensemble": (
         _I, [_V, _I, _I, _I, _V, _V, _V, _V, _I, _I, _V, _V, _V, _I, _I, _I, _D,

@@ -445,6 +445,8 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
     h->fuse_diag = e4 ? atoi(e4) : 2;  // 0 off, 1 block-column updates, 2 + bulk updates
     const char *e5 = getenv("SP_EAGER");
     h->eager = e5 ? atoi(e5) : 1;
+    const char *e7 = getenv("SP_ONELAUNCH");
+    h->onelaunch = e7 ? atoi(e7) : 0;
     const char *e3 = getenv("SP_GROUPS");
     h->groups = e3 ? atoi(e3) : 1;
     const char *e2 = getenv("SP_SUPER");
@@ -848,6 +850,13 @@ int sp_cholesky_rev(sp_handle *h, const double *L_dev, int K, long ldl, long str
   if ((rc = sp_launch_tri_solve(L_dev, K, ldl, strideL, P, kk, 1, K, K, batch, 2, st))) return rc;
   if ((rc = sp_launch_tri_solve(L_dev, K, ldl, strideL, P, kk, K, 1, K, batch, 2, st))) return rc;
   return sp_launch_chol_rev_finish(P, L_dev, ldl, strideL, Cbar_dev, K, batch, st);
+}
+
+int sp_set_panel_mode(sp_handle *h, int one_launch) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || (one_launch != 0 && one_launch != 1)) return SP_ERR_INVALID;
+  h->onelaunch = one_launch;
+  return SP_OK;
 }
 
 long sp_lnlike_workspace_bytes(sp_handle *h, int S, int K, int M) {

@@ -424,7 +424,8 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, double *sink,
 // same rows; lower-triangle tiles only.  Timed for bench.py when profiling is on.
 static int bulk_update(sp_handle *h, double *sys, long ld, long stride, int S, int c0,
                        int cfrom, int Kp, int kd, hipStream_t st, int fuse_nact = 0,
-                       double *invL = nullptr, int32_t *info = nullptr, int skip00 = 0) {
+                       double *invL = nullptr, int32_t *info = nullptr, int skip00 = 0,
+                       int skip_tile00 = 0) {
   // fuse_nact > 0: tile (0, 0) is the diagonal block of the next panel and its
   // workgroup factors it on the spot (hidden behind the other tiles)
   const int n = Kp - cfrom;
@@ -436,7 +437,7 @@ static int bulk_update(sp_handle *h, double *sys, long ld, long stride, int S, i
                ? sp_launch_gemm_nt_diag(X, ld, stride, X, ld, stride, T, ld, stride, n, n, kd,
                                         -1.0, 1, S, fuse_nact, invL, info, st, skip00)
                : sp_launch_gemm_nt(X, ld, stride, X, ld, stride, T, ld, stride, n, n, kd, -1.0,
-                                   1, 1, S, st);
+                                   1, 1, S, st, skip_tile00);
   if (rc != SP_OK) return rc;
   if (timed) {
     SP_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
@@ -497,6 +498,62 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
   // measured with the eager diagonal updates: K = 1000 (16 panels) w = 2 / 4 / 6 / 8 /
   // 12 / 16 -> 1.17 / 1.10 / 1.085 / 1.08 / 1.12 / 1.14 ms per step; K = 3000 (47 panels): 8 best as well
   const int w = (h && h->superpanel > 0) ? h->superpanel : (nsteps >= 16 ? 8 : 4);
+  if (h && h->onelaunch && h->fuse_diag > 1 && h->eager) {
+    // ONE launch per panel (sp_launch_panel): update + solve + eager diagonal updates + the
+    // next diagonal block; the L_d^T images ping-pong between the two slots of a star
+    for (int g = 0; g < ngroups; ++g) {
+      const sp_chol_group &G = grp[g];
+      hipLaunchKernelGGL(diag_kernel<false>, dim3(G.S), dim3(256), 0, G.st, G.sys, ld, stride, 0,
+                         K < SP_NB ? K : SP_NB, G.invL, G.info, nullptr);
+      SP_LAUNCH_CHECK();
+    }
+    for (int s0 = 0; s0 < nsteps; s0 += w) {
+      const int cS = s0 * SP_NB;
+      for (int q = 0; q < w && s0 + q < nsteps; ++q) {
+        const int j = s0 + q, c0 = j * SP_NB;
+        const int nact = K - c0 < SP_NB ? K - c0 : SP_NB;
+        const int r1 = c0 + nact;
+        int last = s0 + w;
+        if (last > nsteps - 1) last = nsteps - 1;
+        const int neager = last > j ? last - j : 0;
+        const int c1 = c0 + SP_NB;
+        const int next_nact = (j + 1 < nsteps) ? (K - c1 < SP_NB ? K - c1 : SP_NB) : 0;
+        for (int g = 0; g < ngroups; ++g) {
+          const sp_chol_group &G = grp[g];
+          const double *lt_in = G.invL + (size_t)(j & 1) * SP_LT_IMG;
+          double *lt_out = G.invL + (size_t)((j + 1) & 1) * SP_LT_IMG;
+          int rc;
+          if (nact < SP_NB) {
+            // partial last block: the rows of its own diagonal tile below the active ones
+            // (residual rows, padding) already carry every update -- the eager updates cover
+            // the whole tile -- and are only solved; the rows beyond the tile get the product
+            rc = sp_launch_panel(G.sys + (size_t)r1 * ld + cS, ld, G.sys + (size_t)c0 * ld + cS, ld,
+                                 G.sys + (size_t)r1 * ld + c0, ld, stride, c1 - r1, 0, G.S, lt_in,
+                                 lt_out, 0, 0, G.info, G.st);
+            if (rc != SP_OK) return rc;
+            rc = sp_launch_panel(G.sys + (size_t)c1 * ld + cS, ld, G.sys + (size_t)c0 * ld + cS, ld,
+                                 G.sys + (size_t)c1 * ld + c0, ld, stride, Kp - c1, q * SP_NB, G.S,
+                                 lt_in, lt_out, 0, 0, G.info, G.st);
+          } else {
+            rc = sp_launch_panel(G.sys + (size_t)r1 * ld + cS, ld, G.sys + (size_t)c0 * ld + cS, ld,
+                                 G.sys + (size_t)r1 * ld + c0, ld, stride, Kp - r1, q * SP_NB, G.S,
+                                 lt_in, lt_out, neager, next_nact, G.info, G.st);
+          }
+          if (rc != SP_OK) return rc;
+        }
+      }
+      const int cE = (s0 + w) * SP_NB;
+      if (cE < K) {
+        for (int g = 0; g < ngroups; ++g) {
+          const sp_chol_group &G = grp[g];
+          int rc = bulk_update(h, G.sys, ld, stride, G.S, cS, cE, Kp, w * SP_NB, G.st, 0, nullptr,
+                               nullptr, 0, 1);
+          if (rc != SP_OK) return rc;
+        }
+      }
+    }
+    return SP_OK;
+  }
   // launches are issued breadth-first over the groups so that the groups'
   // streams advance together (the host enqueues ~3-8 us per launch)
   for (int s0 = 0; s0 < nsteps; s0 += w) {

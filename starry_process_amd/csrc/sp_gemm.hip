@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
     const double *__restrict__ B, long ldb, long strideB, double *C,
     long ldc, long strideC, int Mrows, int Nrows, int Kd, double alpha,
     int beta, int lower_only, int batch, int ntm, int ntn, int ntiles, int nact,
-    double *invL_all, int32_t *info, int skip00) {
+    double *invL_all, int32_t *info, int skip00, const double *lt_in) {
   // Padded LDS row of BK + 1 doubles.  hipcc fuses the per-k-step fragment reads
   // into ds_read2_b64, which is banked mod 32 dwords in 16-lane groups: an ODD
   // row length puts the 16 rows of a group on 16 distinct bank pairs.  (An even
@@ -134,9 +134,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
     tj = tile % ntn;
   }
   const int row0 = ti * GT, col0 = tj * GT;
+  // (one-launch-per-panel mode: the first diagonal block of the next super-panel has
+  //  been updated eagerly AND factored by the last panel launch -- leave it alone)
+  if (FUSE == 0 && skip00 && lower_only && ti == 0 && tj == 0) return;
   // the workgroup that will factor the diagonal block is the critical path of the
   // launch: let its wavefronts win the issue arbitration on their SIMDs
-  if (FUSE == 1 && ti == 0 && tj == 0) __builtin_amdgcn_s_setprio(3);
+  if ((FUSE == 1 && ti == 0 && tj == 0) || (FUSE == 2 && ti == 0)) __builtin_amdgcn_s_setprio(3);
   const double *Ab = A + (size_t)mtx * strideA;
   const double *Bb = B + (size_t)mtx * strideB;
   double *Cb = C + (size_t)mtx * strideC;
@@ -227,6 +230,103 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
     for (int n = 0; n < 4; ++n) acc[n] += cin[n];
   }
 
+  if (FUSE == 2) {
+    // One launch per panel: the updated 64 x 64 tile never goes back to memory unsolved.
+    //   accumulators -> LDS -> four lanes per row -> X = P L_d^-T against the image the
+    //   previous launch left (lt_in) -> solved rows stored; the leading row tiles then apply
+    //   their eager update to their own diagonal tile, and the first of them, whose diagonal
+    //   tile is the next pivot block and is now complete, factors it (image -> invL_all, the
+    //   other parity, while the rest of this launch still reads lt_in).
+    constexpr int XW = 65;
+    double *sT = smem;                         // 64 x 65 doubles <= SP_TILE_LDS_DOUBLES
+    const int tid = threadIdx.x, q = tid & 3, lrow = tid >> 2;
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sT[(16 * wave + fk + 4 * r) * XW + 16 * n + fr] = acc[n][r];
+    LtRegs lt;
+    lt_load(lt, lt_in + (size_t)mtx * SP_LT_STRIDE);
+    __syncthreads();
+    double x[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      x[2 * i] = sT[lrow * XW + 8 * i + 2 * q];
+      x[2 * i + 1] = sT[lrow * XW + 8 * i + 2 * q + 1];
+    }
+    __syncthreads();
+    lt_store(lt, sT, sT + 4096);
+    __syncthreads();
+    const bool valid = row0 + lrow < Mrows;
+    double *prow = Cb + (size_t)(row0 + (valid ? lrow : 0)) * ldc + col0 + 2 * q;
+    quad_solve_store(x, sT, sT + 4096, prow, valid);
+    const int neager = skip00;
+    if (ti >= neager) return;
+    __syncthreads();
+    {
+      double *row = sT + lrow * XW + 2 * q;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        row[8 * i] = x[2 * i];
+        row[8 * i + 1] = x[2 * i + 1];
+      }
+    }
+    __syncthreads();
+    // my own diagonal tile: rows / columns (GT + row0 ..) relative to the block column
+    double *D = Cb + (size_t)row0 * ldc + GT + row0;
+    d4 dac[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        dac[n][r] = D[(size_t)(16 * wave + fk + 4 * r) * ldc + 16 * n + fr];
+    {
+      const double *pa = sT + (16 * wave + fr) * XW + fk;
+      const double *pb = sT + fr * XW + fk;
+#pragma unroll
+      for (int kk = 0; kk < 64; kk += 4) {
+        const double a = -pa[kk];
+        dac[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, pb[kk], dac[0], 0, 0, 0);
+        dac[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, pb[16 * XW + kk], dac[1], 0, 0, 0);
+        dac[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, pb[32 * XW + kk], dac[2], 0, 0, 0);
+        dac[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, pb[48 * XW + kk], dac[3], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        D[(size_t)(16 * wave + fk + 4 * r) * ldc + 16 * n + fr] = dac[n][r];
+    if (ti > 0 || nact <= 0) return;
+    // the next pivot block: complete now -- factor it (nact = its active columns; rows and
+    // columns beyond them keep the updated values just stored)
+    __syncthreads();
+    double *sD = smem, *sRd = smem + 64 * BLD;
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int li = 16 * wave + fk + 4 * r, lj = 16 * n + fr;
+        double v = (li < nact && lj < nact) ? dac[n][r] : (li == lj ? 1.0 : 0.0);
+        if (lj > li) v = 0.0;
+        sD[li * BLD + lj] = v;
+      }
+    __syncthreads();
+    const int notpd = diag_block(sD, sRd, invL_all + (size_t)mtx * SP_LT_STRIDE);
+    if (notpd && info) info[mtx] = 1;
+    {
+      const int cj = (threadIdx.x & 15) * 4, ri = threadIdx.x >> 4;
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int r = ri + 16 * pass;
+        double *dst = D + (size_t)r * ldc + cj;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (r < nact && cj + e <= r) dst[e] = sD[r * BLD + cj + e];
+      }
+    }
+    return;
+  }
+
 #pragma unroll
   for (int n = 0; n < 4; ++n)
 #pragma unroll
@@ -287,11 +387,11 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
 #define SP_GO_FAST(FD)                                                                       \
   hipLaunchKernelGGL((gemm_nt_kernel<32, false, FD, 0, true>), dim3((unsigned)nblk), dim3(256), 0, \
                      st, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd,  \
-                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00)
+                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00, nullptr)
 #define SP_GO(BK, DC, FD)                                                              \
   hipLaunchKernelGGL((gemm_nt_kernel<BK, DC, FD>), dim3((unsigned)nblk), dim3(256), 0, st, \
                      A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd, \
-                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00)
+                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00, nullptr)
   static int abl = -1;
   if (abl < 0) {
     const char *e = getenv("SP_GEMM_ABL");
@@ -300,7 +400,7 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
 #define SP_GO_ABL(N)                                                                          \
   hipLaunchKernelGGL((gemm_nt_kernel<32, false, 0, N>), dim3((unsigned)nblk), dim3(256), 0, st, \
                      A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd,       \
-                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00)
+                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00, nullptr)
   if (abl > 0 && !fuse) {
     switch (abl) {
       case 1: SP_GO_ABL(1); break;
@@ -317,7 +417,7 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
   } else if (fast && variant == 2 && (Kd % 64) == 0) {
     hipLaunchKernelGGL((gemm_nt_kernel<64, false, 0, 0, true>), dim3((unsigned)nblk), dim3(256), 0,
                        st, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd,
-                       alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00);
+                       alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00, nullptr);
   } else {
     switch (variant) {
       case 1: SP_GO(32, true, 0); break;
@@ -331,12 +431,38 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
   return SP_OK;
 }
 
+// One launch per panel (FUSE = 2): rows r1.. of block column c0 are updated with the Kd
+// columns of the panels before it in the super-panel (A: those rows, B: the 64 rows of the
+// pivot block), solved against lt_in, eagerly applied to the leading `neager` diagonal
+// tiles, and the first of those is factored (next_nact > 0) into lt_out.
+int sp_launch_panel(const double *A, long lda, const double *B, long ldb, double *C, long ldc,
+                    long stride, int Mrows, int Kd, int batch, const double *lt_in, double *lt_out,
+                    int neager, int next_nact, int32_t *info, hipStream_t st) {
+  if (Mrows <= 0 || batch <= 0) return SP_OK;
+  const int ntm = (Mrows + GT - 1) / GT, ntn = 1, ntiles = ntm;
+  const long nblk = sp_xcd_grid(batch, ntiles);
+  if (nblk > 0x7fffffffL) return SP_ERR_INVALID;
+  const bool fast = (Mrows % GT) == 0 && (Kd % 32) == 0 && Kd > 0 && ((lda | ldb) & 1) == 0 &&
+                    (stride & 1) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
+  if (fast)
+    hipLaunchKernelGGL((gemm_nt_kernel<32, false, 2, 0, true>), dim3((unsigned)nblk), dim3(256), 0,
+                       st, A, lda, stride, B, ldb, stride, C, ldc, stride, Mrows, GT, Kd, -1.0, 1, 0,
+                       batch, ntm, ntn, ntiles, next_nact, lt_out, info, neager, lt_in);
+  else
+    hipLaunchKernelGGL((gemm_nt_kernel<32, false, 2, 0, false>), dim3((unsigned)nblk), dim3(256), 0,
+                       st, A, lda, stride, B, ldb, stride, C, ldc, stride, Mrows, GT, Kd, -1.0, 1, 0,
+                       batch, ntm, ntn, ntiles, next_nact, lt_out, info, neager, lt_in);
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}
+
 int sp_launch_gemm_nt(const double *A, long lda, long strideA, const double *B, long ldb,
                       long strideB, double *C, long ldc, long strideC, int Mrows, int Nrows,
                       int Kd, double alpha, int beta, int lower_only, int batch,
-                      hipStream_t st) {
+                      hipStream_t st, int skip_tile00) {
   return launch_gemm(A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd,
-                     alpha, beta, lower_only, batch, 0, 0, nullptr, nullptr, st);
+                     alpha, beta, lower_only, batch, 0, 0, nullptr, nullptr, st, skip_tile00);
 }
 
 // Update (beta = 1) whose tile (0, 0) is the next diagonal block: that tile's

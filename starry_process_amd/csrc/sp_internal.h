@@ -46,6 +46,7 @@ struct sp_handle {
   int groups;                   // concurrent star groups (SP_GROUPS, default 1)
   int fuse_diag;                // fuse the diagonal-block factorisation into the block-column update
   int eager;                    // panel solves keep the coming diagonal blocks up to date (SP_EAGER)
+  int onelaunch;                // update + solve + eager + next diagonal block in ONE launch per panel (SP_ONELAUNCH)
   std::vector<hipStream_t> gstream;
   std::vector<hipEvent_t> gdone;
   hipEvent_t gfork;
@@ -115,6 +116,9 @@ int sp_launch_polar_moments(sp_handle *h, const double *mu_src, const double *co
 //   A: Mrows x Kd (lda), B: Nrows x Kd (ldb), C: Mrows x Nrows (ldc)
 //   beta is 0 or 1;  lower_only: only tiles with tile_i >= tile_j are touched
 //   Mrows, Nrows multiples of 64; Kd multiple of 4.
+int sp_launch_panel(const double *A, long lda, const double *B, long ldb, double *C, long ldc,
+                    long stride, int Mrows, int Kd, int batch, const double *lt_in, double *lt_out,
+                    int neager, int next_nact, int32_t *info, hipStream_t st);
 int sp_launch_tri_solve(const double *L, int K, long ldl, long strideL, double *B, long strideB,
                         long rs, long cs, int nrhs, int batch, int mode, hipStream_t st);
 int sp_launch_transpose(const double *in, long ldi, long stridei, double *out, int K, int batch,
@@ -125,7 +129,7 @@ int sp_launch_chol_rev_finish(const double *S, const double *L, long ldl, long s
 int sp_launch_gemm_nt(const double *A, long lda, long strideA, const double *B,
                       long ldb, long strideB, double *C, long ldc, long strideC,
                       int Mrows, int Nrows, int Kd, double alpha, int beta,
-                      int lower_only, int batch, hipStream_t st);
+                      int lower_only, int batch, hipStream_t st, int skip_tile00 = 0);
 
 int sp_launch_gemm_nt_diag(const double *A, long lda, long strideA, const double *B, long ldb,
                            long strideB, double *C, long ldc, long strideC, int Mrows,
@@ -134,6 +138,6 @@ int sp_launch_gemm_nt_diag(const double *A, long lda, long strideA, const double
                            int skip00 = 0);
 
 // per-star scratch of the factorisation (doubles): the L_d^T image of the current panel
-#define SP_LT_DOUBLES 4096
+#define SP_LT_DOUBLES 8192   /* = SP_LT_STRIDE (sp_tile.h): two L_d^T images per star */
 
 #endif

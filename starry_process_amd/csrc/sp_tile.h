@@ -31,7 +31,9 @@ static inline long sp_xcd_grid(long batch, long ntiles) { return 8L * ((batch * 
 
 // per-star scratch of the factorisation: the L_d^T image of the current panel
 #define SP_LT_IMG 4096
-#define SP_LT_STRIDE SP_LT_IMG
+// two images per star: the one-launch-per-panel mode writes the next panel's image while the
+// workgroups of the current launch still read this one (ping-pong by panel parity)
+#define SP_LT_STRIDE (2 * SP_LT_IMG)
 
 // ---- substitution (shared with trsm_quad_kernel) ------------------------------
 struct TrsmRow {

@@ -5,6 +5,7 @@ buffers, streams, torch.distributed); every number is produced by the HIP
 kernels in ``csrc/``.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -302,6 +303,11 @@ class Engine(object):
         check(self._L.sp_cho_solve(self._h, self._p(Lb), K, K, K * K, self._p(bb), nrhs, B, self._stream()))
         return bb.reshape(shape)
 
+    def set_panel_mode(self, one_launch):
+        """False: two launches per panel (shortest critical path, one evaluation at a time);
+        True: one launch per panel (least HBM traffic, several evaluations in flight)."""
+        check(self._L.sp_set_panel_mode(self._h, int(bool(one_launch))))
+
     def tri_solve(self, L, b, trans=False):
         """L^-1 b (trans False) or L^-T b (trans True); shapes as in cho_solve."""
         L = self.f64(L)
@@ -423,13 +429,21 @@ def engine_slots(ydeg=15, udeg=2, device=None, depth=3):
     each with its own workspace and outputs.  One evaluation alone leaves most of the GPU idle
     during its latency-bound phases (diagonal blocks, panel solves); with three in flight those
     overlap the neighbours' assembly and trailing updates: 1.02 -> 0.75 ms per 64-star step
-    (bench.py).  A handle is not re-entrant, hence one per slot; slot 0 is the
-    process-wide engine of ``get_engine``."""
+    (bench.py).  A handle is not re-entrant, hence one per slot (fresh handles in
+    the one-launch-per-panel mode; the process-wide engine of ``get_engine`` is left as it is,
+    and is what depth = 1 returns)."""
     torch = _torch()
     first = get_engine(ydeg, udeg, device)
+    depth = max(1, int(depth))
+    if depth == 1:
+        return [(first, torch.cuda.Stream(device=first.device))]
     out = []
-    for k in range(max(1, int(depth))):
-        e = first if k == 0 else Engine(first.ydeg, first.udeg, first.device_index)
+    for k in range(depth):
+        e = Engine(first.ydeg, first.udeg, first.device_index)
+        if os.environ.get("SP_ONELAUNCH") is None:
+            # several evaluations in flight saturate the GPU: spend launches for traffic, not
+            # latency (include/starry_process_amd.h: sp_set_panel_mode)
+            e.set_panel_mode(True)
         out.append((e, torch.cuda.Stream(device=e.device)))
     return out
 

@@ -288,9 +288,10 @@ def test_steps_in_flight(eng):
     S, K = 8, 300
     mom = golden("moments_L15")
     slots = engine_slots(15, 2, None, 3)
-    assert slots[0][0] is eng(15) and len({id(e) for e, _ in slots}) == 3
+    assert len({id(e) for e, _ in slots} | {id(eng(15))}) == 4      # fresh handles, shared engine untouched
+    assert engine_slots(15, 2, None, 1)[0][0] is eng(15)
     sts = [synthetic_star(s, K) for s in range(S)]
-    e0 = slots[0][0]
+    e0 = eng(15)
     t_d = e0.f64(np.array([s["t"] for s in sts]))
     f_d = e0.f64(np.array([s["flux"] for s in sts])[:, None, :])
     stars = e0.stars_to_device(make_stars(S, period=[s["p"] for s in sts], data_var=1e-6))
