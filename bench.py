@@ -89,6 +89,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--in-flight", type=int, default=3,
                     help="independent steps kept in flight on separate streams / handles")
+    ap.add_argument("--prewarm-ms", type=float, default=300.0,
+                    help="untimed pre-warm after the --warmup steps: whole steps keep running until this "
+                         "much wall time has passed and every slot has run 3 times (clocks and fabric "
+                         "at their loaded state); the timed region is exactly --steps steps either way")
     ap.add_argument("--cpu-stars", type=int, default=128)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -160,8 +164,22 @@ def main():
     if use_dist:
         # communicator set-up (lazy in RCCL) must not land in the timed region even with --warmup 0
         dist.all_gather_into_tensor(slots[0]["gathered"], slots[0]["out"])
-    for i in range(max(args.warmup, F if args.warmup else 0)):
+    nwarm = max(args.warmup, F if args.warmup else 0)
+    for i in range(nwarm):
         step(i)
+    # Stated, untimed pre-warm: a fresh process reaches the timed region
+    # 5 ms after its first launch otherwise, with the memory / fabric clocks still at their idle
+    # state, and the bandwidth-bound in-flight mode then reads like the latency-bound one.
+    # Whole steps of the same workload, every slot at least 3 times, at least --prewarm-ms.
+    prewarm_steps = 0
+    if args.prewarm_ms > 0:
+        torch.cuda.synchronize()
+        tw = time.perf_counter()
+        while prewarm_steps < 3 * F or 1e3 * (time.perf_counter() - tw) < args.prewarm_ms:
+            for _ in range(F):
+                step(nwarm + prewarm_steps)
+                prewarm_steps += 1
+            torch.cuda.synchronize()
     nsyrk = (K + 63) // 64  # upper bound on timed launches per step
     for c in slots:
         c["e"].profile_begin((args.steps // F + 1) * nsyrk)
@@ -210,7 +228,7 @@ def main():
         one["trailing_update_frac"] = one["trailing_update_TFLOPs"] / FP64_PEAK_TFLOPS
 
     out, status = slots[0]["out"], slots[0]["status"]
-    nran = min(F, args.steps + (max(args.warmup, F) if args.warmup else 0))   # slots that ran
+    nran = min(F, args.steps + nwarm + prewarm_steps)   # slots that ran
     slots_agree = all(torch.equal(c["out"], out) for c in slots[1:nran])   # same inputs, same bits
     lnl = out.cpu().numpy()
     ok = bool(np.all(np.isfinite(lnl))) and not bool(status.cpu().numpy().any()) and slots_agree
@@ -288,6 +306,7 @@ def main():
                 "steps_in_flight": F,
             },
             "parity_ok": ok,
+            "prewarm": {"steps": prewarm_steps, "min_ms": args.prewarm_ms, "timed": False},
             "steps_in_flight": F,
             "one_step_at_a_time": one,
             "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,

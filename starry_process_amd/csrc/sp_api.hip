@@ -204,30 +204,23 @@ int check_handle(const sp_handle *h) { return h ? SP_OK : SP_ERR_INVALID; }
 
 }  // namespace
 
-// The handle-owned grow-only buffer lives outside the struct in sp_internal.h
-// to keep that header small.
-struct BigBuf {
-  void *ptr = nullptr;
-  size_t bytes = 0;
-};
-static BigBuf g_big[16];
-
 namespace {
+// (growing synchronises the device: the old buffer may still be in use by launches of this
+//  handle on any stream; steady-state calls never get here)
 int ensure_big(sp_handle *h, size_t bytes, void **out) {
-  BigBuf &b = g_big[h->device & 15];
-  if (b.bytes < bytes) {
+  if (h->big_bytes < bytes) {
     SP_HIP(hipDeviceSynchronize());
-    if (b.ptr) SP_HIP(hipFree(b.ptr));
-    b.ptr = nullptr;
-    b.bytes = 0;
-    hipError_t e = hipMalloc(&b.ptr, bytes);
+    if (h->big_ptr) SP_HIP(hipFree(h->big_ptr));
+    h->big_ptr = nullptr;
+    h->big_bytes = 0;
+    hipError_t e = hipMalloc(&h->big_ptr, bytes);
     if (e != hipSuccess) {
       sp_set_hip_error(e, "hipMalloc(scratch)");
       return SP_ERR_ALLOC;
     }
-    b.bytes = bytes;
+    h->big_bytes = bytes;
   }
-  *out = b.ptr;
+  *out = h->big_ptr;
   return SP_OK;
 }
 
@@ -397,6 +390,11 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
   h->scratch_bytes = 0;
   h->d_tab_scratch = nullptr;
   h->tab_scratch_bytes = 0;
+  h->table_attr_done = false;
+  h->big_ptr = nullptr;
+  h->big_bytes = 0;
+  for (auto &c : h->cs_ring) c = sp_handle::CsSlot{nullptr, nullptr, 0, nullptr, false};
+  h->cs_next = 0;
   h->superpanel = 0;
   h->groups = 1;
   h->fuse_diag = 2;
@@ -480,6 +478,12 @@ void sp_destroy(sp_handle *h) {
   for (hipEvent_t e : h->gdone) (void)hipEventDestroy(e);
   for (hipStream_t s2 : h->gstream) (void)hipStreamDestroy(s2);
   if (h->gfork) (void)hipEventDestroy(h->gfork);
+  if (h->big_ptr) (void)hipFree(h->big_ptr);
+  for (auto &c : h->cs_ring) {
+    if (c.host) (void)hipHostFree(c.host);
+    if (c.dev) (void)hipFree(c.dev);
+    if (c.done) (void)hipEventDestroy(c.done);
+  }
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   delete h;
@@ -503,19 +507,32 @@ int sp_Rx(sp_handle *h, const double *theta_host, int nangles, double *R_dev,
   if (!h || !theta_host || !R_dev || nangles < 0) return SP_ERR_INVALID;
   if (nangles == 0) return SP_OK;
   hipStream_t st = (hipStream_t)stream;
-  // cos/sin on the host with libm, like the reference (wigner.h:153-154)
-  std::vector<double> cs(2 * (size_t)nangles);
-  for (int i = 0; i < nangles; ++i) {
-    cs[2 * i] = std::cos(theta_host[i]);
-    cs[2 * i + 1] = std::sin(theta_host[i]);
+  // cos/sin on the host with libm, like the reference (wigner.h:153-154), staged through the
+  // handle's ring: the slot's previous use is waited for on the host (long finished in
+  // practice), nothing is allocated, freed or synchronised once the ring has grown
+  sp_handle::CsSlot &c = h->cs_ring[h->cs_next];
+  h->cs_next = (h->cs_next + 1) & 3;
+  const size_t need = 2 * (size_t)nangles;
+  if (c.used) SP_HIP(hipEventSynchronize(c.done));
+  if (c.cap < need) {
+    if (c.host) SP_HIP(hipHostFree(c.host));
+    if (c.dev) SP_HIP(hipFree(c.dev));
+    c.host = c.dev = nullptr;
+    c.cap = 0;
+    const size_t cap = need < 64 ? 64 : need;
+    SP_HIP(hipHostMalloc((void **)&c.host, sizeof(double) * cap, hipHostMallocDefault));
+    SP_HIP(hipMalloc((void **)&c.dev, sizeof(double) * cap));
+    c.cap = cap;
   }
-  double *d_cs = nullptr;
-  SP_HIP(hipMalloc((void **)&d_cs, sizeof(double) * cs.size()));
-  SP_HIP(hipMemcpyAsync(d_cs, cs.data(), sizeof(double) * cs.size(),
-                        hipMemcpyHostToDevice, st));
-  int rc = sp_launch_Rx(h, d_cs, nangles, R_dev, dR_dev, st);
-  SP_HIP(hipStreamSynchronize(st));
-  SP_HIP(hipFree(d_cs));
+  if (!c.done) SP_HIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+  for (int i = 0; i < nangles; ++i) {
+    c.host[2 * i] = std::cos(theta_host[i]);
+    c.host[2 * i + 1] = std::sin(theta_host[i]);
+  }
+  SP_HIP(hipMemcpyAsync(c.dev, c.host, sizeof(double) * need, hipMemcpyHostToDevice, st));
+  int rc = sp_launch_Rx(h, c.dev, nangles, R_dev, dR_dev, st);
+  SP_HIP(hipEventRecord(c.done, st));
+  c.used = true;
   return rc;
 }
 

@@ -42,6 +42,22 @@ struct sp_handle {
   size_t scratch_bytes;
   double *d_tab_scratch;        // [ntab][2][N] row reductions of the kernel table
   size_t tab_scratch_bytes;
+  bool table_attr_done;         // dynamic-LDS opt-in of table_finish_kernel made on this handle's device
+  // grow-only device scratch of the non-fused ops (sp_cov_*_batched, sp_cho_factor, ...): owned
+  // by the handle, so two handles on one GPU never share it
+  void *big_ptr;
+  size_t big_bytes;
+  // cos / sin staging of sp_Rx: a ring of pinned host + device buffer pairs, each guarded by the
+  // event of its last use (no allocation, no stream synchronisation in the launch path)
+  struct CsSlot {
+    double *host;
+    double *dev;
+    size_t cap;                 // doubles
+    hipEvent_t done;
+    bool used;
+  };
+  CsSlot cs_ring[4];
+  int cs_next;
   int superpanel;               // panels per super-panel (SP_SUPER; 0 = chosen from K)
   int groups;                   // concurrent star groups (SP_GROUPS, default 1)
   int fuse_diag;                // fuse the diagonal-block factorisation into the block-column update

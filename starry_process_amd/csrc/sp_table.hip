@@ -183,11 +183,11 @@ int sp_launch_kernel_table(sp_handle *h, const double *rta1_dev, int ntab,
     SP_HIP(hipMalloc((void **)&h->d_tab_scratch, need));
     h->tab_scratch_bytes = need;
   }
-  static bool attr_done = false;
-  if (!attr_done) {
+  // (the attribute is per device: remembered per handle, a handle lives on one device)
+  if (!h->table_attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(table_finish_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr_done = true;
+    h->table_attr_done = true;
   }
   hipLaunchKernelGGL(table_rows_kernel, dim3((h->N + 3) / 4, ntab), dim3(256), 0, st,
                      h->N, h->d_l_of, h->d_mirror, h->d_Wnp, h->d_Ez, rta1_dev,

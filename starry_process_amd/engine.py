@@ -59,6 +59,7 @@ class Engine(object):
         Wnp = np.ascontiguousarray(Wnp)
         check(L.sp_set_marginal_constants(self._h, hptr(wnp), hptr(Wnp)))
         self._moments_id = None
+        self._moments_owner = None
         self._ws = None
 
     def __del__(self):
@@ -205,11 +206,14 @@ class Engine(object):
         mean_ylm = np.ascontiguousarray(np.asarray(mean_ylm, dtype=np.float64).reshape(-1))
         cov_ylm = np.ascontiguousarray(np.asarray(cov_ylm, dtype=np.float64))
         assert mean_ylm.shape == (self.N,) and cov_ylm.shape == (self.N, self.N)
+        # whoever bound its moments before (flux.FluxIntegral._bind) no longer owns the resident set
+        self._moments_owner = None
         check(self._L.sp_set_ylm_moments(self._h, hptr(mean_ylm), hptr(cov_ylm)))
 
     def set_moments_dev(self, mean_ylm, cov_ylm):
         """Same with the moments already on the device (asynchronous)."""
         assert mean_ylm.is_cuda and cov_ylm.is_cuda
+        self._moments_owner = None
         check(self._L.sp_set_ylm_moments_dev(self._h, self._p(mean_ylm), self._p(cov_ylm), self._stream()))
 
     def profile_begin(self, max_launches):
