@@ -370,6 +370,12 @@ int sp_allgather_lnlike(sp_handle *h, void *nccl_comm, const double *local_dev, 
 int sp_debug_cholesky_phase(sp_handle *h, int S, int K, int M, void *workspace_dev,
                             int phase, int j, void *stream);
 
+/* Tile shape of the pipelined fp64 product (csrc/sp_mm.h) for every later launch of this
+ * process: 0 = register-staged 64 x 64 kernel, 1 = 64 x 64 tiles, 16-deep slices, 4 LDS stages
+ * (default), 2-8 = the other shapes tools/mm_bench.py compares.  Results do not depend on it
+ * beyond the summation order.  Environment: SP_MM.                                        */
+int sp_debug_set_mm_variant(int variant);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1036,6 +1036,12 @@ int sp_debug_cholesky_phase(sp_handle *h, int S, int K, int M, void *workspace_d
                         phase, j, (hipStream_t)stream);
 }
 
+int sp_debug_set_mm_variant(int variant) {
+  if (variant < 0 || variant > 16) return SP_ERR_INVALID;
+  sp_set_mm_variant(variant);
+  return SP_OK;
+}
+
 int sp_cholesky_lnlike_batched(sp_handle *h, int S, int K, int M,
                                const double *cov_dev, const double *resid_dev,
                                void *workspace_dev, double *lnlike_dev,

@@ -21,6 +21,7 @@
 
 #include "sp_internal.h"
 #include "sp_tile.h"
+#include "sp_mm.h"
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
@@ -365,6 +366,98 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
 
 }  // namespace
 
+
+// ---- pipelined kernel (sp_mm.h): full tiles, Kd a multiple of BK, aligned operands ------------
+// C[b] = beta C[b] + alpha A[b] B[b]^T on TM x TN tiles; the C tile is fetched up front and
+// added after the loop (its latency hides behind the product).
+namespace {
+// SGN: alpha is +1 or -1 and the accumulators start from +-C (no second register tile, exact);
+// otherwise the C tile waits in registers and is combined after the loop.
+template <int TM, int TN, int BK, int NS, int WR, bool SGN>
+__global__ __launch_bounds__(256) void mm_nt_kernel(
+    const double *__restrict__ A, long lda, long strideA, const double *__restrict__ B, long ldb,
+    long strideB, double *__restrict__ C, long ldc, long strideC, int Kd, double alpha, int beta,
+    int lower_only, int batch, int ntn, int ntiles, int skip00) {
+  using Core = MM<TM, TN, BK, NS, WR>;
+  __shared__ __attribute__((aligned(16))) double lds[Core::LDS_DOUBLES];
+  int mtx, tile;
+  if (!sp_xcd_decode(blockIdx.x, batch, ntiles, mtx, tile)) return;
+  int ti, tj;
+  if (lower_only) {
+    ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > tile) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+    tj = tile - ti * (ti + 1) / 2;
+  } else {
+    ti = tile / ntn;
+    tj = tile % ntn;
+  }
+  if (skip00 && lower_only && ti == 0 && tj == 0) return;
+  const double *Ab = A + (size_t)mtx * strideA + (size_t)ti * TM * lda;
+  const double *Bb = B + (size_t)mtx * strideB + (size_t)tj * TN * ldb;
+  double *Cb = C + (size_t)mtx * strideC + (size_t)ti * TM * ldc + (size_t)tj * TN;
+  Core mm;
+  mm.init(Ab, lda, Bb, ldb);
+  mm_d4 acc[Core::MA][Core::NA], cin[SGN ? 1 : Core::MA][SGN ? 1 : Core::NA];
+  mm.prologue(lds, 0, Kd);   // the first slices are on their way while the C tile is fetched
+#pragma unroll
+  for (int m = 0; m < Core::MA; ++m)
+#pragma unroll
+    for (int n = 0; n < Core::NA; ++n) {
+      mm_d4 c = mm_d4{0.0, 0.0, 0.0, 0.0};
+      if (beta) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[r] = Cb[(size_t)mm.acc_row(m, r) * ldc + mm.acc_col(n)];
+      }
+      if (SGN) {
+        acc[m][n] = alpha < 0.0 ? -c : c;
+      } else {
+        acc[m][n] = mm_d4{0.0, 0.0, 0.0, 0.0};
+        cin[m][n] = c;
+      }
+    }
+  mm.loop(lds, 0, Kd, acc);
+#pragma unroll
+  for (int m = 0; m < Core::MA; ++m)
+#pragma unroll
+    for (int n = 0; n < Core::NA; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double v;
+        if (SGN)
+          v = alpha < 0.0 ? -acc[m][n][r] : acc[m][n][r];
+        else
+          v = fma(alpha, acc[m][n][r], cin[m][n][r]);
+        Cb[(size_t)mm.acc_row(m, r) * ldc + mm.acc_col(n)] = v;
+      }
+}
+
+template <int TM, int TN, int BK, int NS, int WR>
+int mm_launch(const double *A, long lda, long strideA, const double *B, long ldb, long strideB,
+              double *C, long ldc, long strideC, int Mrows, int Nrows, int Kd, double alpha, int beta,
+              int lower_only, int batch, hipStream_t st, int skip00) {
+  const int ntm = Mrows / TM, ntn = Nrows / TN;
+  const int ntiles = lower_only ? ntm * (ntm + 1) / 2 : ntm * ntn;
+  const long nblk = sp_xcd_grid(batch, ntiles);
+  if (nblk > 0x7fffffffL) return SP_ERR_INVALID;
+  if (alpha == 1.0 || alpha == -1.0)
+    hipLaunchKernelGGL((mm_nt_kernel<TM, TN, BK, NS, WR, true>), dim3((unsigned)nblk), dim3(256), 0, st,
+                       A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Kd, alpha, beta, lower_only,
+                       batch, ntn, ntiles, skip00);
+  else
+    hipLaunchKernelGGL((mm_nt_kernel<TM, TN, BK, NS, WR, false>), dim3((unsigned)nblk), dim3(256), 0, st,
+                       A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Kd, alpha, beta, lower_only,
+                       batch, ntn, ntiles, skip00);
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}
+}  // namespace
+
+// tile shape of the pipelined kernel (SP_MM, or sp_debug_set_mm_variant for the microbenchmarks);
+// 0 = the register-staged gemm_nt_kernel
+static int g_mm_variant = -1;
+void sp_set_mm_variant(int v) { g_mm_variant = v; }
+
 static int launch_gemm(const double *A, long lda, long strideA, const double *B, long ldb,
                        long strideB, double *C, long ldc, long strideC, int Mrows, int Nrows,
                        int Kd, double alpha, int beta, int lower_only, int batch, int fuse,
@@ -401,6 +494,27 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
   hipLaunchKernelGGL((gemm_nt_kernel<32, false, 0, N>), dim3((unsigned)nblk), dim3(256), 0, st, \
                      A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd,       \
                      alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00, nullptr)
+  if (g_mm_variant < 0) {
+    const char *e = getenv("SP_MM");
+    g_mm_variant = e ? atoi(e) : 1;
+  }
+  const int mmv = g_mm_variant;
+  if (fast && !fuse && abl == 0 && mmv > 0) {
+    // pipelined kernels (sp_mm.h); tile shape by SP_MM (tools/microbench.py compares them)
+#define SP_MM_GO(TM, TN, BK, NS, WR)                                                              \
+  return mm_launch<TM, TN, BK, NS, WR>(A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, \
+                                       Nrows, Kd, alpha, beta, lower_only, batch, st, skip00)
+    const bool big = (Mrows % 128) == 0 && (Nrows % 128) == 0;
+    if (mmv == 3 && big) SP_MM_GO(128, 128, 8, 4, 2);
+    if (mmv == 8 && big) SP_MM_GO(128, 128, 8, 3, 2);
+    if (mmv == 5 && big) SP_MM_GO(128, 128, 16, 3, 2);
+    if (mmv == 4 && (Mrows % 128) == 0 && !lower_only) SP_MM_GO(128, 64, 16, 3, 4);
+    if (mmv == 2) SP_MM_GO(64, 64, 32, 3, 4);
+    if (mmv == 6) SP_MM_GO(64, 64, 16, 3, 4);
+    if (mmv == 7) SP_MM_GO(64, 64, 8, 6, 4);
+    SP_MM_GO(64, 64, 16, 4, 4);
+#undef SP_MM_GO
+  }
   if (abl > 0 && !fuse) {
     switch (abl) {
       case 1: SP_GO_ABL(1); break;

@@ -147,6 +147,8 @@ int sp_launch_gemm_nt(const double *A, long lda, long strideA, const double *B,
                       int Mrows, int Nrows, int Kd, double alpha, int beta,
                       int lower_only, int batch, hipStream_t st, int skip_tile00 = 0);
 
+void sp_set_mm_variant(int v);   // tile shape of the pipelined product (sp_gemm.hip)
+
 int sp_launch_gemm_nt_diag(const double *A, long lda, long strideA, const double *B, long ldb,
                            long strideB, double *C, long ldc, long strideC, int Mrows,
                            int Nrows, int Kd, double alpha, int lower_only, int batch,
