@@ -349,6 +349,25 @@ int sp_latitude_integrals(int ydeg, double alpha, double beta, double *q_host,
  * (n (n + 1) / 2 x 64 multiply-adds x 2 per star and launch).                */
 int sp_profile_begin(sp_handle *h, int max_launches);
 int sp_profile_end(sp_handle *h, long *launches, double *total_ms, double *flops);
+/* The same for one KIND of launch of the factorisation (every launch is bracketed while
+ * profiling is on): 0 symmetric trailing updates (what sp_profile_end reports), 1 strip solves
+ * X = A L^-T, 2 the panel chain (diagonal blocks, block-column updates, panel solves),
+ * 3 covariance assembly (row sums + assembly).  Stops the profile like sp_profile_end; may be
+ * called for several kinds in a row.                                                     */
+int sp_profile_kind(sp_handle *h, int kind, long *launches, double *total_ms, double *flops);
+/* sp_profile_begin for a chosen set of kinds (bit k of kind_mask = kind k; sp_profile_begin
+ * = kind 0 only).  An event pair costs a few microseconds of stream time: bracket the panel
+ * chain (32 launches per K = 1000 factorisation) only outside timed regions.             */
+int sp_profile_begin_kinds(sp_handle *h, int max_launches, unsigned kind_mask);
+
+/* Driver of the blocked factorisation (math.py:75-91), per handle:
+ *   2 (default): recursive -- diagonal blocks of 4 panels factored panel by panel, everything
+ *                between them one strip solve (X = A21 L11^-T, a long-lived workgroup per 64-row
+ *                strip) and one symmetric update per level;
+ *   0: super-panels of 8 panels, left-looking inside, one trailing update per super-panel
+ *      (round 1's driver; sp_set_panel_mode selects its one- or two-launch form).
+ * Results agree to rounding (different summation order).  Environment: SP_CHOL.             */
+int sp_set_chol_mode(sp_handle *h, int mode);
 
 /* ---- multi-GPU ------------------------------------------------------
  * The only exchange of the path: every rank contributes the log-likelihoods of

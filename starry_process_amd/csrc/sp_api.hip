@@ -183,7 +183,7 @@ Layout make_layout(const sp_handle *h, int S, int K, int M, bool with_sys) {
   L.cs = take(d * S * 2);
   L.vrow = take(d * S * L.N);
   L.Rinc = take(d * S * L.NWIG);
-  L.invL = take(d * (size_t)S * SP_LT_DOUBLES);
+  L.invL = take(d * (size_t)S * sp_lt_stride(L.Kp));
   L.A = take(d * (size_t)S * K * L.N);
   L.B1 = take(d * (size_t)S * K * L.N);
   L.raw = take(d * (size_t)S * K * K);
@@ -288,7 +288,7 @@ Layout sub_layout(const Layout &L, int s0, int Sg) {
   G.cs += z * 2 * d;
   G.vrow += z * L.N * d;
   G.Rinc += z * L.NWIG * d;
-  G.invL += z * SP_LT_DOUBLES * d;
+  G.invL += z * sp_lt_stride(L.Kp) * d;
   G.A += z * L.K * L.N * d;
   G.B1 += z * L.K * L.N * d;
   G.raw += z * (size_t)L.K * L.K * d;
@@ -400,9 +400,9 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
   h->fuse_diag = 2;
   h->gfork = nullptr;
   h->prof_on = false;
+  h->prof_mask = 1u;
   h->prof_used = 0;
-  h->prof_flops = 0.0;
-  h->prof_launches = 0;
+  h->chol_mode = 2;
   const int N = h->N;
   h->l_of.resize(N);
   h->m_of.resize(N);
@@ -447,6 +447,8 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
     h->onelaunch = e7 ? atoi(e7) : 0;
     const char *e3 = getenv("SP_GROUPS");
     h->groups = e3 ? atoi(e3) : 1;
+    const char *e8 = getenv("SP_CHOL");
+    h->chol_mode = e8 ? atoi(e8) : 2;
     const char *e2 = getenv("SP_SUPER");
     h->superpanel = e2 ? atoi(e2) : 0;   // 0: chosen from K (sp_launch_cholesky_groups)
     if (h->superpanel < 0) h->superpanel = 0;
@@ -595,34 +597,54 @@ int sp_set_ylm_moments_dev(sp_handle *h, const double *mean_ylm_dev,
 }
 
 int sp_profile_begin(sp_handle *h, int max_launches) {
+  return sp_profile_begin_kinds(h, max_launches, 1u << SP_PROF_SYRK);
+}
+
+int sp_profile_begin_kinds(sp_handle *h, int max_launches, unsigned kind_mask) {
   if (h && h->device < 0) return SP_ERR_NO_DEVICE;
   if (!h || max_launches < 0) return SP_ERR_INVALID;
+  h->prof_mask = kind_mask;
   while (h->prof_ev.size() < 2 * (size_t)max_launches) {
     hipEvent_t e;
     SP_HIP(hipEventCreate(&e));
     h->prof_ev.push_back(e);
   }
+  h->prof_kind.assign(h->prof_ev.size() / 2, 0);
+  h->prof_fl.assign(h->prof_ev.size() / 2, 0.0);
   h->prof_used = 0;
-  h->prof_flops = 0.0;
-  h->prof_launches = 0;
   h->prof_on = true;
   return SP_OK;
 }
 
-int sp_profile_end(sp_handle *h, long *launches, double *total_ms, double *flops) {
+int sp_profile_kind(sp_handle *h, int kind, long *launches, double *total_ms, double *flops) {
   if (h && h->device < 0) return SP_ERR_NO_DEVICE;
-  if (!h) return SP_ERR_INVALID;
+  if (!h || kind < 0 || kind >= SP_PROF_NKINDS) return SP_ERR_INVALID;
   h->prof_on = false;
-  double ms = 0.0;
+  double ms = 0.0, fl = 0.0;
+  long n = 0;
   for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
+    if (h->prof_kind[i / 2] != kind) continue;
     SP_HIP(hipEventSynchronize(h->prof_ev[i + 1]));
     float dt = 0.f;
     SP_HIP(hipEventElapsedTime(&dt, h->prof_ev[i], h->prof_ev[i + 1]));
     ms += dt;
+    fl += h->prof_fl[i / 2];
+    n += 1;
   }
-  if (launches) *launches = h->prof_launches;
+  if (launches) *launches = n;
   if (total_ms) *total_ms = ms;
-  if (flops) *flops = h->prof_flops;
+  if (flops) *flops = fl;
+  return SP_OK;
+}
+
+int sp_profile_end(sp_handle *h, long *launches, double *total_ms, double *flops) {
+  return sp_profile_kind(h, SP_PROF_SYRK, launches, total_ms, flops);
+}
+
+int sp_set_chol_mode(sp_handle *h, int mode) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || (mode != 0 && mode != 2)) return SP_ERR_INVALID;
+  h->chol_mode = mode;
   return SP_OK;
 }
 
@@ -778,7 +800,7 @@ int sp_cho_factor(sp_handle *h, double *A_dev, int K, long lda, long strideA,
   hipStream_t st = (hipStream_t)stream;
   const int Kp = sp_roundup(K, SP_NB);
   const size_t sysb = align_up(sizeof(double) * (size_t)batch * Kp * Kp);
-  const size_t invb = align_up(sizeof(double) * (size_t)batch * SP_LT_DOUBLES);
+  const size_t invb = align_up(sizeof(double) * (size_t)batch * sp_lt_stride(Kp));
   void *ws = nullptr;
   int rc = ensure_big(h, sysb + invb + align_up(sizeof(int32_t) * batch), &ws);
   if (rc) return rc;
@@ -982,7 +1004,7 @@ int sp_gp_condition(sp_handle *h, int K, int Ks, const double *Ktt_dev, const do
   const int M = Ks + 1, Kp = sp_roundup(K + M, SP_NB);
   const size_t sysb = align_up(sizeof(double) * (size_t)Kp * Kp);
   const size_t resb = align_up(sizeof(double) * (size_t)M * K);
-  const size_t invb = align_up(sizeof(double) * SP_LT_DOUBLES);
+  const size_t invb = align_up(sizeof(double) * sp_lt_stride(Kp));
   void *ws = nullptr;
   int rc = ensure_big(h, sysb + resb + invb + 256, &ws);
   if (rc) return rc;

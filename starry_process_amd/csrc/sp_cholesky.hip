@@ -34,7 +34,7 @@ namespace {
 template <bool TIMED>
 __global__ __launch_bounds__(256) void diag_kernel(double *__restrict__ sys, long ld,
                                                    long stride, int c0, int nact,
-                                                   double *__restrict__ invL_all,
+                                                   double *__restrict__ invL_all, long lts,
                                                    int32_t *__restrict__ info,
                                                    long long *__restrict__ dbg) {
   __shared__ __attribute__((aligned(16))) double lds[SP_DIAG_LDS_DOUBLES];
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void diag_kernel(double *__restrict__ sys, lon
   }
   __syncthreads();
   if (TIMED) { ts[1] = wall_clock64(); tc[1] = clock64(); }
-  const int notpd = diag_block(sD, sRd, invL_all + (size_t)blockIdx.x * SP_LT_STRIDE,
+  const int notpd = diag_block(sD, sRd, invL_all + (size_t)blockIdx.x * lts,
                                TIMED ? dbg + 8 + 40 * blockIdx.x + 0 : nullptr);
   if (notpd && info) info[blockIdx.x] = 1;
   if (TIMED) { ts[2] = wall_clock64(); tc[2] = clock64(); }
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void diag_kernel(double *__restrict__ sys, lon
 // FMA -> DPP -> FMA.  No barrier after the staging one.
 __global__ __launch_bounds__(256) void trsm_quad_kernel(double *sys, long ld, long stride,
                                                         int r1, int c0, int nrows,
-                                                        const double *__restrict__ LT_all,
+                                                        const double *__restrict__ LT_all, long lts,
                                                         int batch, int ntiles, int neager) {
   __shared__ __attribute__((aligned(16))) double sLT[64 * 64 + 64];
   // XCD-aware decode as in sp_gemm.hip (sp_tile.h)
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void trsm_quad_kernel(double *sys, long ld, lo
   const bool valid = lrow < nrows;
   double *prow = sys + (size_t)mtx * stride + (size_t)(r1 + (valid ? lrow : 0)) * ld + c0 + 2 * q;
   LtRegs lt;
-  lt_load(lt, LT_all + (size_t)mtx * SP_LT_STRIDE);
+  lt_load(lt, LT_all + (size_t)mtx * lts);
   double x[16];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -420,69 +420,186 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, double *sink,
 
 // ---- launchers ---------------------------------------------------------------
 
-// C[cfrom:, cfrom:] -= X[cfrom:, :] X[cfrom:, :]^T with X = columns c0..c0+kd-1 of the
-// same rows; lower-triangle tiles only.  Timed for bench.py when profiling is on.
+// C[cfrom:rend, cfrom:rend] -= X X^T with X = columns c0..c0+kd-1 of the rows cfrom..rend-1;
+// lower-triangle tiles only.  Timed for bench.py when profiling is on (kind SP_PROF_SYRK).
 static int bulk_update(sp_handle *h, double *sys, long ld, long stride, int S, int c0,
-                       int cfrom, int Kp, int kd, hipStream_t st, int fuse_nact = 0,
+                       int cfrom, int rend, int kd, hipStream_t st, long lts, int fuse_nact = 0,
                        double *invL = nullptr, int32_t *info = nullptr, int skip00 = 0,
                        int skip_tile00 = 0) {
   // fuse_nact > 0: tile (0, 0) is the diagonal block of the next panel and its
   // workgroup factors it on the spot (hidden behind the other tiles)
-  const int n = Kp - cfrom;
+  const int n = rend - cfrom;
+  if (n <= 0 || kd <= 0) return SP_OK;
   double *X = sys + (size_t)cfrom * ld + c0;
   double *T = sys + (size_t)cfrom * ld + cfrom;
-  const bool timed = h && h->prof_on && h->prof_used + 2 <= h->prof_ev.size();
-  if (timed) SP_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
-  int rc = fuse_nact > 0
-               ? sp_launch_gemm_nt_diag(X, ld, stride, X, ld, stride, T, ld, stride, n, n, kd,
-                                        -1.0, 1, S, fuse_nact, invL, info, st, skip00)
-               : sp_launch_gemm_nt(X, ld, stride, X, ld, stride, T, ld, stride, n, n, kd, -1.0,
-                                   1, 1, S, st, skip_tile00);
-  if (rc != SP_OK) return rc;
-  if (timed) {
-    SP_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
-    h->prof_used += 2;
-    // algorithmic work of a symmetric rank-kd update of an n x n block:
-    // n (n + 1) / 2 entries x kd multiply-adds
-    h->prof_flops += (double)S * (double)n * (n + 1) * kd;
-    h->prof_launches += 1;
-  }
-  return SP_OK;
+  // algorithmic work of a symmetric rank-kd update of an n x n block:
+  // n (n + 1) / 2 entries x kd multiply-adds
+  SpProfScope prof(h, st, SP_PROF_SYRK, (double)S * (double)n * (n + 1) * kd);
+  return fuse_nact > 0
+             ? sp_launch_gemm_nt_diag(X, ld, stride, X, ld, stride, T, ld, stride, n, n, kd,
+                                      -1.0, 1, S, fuse_nact, invL, lts, info, st, skip00)
+             : sp_launch_gemm_nt(X, ld, stride, X, ld, stride, T, ld, stride, n, n, kd, -1.0,
+                                 1, 1, S, st, skip_tile00);
 }
 
-// rows r1..Kp-1 of panel column c0: X = P L_d^-T in place (LT = diag_block's output)
+// rows r1..rend-1 of panel column c0: X = P L_d^-T in place (LT = diag_block's output)
 // neager: leading row tiles that also update their own diagonal block (trsm_quad_kernel)
-static int launch_trsm(double *sys, long ld, long stride, int S, int r1, int c0, int Kp,
-                       const double *LT, hipStream_t st, int neager = 0) {
-  const int nrows = Kp - r1;
+static int launch_trsm(sp_handle *h, double *sys, long ld, long stride, int S, int r1, int c0,
+                       int rend, const double *LT, long lts, hipStream_t st, int neager = 0) {
+  const int nrows = rend - r1;
   if (nrows <= 0) return SP_OK;
   const int ntiles = (nrows + 63) / 64;
   const long nblk = sp_xcd_grid(S, ntiles);
+  // substitution: 64 x 64 multiply-adds per row; each eager update a 64 x 64 x 64 product
+  SpProfScope prof(h, st, SP_PROF_CHAIN,
+                   (double)S * (2.0 * nrows * 64 * 64 / 2 + 2.0 * neager * 64 * 64 * 64 / 2));
   hipLaunchKernelGGL(trsm_quad_kernel, dim3((unsigned)nblk), dim3(256), 0, st, sys, ld, stride,
-                     r1, c0, nrows, LT, S, ntiles, neager);
+                     r1, c0, nrows, LT, lts, S, ntiles, neager);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }
 
-static int diag_and_solve(double *sys, long ld, long stride, int S, int K, int Kp, int j,
-                          int32_t *info, double *invL, hipStream_t st, bool have_diag = false,
-                          int neager = 0) {
+static int launch_diag(sp_handle *h, double *sys, long ld, long stride, int S, int c0, int nact,
+                       double *invL, long lts, int32_t *info, hipStream_t st) {
+  SpProfScope prof(h, st, SP_PROF_CHAIN, (double)S * nact * (double)nact * nact / 3.0);
+  hipLaunchKernelGGL(diag_kernel<false>, dim3(S), dim3(256), 0, st, sys, ld, stride, c0, nact, invL,
+                     lts, info, nullptr);
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}
+
+static int diag_and_solve(sp_handle *h, double *sys, long ld, long stride, int S, int K, int rend,
+                          int j, int32_t *info, double *invL, long lts, hipStream_t st,
+                          bool have_diag = false, int neager = 0) {
   const int c0 = j * SP_NB;
   const int nact = K - c0 < SP_NB ? K - c0 : SP_NB;
   // diagonal block: L_d (and L_d^T for the solve)
   if (!have_diag) {
-    hipLaunchKernelGGL(diag_kernel<false>, dim3(S), dim3(256), 0, st, sys, ld, stride, c0, nact,
-                       invL, info, nullptr);
-    SP_LAUNCH_CHECK();
+    int rc = launch_diag(h, sys, ld, stride, S, c0, nact, invL, lts, info, st);
+    if (rc != SP_OK) return rc;
   }
   // rows below the active block: X = P L_d^-T, in place
-  return launch_trsm(sys, ld, stride, S, c0 + nact, c0, Kp, invL, st, neager);
+  return launch_trsm(h, sys, ld, stride, S, c0 + nact, c0, rend, invL, lts, st, neager);
+}
+
+// left-looking update of block column j (rows c0..rend-1) by the q panels from column cS on; the
+// tile-(0,0) workgroup goes on to factor the diagonal block (image -> invL)
+static int launch_blockcol_diag(sp_handle *h, const sp_chol_group &G, long ld, long stride, int c0,
+                                int cS, int rend, int q, int nact, double *invL, long lts,
+                                int skip00) {
+  double *A = G.sys + (size_t)c0 * ld + cS;
+  double *T = G.sys + (size_t)c0 * ld + c0;
+  const double rows = rend - c0;
+  SpProfScope prof(h, G.st, SP_PROF_CHAIN,
+                   (double)G.S * (2.0 * rows * 64 * (q * 64.0) + 64.0 * 64 * 64 / 3));
+  return sp_launch_gemm_nt_diag(A, ld, stride, A, ld, stride, T, ld, stride, rend - c0, SP_NB,
+                                q * SP_NB, -1.0, 0, G.S, nact, invL, lts, G.info, G.st, skip00);
+}
+
+// ---- recursive driver (h->chol_mode == 2) -----------------------------------------------------
+//
+//   factor(b0, b1):  the diagonal block of the pivot blocks [b0, b1), rows and columns
+//     more than 4 blocks:  factor(b0, bm);  X = A21 L11^-T  (strip kernel, sp_strip.hip);
+//                          A22 -= X X^T  (one symmetric update);  factor(bm, b1)
+//     else:  the panels one after the other, left-looking (block-column update fused with the
+//            diagonal block, substitution solve with eager diagonal updates), rows of the block only
+//
+// Three quarters of the flops of a factorisation sit in the top-level strip solve and symmetric
+// update, each ONE launch of long-lived workgroups; the latency-bound chain (16 diagonal blocks
+// at K = 1000) works on 256-row blocks.  Every block keeps its own L_d^T image: the strip
+// solves need the images of all the diagonal blocks of their triangle.
+namespace {
+struct RecCtx {
+  sp_handle *h;
+  const sp_chol_group *G;
+  int K, Kp, nsteps;
+  long ld, stride, lts;
+};
+inline double *rec_img(const RecCtx &c, int j) { return c.G->invL + (size_t)j * SP_LT_IMG; }
+
+int rec_base(const RecCtx &c, int b0, int b1) {
+  const sp_chol_group &G = *c.G;
+  const int rend = b1 * SP_NB, cS = b0 * SP_NB;
+  for (int j = b0; j < b1; ++j) {
+    const int q = j - b0, c0 = j * SP_NB;
+    const int nact = c.K - c0 < SP_NB ? c.K - c0 : SP_NB;
+    const int neager = b1 - 1 - j;   // the pivot blocks of this base block still to come
+    int rc;
+    if (q > 0)
+      rc = launch_blockcol_diag(c.h, G, c.ld, c.stride, c0, cS, rend, q, nact, rec_img(c, j), c.lts, 1);
+    else
+      rc = launch_diag(c.h, G.sys, c.ld, c.stride, G.S, c0, nact, rec_img(c, j), c.lts, G.info, G.st);
+    if (rc != SP_OK) return rc;
+    rc = launch_trsm(c.h, G.sys, c.ld, c.stride, G.S, c0 + nact, c0, rend, rec_img(c, j), c.lts, G.st,
+                     nact == SP_NB ? neager : 0);
+    if (rc != SP_OK) return rc;
+  }
+  return SP_OK;
+}
+
+// rows [r0, r1) x column blocks [b0, b1):  X = A L^-T against the factored triangle of those blocks
+int rec_trsm(const RecCtx &c, int r0, int r1, int b0, int b1) {
+  const sp_chol_group &G = *c.G;
+  const int nb = b1 - b0;
+  if (r1 <= r0 || nb <= 0) return SP_OK;
+  if (nb <= SP_STRIP_MAXB) {
+    const double rows = r1 - r0, w = nb * 64.0;
+    SpProfScope prof(c.h, G.st, SP_PROF_STRIP, (double)G.S * rows * w * w);
+    return sp_launch_strip(G.sys, c.ld, c.stride, G.S, r0, (r1 - r0) / SP_NB, b0 * SP_NB, nb,
+                           rec_img(c, b0), c.lts, G.st);
+  }
+  const int bm = b0 + (nb + 1) / 2;
+  int rc = rec_trsm(c, r0, r1, b0, bm);
+  if (rc != SP_OK) return rc;
+  {
+    const double *A = G.sys + (size_t)r0 * c.ld + b0 * SP_NB;
+    const double *B = G.sys + (size_t)bm * SP_NB * c.ld + b0 * SP_NB;
+    double *C = G.sys + (size_t)r0 * c.ld + bm * SP_NB;
+    SpProfScope prof(c.h, G.st, SP_PROF_STRIP,
+                     (double)G.S * 2.0 * (r1 - r0) * ((b1 - bm) * 64.0) * ((bm - b0) * 64.0));
+    rc = sp_launch_gemm_nt(A, c.ld, c.stride, B, c.ld, c.stride, C, c.ld, c.stride, r1 - r0,
+                           (b1 - bm) * SP_NB, (bm - b0) * SP_NB, -1.0, 1, 0, G.S, G.st);
+    if (rc != SP_OK) return rc;
+  }
+  return rec_trsm(c, r0, r1, bm, b1);
+}
+
+int rec_factor(const RecCtx &c, int b0, int b1) {
+  const sp_chol_group &G = *c.G;
+  const int nb = b1 - b0;
+  if (nb <= 0) return SP_OK;
+  if (nb <= SP_REC_BASE) return rec_base(c, b0, b1);
+  // split on a multiple of the base size where possible (equal halves at K = 1000)
+  int bm = b0 + ((nb / 2 + SP_REC_BASE - 1) / SP_REC_BASE) * SP_REC_BASE;
+  if (bm >= b1) bm = b0 + nb / 2;
+  int rc = rec_factor(c, b0, bm);
+  if (rc != SP_OK) return rc;
+  const int rend = b1 * SP_NB;
+  if ((rc = rec_trsm(c, bm * SP_NB, rend, b0, bm)) != SP_OK) return rc;
+  if ((rc = bulk_update(c.h, G.sys, c.ld, c.stride, G.S, b0 * SP_NB, bm * SP_NB, rend,
+                        (bm - b0) * SP_NB, G.st, c.lts)) != SP_OK)
+    return rc;
+  return rec_factor(c, bm, b1);
+}
+}  // namespace
+
+static int cholesky_recursive(sp_handle *h, int ngroups, const sp_chol_group *grp, int K, int Kp) {
+  for (int g = 0; g < ngroups; ++g) {
+    RecCtx c{h, &grp[g], K, Kp, (K + SP_NB - 1) / SP_NB, (long)Kp, (long)Kp * Kp, sp_lt_stride(Kp)};
+    int rc = rec_factor(c, 0, c.nsteps);
+    if (rc != SP_OK) return rc;
+    // rows below the last pivot block (residual rows of a wide right-hand side): solved against
+    // the whole factor
+    if ((rc = rec_trsm(c, c.nsteps * SP_NB, Kp, 0, c.nsteps)) != SP_OK) return rc;
+  }
+  return SP_OK;
 }
 
 // In-place factorisation of S padded systems (Kp x Kp, ld = Kp): the leading
 // K x K part is factored, rows K..Kp-1 only receive the triangular solve.
 //
-// Two-level blocking.  Panels (64 columns) are grouped in super-panels of w
+// chol_mode 2 (default): the recursive driver above.
+// chol_mode 0 / 1: two-level blocking.  Panels (64 columns) are grouped in super-panels of w
 // panels.  Inside a super-panel a block column is brought up to date
 // left-looking (ONE narrow product over the q previous panels of the group,
 // k = 64 q) just before it is factored; the big trailing matrix is touched once
@@ -491,8 +608,10 @@ static int diag_and_solve(double *sys, long ld, long stride, int S, int K, int K
 // measured 4.0 TB/s, profiles/r01_*); k = 64 w divides that traffic by w.
 int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *grp, int K,
                               int Kp) {
-  const long ld = Kp, stride = (long)Kp * Kp;
+  const long ld = Kp, stride = (long)Kp * Kp, lts = sp_lt_stride(Kp);
   const int nsteps = (K + SP_NB - 1) / SP_NB;
+  if (h && h->chol_mode == 2 && h->fuse_diag && h->eager)
+    return cholesky_recursive(h, ngroups, grp, K, Kp);
   // panels per super-panel: wider super-panels raise the arithmetic intensity of the
   // trailing update (k = 64 w) at the price of more left-looking work per block column;
   // measured with the eager diagonal updates: K = 1000 (16 panels) w = 2 / 4 / 6 / 8 /
@@ -503,9 +622,9 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
     // next diagonal block; the L_d^T images ping-pong between the two slots of a star
     for (int g = 0; g < ngroups; ++g) {
       const sp_chol_group &G = grp[g];
-      hipLaunchKernelGGL(diag_kernel<false>, dim3(G.S), dim3(256), 0, G.st, G.sys, ld, stride, 0,
-                         K < SP_NB ? K : SP_NB, G.invL, G.info, nullptr);
-      SP_LAUNCH_CHECK();
+      int rc = launch_diag(h, G.sys, ld, stride, G.S, 0, K < SP_NB ? K : SP_NB, G.invL, lts, G.info,
+                           G.st);
+      if (rc != SP_OK) return rc;
     }
     for (int s0 = 0; s0 < nsteps; s0 += w) {
       const int cS = s0 * SP_NB;
@@ -522,6 +641,10 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
           const sp_chol_group &G = grp[g];
           const double *lt_in = G.invL + (size_t)(j & 1) * SP_LT_IMG;
           double *lt_out = G.invL + (size_t)((j + 1) & 1) * SP_LT_IMG;
+          const double rows = Kp - r1;
+          SpProfScope prof(h, G.st, SP_PROF_CHAIN,
+                           (double)G.S * (2.0 * rows * 64 * (q * 64.0) + rows * 64 * 64 +
+                                          neager * 64.0 * 64 * 64 + 64.0 * 64 * 64 / 3));
           int rc;
           if (nact < SP_NB) {
             // partial last block: the rows of its own diagonal tile below the active ones
@@ -529,15 +652,15 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
             // the whole tile -- and are only solved; the rows beyond the tile get the product
             rc = sp_launch_panel(G.sys + (size_t)r1 * ld + cS, ld, G.sys + (size_t)c0 * ld + cS, ld,
                                  G.sys + (size_t)r1 * ld + c0, ld, stride, c1 - r1, 0, G.S, lt_in,
-                                 lt_out, 0, 0, G.info, G.st);
+                                 lt_out, lts, 0, 0, G.info, G.st);
             if (rc != SP_OK) return rc;
             rc = sp_launch_panel(G.sys + (size_t)c1 * ld + cS, ld, G.sys + (size_t)c0 * ld + cS, ld,
                                  G.sys + (size_t)c1 * ld + c0, ld, stride, Kp - c1, q * SP_NB, G.S,
-                                 lt_in, lt_out, 0, 0, G.info, G.st);
+                                 lt_in, lt_out, lts, 0, 0, G.info, G.st);
           } else {
             rc = sp_launch_panel(G.sys + (size_t)r1 * ld + cS, ld, G.sys + (size_t)c0 * ld + cS, ld,
                                  G.sys + (size_t)r1 * ld + c0, ld, stride, Kp - r1, q * SP_NB, G.S,
-                                 lt_in, lt_out, neager, next_nact, G.info, G.st);
+                                 lt_in, lt_out, lts, neager, next_nact, G.info, G.st);
           }
           if (rc != SP_OK) return rc;
         }
@@ -546,8 +669,8 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
       if (cE < K) {
         for (int g = 0; g < ngroups; ++g) {
           const sp_chol_group &G = grp[g];
-          int rc = bulk_update(h, G.sys, ld, stride, G.S, cS, cE, Kp, w * SP_NB, G.st, 0, nullptr,
-                               nullptr, 0, 1);
+          int rc = bulk_update(h, G.sys, ld, stride, G.S, cS, cE, Kp, w * SP_NB, G.st, lts, 0,
+                               nullptr, nullptr, 0, 1);
           if (rc != SP_OK) return rc;
         }
       }
@@ -576,13 +699,10 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
           // left-looking update of block column j by panels s0..j-1; the tile-(0,0)
           // workgroup goes on to factor the diagonal block (fused), so only the
           // panel solve remains as a separate launch
-          double *A = G.sys + (size_t)c0 * ld + cS;
-          double *T = G.sys + (size_t)c0 * ld + c0;
-          int rc = sp_launch_gemm_nt_diag(A, ld, stride, A, ld, stride, T, ld, stride, Kp - c0,
-                                          SP_NB, q * SP_NB, -1.0, 0, G.S, nact, G.invL, G.info,
-                                          G.st, h->eager ? 1 : 0);
+          int rc = launch_blockcol_diag(h, G, ld, stride, c0, cS, Kp, q, nact, G.invL, lts,
+                                        h->eager ? 1 : 0);
           if (rc != SP_OK) return rc;
-          rc = launch_trsm(G.sys, ld, stride, G.S, c0 + nact, c0, Kp, G.invL, G.st, neager);
+          rc = launch_trsm(h, G.sys, ld, stride, G.S, c0 + nact, c0, Kp, G.invL, lts, G.st, neager);
           if (rc != SP_OK) return rc;
           continue;
         }
@@ -596,7 +716,7 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
         // first panel of a super-panel: its diagonal block was factored by the
         // fused bulk update of the previous super-panel (if fusing is on)
         const bool have_diag = q == 0 && s0 > 0 && h && h->fuse_diag > 1;
-        int rc = diag_and_solve(G.sys, ld, stride, G.S, K, Kp, j, G.info, G.invL, G.st,
+        int rc = diag_and_solve(h, G.sys, ld, stride, G.S, K, Kp, j, G.info, G.invL, lts, G.st,
                                 have_diag, neager);
         if (rc != SP_OK) return rc;
       }
@@ -606,7 +726,7 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
       const int nactE = K - cE < SP_NB ? K - cE : SP_NB;
       for (int g = 0; g < ngroups; ++g) {
         int rc = bulk_update(h, grp[g].sys, ld, stride, grp[g].S, cS, cE, Kp, w * SP_NB,
-                             grp[g].st, (h && h->fuse_diag > 1) ? nactE : 0, grp[g].invL,
+                             grp[g].st, lts, (h && h->fuse_diag > 1) ? nactE : 0, grp[g].invL,
                              grp[g].info, (h && h->fuse_diag > 1 && h->eager) ? 1 : 0);
         if (rc != SP_OK) return rc;
       }
@@ -628,12 +748,8 @@ int sp_debug_phase(sp_handle *h, double *sys, int S, int K, int Kp, int32_t *inf
   const long ld = Kp, stride = (long)Kp * Kp;
   const int c0 = j * SP_NB;
   const int nact = K - c0 < SP_NB ? K - c0 : SP_NB;
-  if (phase == 0) {
-    hipLaunchKernelGGL(diag_kernel<false>, dim3(S), dim3(256), 0, st, sys, ld, stride, c0, nact,
-                       invL, info, nullptr);
-    SP_LAUNCH_CHECK();
-    return SP_OK;
-  }
+  const long lts = sp_lt_stride(Kp);
+  if (phase == 0) return launch_diag(nullptr, sys, ld, stride, S, c0, nact, invL, lts, info, st);
   if (phase == 5) {
     const int nb = 256 * (j > 0 ? j : 1), iters = 20000;
     long long *ts = nullptr;
@@ -668,13 +784,13 @@ int sp_debug_phase(sp_handle *h, double *sys, int S, int K, int Kp, int32_t *inf
     return SP_OK;
   }
   if (phase == 4)  // the rank-256 trailing update of the first super-panel, not fused
-    return bulk_update(nullptr, sys, ld, stride, S, 0, 4 * SP_NB, Kp, 4 * SP_NB, st);
+    return bulk_update(nullptr, sys, ld, stride, S, 0, 4 * SP_NB, Kp, 4 * SP_NB, st, lts);
   if (phase == 3) {  // in-kernel timestamps of the diagonal-block kernel, printed to stderr
     long long *dbg = nullptr;
     SP_HIP(hipMalloc(&dbg, sizeof(long long) * 40 * S));
     for (int rep = 0; rep < 3; ++rep) {
       hipLaunchKernelGGL(diag_kernel<true>, dim3(S), dim3(256), 0, st, sys, ld, stride, c0, nact,
-                         invL, info, dbg);
+                         invL, lts, info, dbg);
       SP_LAUNCH_CHECK();
     }
     SP_HIP(hipStreamSynchronize(st));
@@ -705,9 +821,9 @@ int sp_debug_phase(sp_handle *h, double *sys, int S, int K, int Kp, int32_t *inf
     return SP_OK;
   }
   if (phase == 1) {
-    return launch_trsm(sys, ld, stride, S, c0 + nact, c0, Kp, invL, st);
+    return launch_trsm(nullptr, sys, ld, stride, S, c0 + nact, c0, Kp, invL, lts, st);
   }
-  return bulk_update(nullptr, sys, ld, stride, S, c0, c0 + SP_NB, Kp, SP_NB, st);
+  return bulk_update(nullptr, sys, ld, stride, S, c0, c0 + SP_NB, Kp, SP_NB, st, lts);
 }
 
 int sp_launch_lnlike_reduce(const double *sys, int S, int K, int M, int Kp,

@@ -22,6 +22,7 @@
 #include "sp_internal.h"
 #include "sp_tile.h"
 #include "sp_mm.h"
+#include "sp_wt.h"
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
     const double *__restrict__ B, long ldb, long strideB, double *C,
     long ldc, long strideC, int Mrows, int Nrows, int Kd, double alpha,
     int beta, int lower_only, int batch, int ntm, int ntn, int ntiles, int nact,
-    double *invL_all, int32_t *info, int skip00, const double *lt_in) {
+    double *invL_all, int32_t *info, int skip00, const double *lt_in, long lts) {
   // Padded LDS row of BK + 1 doubles.  hipcc fuses the per-k-step fragment reads
   // into ds_read2_b64, which is banked mod 32 dwords in 16-lane groups: an ODD
   // row length puts the 16 rows of a group on 16 distinct bank pairs.  (An even
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
 #pragma unroll
       for (int r = 0; r < 4; ++r) sT[(16 * wave + fk + 4 * r) * XW + 16 * n + fr] = acc[n][r];
     LtRegs lt;
-    lt_load(lt, lt_in + (size_t)mtx * SP_LT_STRIDE);
+    lt_load(lt, lt_in + (size_t)mtx * lts);
     __syncthreads();
     double x[16];
 #pragma unroll
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
         sD[li * BLD + lj] = v;
       }
     __syncthreads();
-    const int notpd = diag_block(sD, sRd, invL_all + (size_t)mtx * SP_LT_STRIDE);
+    const int notpd = diag_block(sD, sRd, invL_all + (size_t)mtx * lts);
     if (notpd && info) info[mtx] = 1;
     {
       const int cj = (threadIdx.x & 15) * 4, ri = threadIdx.x >> 4;
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
         sD[li * BLD + lj] = v;
       }
     __syncthreads();
-    const int notpd = diag_block(sD, sRd, invL_all + (size_t)mtx * SP_LT_STRIDE);
+    const int notpd = diag_block(sD, sRd, invL_all + (size_t)mtx * lts);
     if (notpd && info) info[mtx] = 1;
     const int cj = (threadIdx.x & 15) * 4, ri = threadIdx.x >> 4;
 #pragma unroll
@@ -432,6 +433,110 @@ __global__ __launch_bounds__(256) void mm_nt_kernel(
       }
 }
 
+
+// ---- wave-tile kernel (sp_wt.h): each wavefront a 64 x 64 tile fed straight from L2 -----------
+// A workgroup is a 2 x 2 arrangement of wave tiles (a 128 x 128 super-tile: the two wavefronts of
+// a tile row read the same A panel, those of a tile column the same B panel, within one CU's L1).
+// lower_only: super-tiles on or below the diagonal; inside a diagonal super-tile the wavefront
+// above the diagonal has nothing to do, and a diagonal wave tile of a symmetric update (same_ab:
+// A and B are the same rows) loads its panel once and forms only the blocks on or below its own
+// diagonal.  Tiles beyond an odd tile count are skipped by their wavefront.
+template <bool SGN>
+__global__ __launch_bounds__(256, 2) void wt_nt_kernel(
+    const double *__restrict__ A, long lda, long strideA, const double *__restrict__ B, long ldb,
+    long strideB, double *__restrict__ C, long ldc, long strideC, int ntm, int ntn, int Kd,
+    double alpha, int beta, int lower_only, int same_ab, int batch, int nsn, int nsuper,
+    int skip00) {
+  int mtx, st;
+  if (!sp_xcd_decode(blockIdx.x, batch, nsuper, mtx, st)) return;
+  int si, sj;
+  if (lower_only) {
+    si = (int)((sqrt(8.0 * st + 1.0) - 1.0) * 0.5);
+    while (si * (si + 1) / 2 > st) --si;
+    while ((si + 1) * (si + 2) / 2 <= st) ++si;
+    sj = st - si * (si + 1) / 2;
+  } else {
+    si = st / nsn;
+    sj = st % nsn;
+  }
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ti = 2 * si + (wave >> 1), tj = 2 * sj + (wave & 1);
+  if (ti >= ntm || tj >= ntn) return;
+  if (lower_only && tj > ti) return;
+  if (skip00 && lower_only && ti == 0 && tj == 0) return;
+  const double *Ab = A + (size_t)mtx * strideA + (size_t)ti * 64 * lda;
+  const double *Bb = B + (size_t)mtx * strideB + (size_t)tj * 64 * ldb;
+  double *Cb = C + (size_t)mtx * strideC + (size_t)ti * 64 * ldc + (size_t)tj * 64;
+  wt_d4 acc[4][4];
+  (void)same_ab;
+  if (SGN && beta) {   // (one uniform branch around ALL the loads: a select per element serialises them)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[m][n][r] = Cb[(size_t)wt_row(m, r) * ldc + wt_col(n)];
+    if (alpha < 0.0) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = -acc[m][n];
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[m][n] = wt_d4{0.0, 0.0, 0.0, 0.0};
+  }
+  WT<false> w;
+  w.init(Ab, lda, Bb, ldb);
+  w.run(Kd, acc);
+  if (SGN) {
+    if (alpha < 0.0) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = -acc[m][n];
+    }
+  } else if (beta) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[m][n][r] = fma(alpha, acc[m][n][r], Cb[(size_t)wt_row(m, r) * ldc + wt_col(n)]);
+  } else {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[m][n] = alpha * acc[m][n];
+  }
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cb[(size_t)wt_row(m, r) * ldc + wt_col(n)] = acc[m][n][r];
+}
+
+static int wt_launch(const double *A, long lda, long strideA, const double *B, long ldb, long strideB,
+                     double *C, long ldc, long strideC, int Mrows, int Nrows, int Kd, double alpha,
+                     int beta, int lower_only, int batch, hipStream_t st, int skip00) {
+  const int ntm = Mrows / 64, ntn = Nrows / 64;
+  const int nsm = (ntm + 1) / 2, nsn = (ntn + 1) / 2;
+  const int nsuper = lower_only ? nsm * (nsm + 1) / 2 : nsm * nsn;
+  const long nblk = sp_xcd_grid(batch, nsuper);
+  if (nblk > 0x7fffffffL) return SP_ERR_INVALID;
+  const int same_ab = (A == B && lda == ldb && strideA == strideB) ? 1 : 0;
+  if (alpha != 1.0 && alpha != -1.0) return SP_ERR_INVALID;   // (general alpha: mm_nt_kernel)
+  hipLaunchKernelGGL((wt_nt_kernel<true>), dim3((unsigned)nblk), dim3(256), 0, st, A, lda, strideA, B,
+                     ldb, strideB, C, ldc, strideC, ntm, ntn, Kd, alpha, beta, lower_only, same_ab,
+                     batch, nsn, nsuper, skip00);
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}
+
 template <int TM, int TN, int BK, int NS, int WR>
 int mm_launch(const double *A, long lda, long strideA, const double *B, long ldb, long strideB,
               double *C, long ldc, long strideC, int Mrows, int Nrows, int Kd, double alpha, int beta,
@@ -461,7 +566,7 @@ void sp_set_mm_variant(int v) { g_mm_variant = v; }
 static int launch_gemm(const double *A, long lda, long strideA, const double *B, long ldb,
                        long strideB, double *C, long ldc, long strideC, int Mrows, int Nrows,
                        int Kd, double alpha, int beta, int lower_only, int batch, int fuse,
-                       int nact, double *invL, int32_t *info, hipStream_t st, int skip00 = 0) {
+                       int nact, double *invL, long lts, int32_t *info, hipStream_t st, int skip00 = 0) {
   if (Mrows <= 0 || Nrows <= 0 || batch <= 0) return SP_OK;
   if (Kd < 0) return SP_ERR_INVALID;
   const int ntm = (Mrows + GT - 1) / GT, ntn = (Nrows + GT - 1) / GT;
@@ -480,11 +585,11 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
 #define SP_GO_FAST(FD)                                                                       \
   hipLaunchKernelGGL((gemm_nt_kernel<32, false, FD, 0, true>), dim3((unsigned)nblk), dim3(256), 0, \
                      st, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd,  \
-                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00, nullptr)
+                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00, nullptr, lts)
 #define SP_GO(BK, DC, FD)                                                              \
   hipLaunchKernelGGL((gemm_nt_kernel<BK, DC, FD>), dim3((unsigned)nblk), dim3(256), 0, st, \
                      A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd, \
-                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00, nullptr)
+                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00, nullptr, lts)
   static int abl = -1;
   if (abl < 0) {
     const char *e = getenv("SP_GEMM_ABL");
@@ -493,7 +598,7 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
 #define SP_GO_ABL(N)                                                                          \
   hipLaunchKernelGGL((gemm_nt_kernel<32, false, 0, N>), dim3((unsigned)nblk), dim3(256), 0, st, \
                      A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd,       \
-                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00, nullptr)
+                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00, nullptr, lts)
   if (g_mm_variant < 0) {
     const char *e = getenv("SP_MM");
     g_mm_variant = e ? atoi(e) : 1;
@@ -504,6 +609,9 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
 #define SP_MM_GO(TM, TN, BK, NS, WR)                                                              \
   return mm_launch<TM, TN, BK, NS, WR>(A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, \
                                        Nrows, Kd, alpha, beta, lower_only, batch, st, skip00)
+    if (mmv == 9 && (Kd % 16) == 0 && (alpha == 1.0 || alpha == -1.0))
+      return wt_launch(A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd, alpha, beta,
+                       lower_only, batch, st, skip00);
     const bool big = (Mrows % 128) == 0 && (Nrows % 128) == 0;
     if (mmv == 3 && big) SP_MM_GO(128, 128, 8, 4, 2);
     if (mmv == 8 && big) SP_MM_GO(128, 128, 8, 3, 2);
@@ -531,7 +639,7 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
   } else if (fast && variant == 2 && (Kd % 64) == 0) {
     hipLaunchKernelGGL((gemm_nt_kernel<64, false, 0, 0, true>), dim3((unsigned)nblk), dim3(256), 0,
                        st, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd,
-                       alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00, nullptr);
+                       alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00, nullptr, lts);
   } else {
     switch (variant) {
       case 1: SP_GO(32, true, 0); break;
@@ -551,7 +659,7 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
 // tiles, and the first of those is factored (next_nact > 0) into lt_out.
 int sp_launch_panel(const double *A, long lda, const double *B, long ldb, double *C, long ldc,
                     long stride, int Mrows, int Kd, int batch, const double *lt_in, double *lt_out,
-                    int neager, int next_nact, int32_t *info, hipStream_t st) {
+                    long lts, int neager, int next_nact, int32_t *info, hipStream_t st) {
   if (Mrows <= 0 || batch <= 0) return SP_OK;
   const int ntm = (Mrows + GT - 1) / GT, ntn = 1, ntiles = ntm;
   const long nblk = sp_xcd_grid(batch, ntiles);
@@ -562,11 +670,11 @@ int sp_launch_panel(const double *A, long lda, const double *B, long ldb, double
   if (fast)
     hipLaunchKernelGGL((gemm_nt_kernel<32, false, 2, 0, true>), dim3((unsigned)nblk), dim3(256), 0,
                        st, A, lda, stride, B, ldb, stride, C, ldc, stride, Mrows, GT, Kd, -1.0, 1, 0,
-                       batch, ntm, ntn, ntiles, next_nact, lt_out, info, neager, lt_in);
+                       batch, ntm, ntn, ntiles, next_nact, lt_out, info, neager, lt_in, lts);
   else
     hipLaunchKernelGGL((gemm_nt_kernel<32, false, 2, 0, false>), dim3((unsigned)nblk), dim3(256), 0,
                        st, A, lda, stride, B, ldb, stride, C, ldc, stride, Mrows, GT, Kd, -1.0, 1, 0,
-                       batch, ntm, ntn, ntiles, next_nact, lt_out, info, neager, lt_in);
+                       batch, ntm, ntn, ntiles, next_nact, lt_out, info, neager, lt_in, lts);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }
@@ -576,7 +684,7 @@ int sp_launch_gemm_nt(const double *A, long lda, long strideA, const double *B, 
                       int Kd, double alpha, int beta, int lower_only, int batch,
                       hipStream_t st, int skip_tile00) {
   return launch_gemm(A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd,
-                     alpha, beta, lower_only, batch, 0, 0, nullptr, nullptr, st, skip_tile00);
+                     alpha, beta, lower_only, batch, 0, 0, nullptr, 0, nullptr, st, skip_tile00);
 }
 
 // Update (beta = 1) whose tile (0, 0) is the next diagonal block: that tile's
@@ -584,8 +692,9 @@ int sp_launch_gemm_nt(const double *A, long lda, long strideA, const double *B, 
 int sp_launch_gemm_nt_diag(const double *A, long lda, long strideA, const double *B, long ldb,
                            long strideB, double *C, long ldc, long strideC, int Mrows,
                            int Nrows, int Kd, double alpha, int lower_only, int batch,
-                           int nact, double *invL, int32_t *info, hipStream_t st, int skip00) {
+                           int nact, double *invL, long lts, int32_t *info, hipStream_t st,
+                           int skip00) {
   return launch_gemm(A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd,
-                     alpha, 1, lower_only, batch, 1, nact, invL, info, st, skip00);
+                     alpha, 1, lower_only, batch, 1, nact, invL, lts, info, st, skip00);
 }
 

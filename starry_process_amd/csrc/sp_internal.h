@@ -66,13 +66,44 @@ struct sp_handle {
   std::vector<hipStream_t> gstream;
   std::vector<hipEvent_t> gdone;
   hipEvent_t gfork;
-  // optional per-launch timing of the trailing-update kernel (bench roofline)
+  int chol_mode;                // 2: recursive driver (strip solves), 0: super-panel driver (SP_CHOL)
+  // optional per-launch timing of the factorisation's launches by kind (bench roofline)
   bool prof_on;
+  unsigned prof_mask;                // kinds that are bracketed (bit k = kind k)
   std::vector<hipEvent_t> prof_ev;   // pairs (start, stop)
+  std::vector<int> prof_kind;        // kind of pair i
+  std::vector<double> prof_fl;       // algorithmic flops of pair i
   size_t prof_used;                  // events handed out so far
-  double prof_flops;                 // algorithmic flops of the timed launches
-  long prof_launches;
 };
+
+// kinds of timed launches (sp_profile_kind)
+enum { SP_PROF_SYRK = 0, SP_PROF_STRIP = 1, SP_PROF_CHAIN = 2, SP_PROF_ASSEMBLE = 3, SP_PROF_NKINDS = 4 };
+
+// brackets the launches issued during its lifetime with a pair of events on `st`
+struct SpProfScope {
+  sp_handle *h;
+  hipStream_t st;
+  bool on;
+  SpProfScope(sp_handle *h_, hipStream_t st_, int kind, double flops) : h(h_), st(st_), on(false) {
+    if (!h || !h->prof_on || !((h->prof_mask >> kind) & 1u) || h->prof_used + 2 > h->prof_ev.size()) return;
+    if (hipEventRecord(h->prof_ev[h->prof_used], st) != hipSuccess) return;
+    h->prof_kind[h->prof_used / 2] = kind;
+    h->prof_fl[h->prof_used / 2] = flops;
+    on = true;
+  }
+  ~SpProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(h->prof_ev[h->prof_used + 1], st);
+    h->prof_used += 2;
+  }
+};
+
+// strip solve: at most this many 64-column blocks per launch (wider triangles are split)
+#define SP_STRIP_MAXB 8
+// diagonal blocks of at most this many panels are factored panel by panel
+#define SP_REC_BASE 4
+int sp_launch_strip(double *sys, long ld, long stride, int batch, int r0, int nrt, int c0, int nb,
+                    const double *lt_first, long lts, hipStream_t st);
 
 const char *sp_set_hip_error(hipError_t e, const char *what);
 
@@ -103,7 +134,7 @@ static inline int sp_roundup(int x, int m) { return ((x + m - 1) / m) * m; }
 struct sp_chol_group {
   double *sys;
   int32_t *info;
-  double *invL;
+  double *invL;      // S x sp_lt_stride(Kp) doubles
   int S;
   hipStream_t st;
 };
@@ -134,7 +165,7 @@ int sp_launch_polar_moments(sp_handle *h, const double *mu_src, const double *co
 //   Mrows, Nrows multiples of 64; Kd multiple of 4.
 int sp_launch_panel(const double *A, long lda, const double *B, long ldb, double *C, long ldc,
                     long stride, int Mrows, int Kd, int batch, const double *lt_in, double *lt_out,
-                    int neager, int next_nact, int32_t *info, hipStream_t st);
+                    long lts, int neager, int next_nact, int32_t *info, hipStream_t st);
 int sp_launch_tri_solve(const double *L, int K, long ldl, long strideL, double *B, long strideB,
                         long rs, long cs, int nrhs, int batch, int mode, hipStream_t st);
 int sp_launch_transpose(const double *in, long ldi, long stridei, double *out, int K, int batch,
@@ -152,10 +183,11 @@ void sp_set_mm_variant(int v);   // tile shape of the pipelined product (sp_gemm
 int sp_launch_gemm_nt_diag(const double *A, long lda, long strideA, const double *B, long ldb,
                            long strideB, double *C, long ldc, long strideC, int Mrows,
                            int Nrows, int Kd, double alpha, int lower_only, int batch,
-                           int nact, double *invL, int32_t *info, hipStream_t st,
+                           int nact, double *invL, long lts, int32_t *info, hipStream_t st,
                            int skip00 = 0);
 
-// per-star scratch of the factorisation (doubles): the L_d^T image of the current panel
-#define SP_LT_DOUBLES 8192   /* = SP_LT_STRIDE (sp_tile.h): two L_d^T images per star */
+// per-star scratch of the factorisation: one L_d^T image (64 x 64 doubles) per 64-column block
+// of the padded system, at least two (the ping-pong of the one-launch-per-panel mode).  Doubles.
+static inline long sp_lt_stride(int Kp) { const long nb = Kp / SP_NB; return (nb < 2 ? 2 : nb) * 4096L; }
 
 #endif

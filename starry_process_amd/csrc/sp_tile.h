@@ -29,11 +29,11 @@ static inline long sp_xcd_grid(long batch, long ntiles) { return 8L * ((batch * 
 
 #define SP_TILE_LDS_DOUBLES SP_DIAG_LDS_DOUBLES
 
-// per-star scratch of the factorisation: the L_d^T image of the current panel
+// per-star scratch of the factorisation: L_d^T images of 64 x 64 doubles, `lts` doubles apart
+// from star to star (sp_lt_stride, sp_internal.h).  The one-launch-per-panel mode ping-pongs
+// between the first two (it writes the next panel's image while the workgroups of the current
+// launch still read this one); the recursive driver keeps the image of every block.
 #define SP_LT_IMG 4096
-// two images per star: the one-launch-per-panel mode writes the next panel's image while the
-// workgroups of the current launch still read this one (ping-pong by panel parity)
-#define SP_LT_STRIDE (2 * SP_LT_IMG)
 
 // ---- substitution (shared with trsm_quad_kernel) ------------------------------
 struct TrsmRow {
