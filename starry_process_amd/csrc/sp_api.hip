@@ -402,7 +402,7 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
   h->prof_on = false;
   h->prof_mask = 1u;
   h->prof_used = 0;
-  h->chol_mode = 2;
+  h->chol_mode = 0;
   const int N = h->N;
   h->l_of.resize(N);
   h->m_of.resize(N);
@@ -448,7 +448,7 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
     const char *e3 = getenv("SP_GROUPS");
     h->groups = e3 ? atoi(e3) : 1;
     const char *e8 = getenv("SP_CHOL");
-    h->chol_mode = e8 ? atoi(e8) : 2;
+    h->chol_mode = e8 ? atoi(e8) : 0;
     const char *e2 = getenv("SP_SUPER");
     h->superpanel = e2 ? atoi(e2) : 0;   // 0: chosen from K (sp_launch_cholesky_groups)
     if (h->superpanel < 0) h->superpanel = 0;
@@ -1059,6 +1059,10 @@ int sp_debug_cholesky_phase(sp_handle *h, int S, int K, int M, void *workspace_d
 }
 
 int sp_debug_set_mm_variant(int variant) {
+  if (variant >= 100) {   // 100 + f: ablation flags of the strip solve (tools/strip_bench.py)
+    sp_set_strip_flags(variant - 100);
+    return SP_OK;
+  }
   if (variant < 0 || variant > 16) return SP_ERR_INVALID;
   sp_set_mm_variant(variant);
   return SP_OK;

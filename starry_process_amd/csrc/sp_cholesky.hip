@@ -105,28 +105,42 @@ __global__ __launch_bounds__(256) void diag_kernel(double *__restrict__ sys, lon
 __global__ __launch_bounds__(256) void trsm_quad_kernel(double *sys, long ld, long stride,
                                                         int r1, int c0, int nrows,
                                                         const double *__restrict__ LT_all, long lts,
-                                                        int batch, int ntiles, int neager) {
+                                                        int batch, int ntiles, int neager,
+                                                        double *__restrict__ inv_all) {
   __shared__ __attribute__((aligned(16))) double sLT[64 * 64 + 64];
   // XCD-aware decode as in sp_gemm.hip (sp_tile.h)
   int mtx, tile;
-  if (!sp_xcd_decode(blockIdx.x, batch, ntiles, mtx, tile)) return;
+  if (!sp_xcd_decode(blockIdx.x, batch, ntiles + (inv_all ? 1 : 0), mtx, tile)) return;
   const int tid = threadIdx.x;
   const int lrow = tile * 64 + (tid >> 2), q = tid & 3;
-  const bool valid = lrow < nrows;
-  double *prow = sys + (size_t)mtx * stride + (size_t)(r1 + (valid ? lrow : 0)) * ld + c0 + 2 * q;
+  // inv_all: one more tile per star whose rows are those of the identity -- solved like any
+  // other, it is L_d^-T (row k, column n: (L_d^-1)[n][k]), the operand with which the strip
+  // solves (sp_strip.hip) apply this block on the matrix cores; off the chain, beside the others
+  const bool ident = tile == ntiles;
+  const bool valid = ident || lrow < nrows;
+  double *prow = ident ? inv_all + (size_t)mtx * lts + (size_t)(tid >> 2) * 64 + 2 * q
+                       : sys + (size_t)mtx * stride + (size_t)(r1 + (valid ? lrow : 0)) * ld + c0 + 2 * q;
   LtRegs lt;
   lt_load(lt, LT_all + (size_t)mtx * lts);
   double x[16];
+  if (ident) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const d2v v = *reinterpret_cast<const d2v *>(prow + 8 * i);
-    x[2 * i] = v.x;
-    x[2 * i + 1] = v.y;
+    for (int i = 0; i < 8; ++i) {
+      x[2 * i] = (8 * i + 2 * q == (tid >> 2)) ? 1.0 : 0.0;
+      x[2 * i + 1] = (8 * i + 2 * q + 1 == (tid >> 2)) ? 1.0 : 0.0;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const d2v v = *reinterpret_cast<const d2v *>(prow + 8 * i);
+      x[2 * i] = v.x;
+      x[2 * i + 1] = v.y;
+    }
   }
   lt_store(lt, sLT, sLT + 4096);
   __syncthreads();
   quad_solve_store(x, sLT, sLT + 4096, prow, valid);
-  if (tile >= neager) return;
+  if (ident || tile >= neager) return;
   // Eager update of a coming diagonal block.  The first `neager` row tiles of this panel are
   // the rows of the pivot blocks still to be factored before the next trailing update reaches
   // them; each takes its share D_ii -= X_i X_i^T now, from the rows it has just solved, so
@@ -445,16 +459,17 @@ static int bulk_update(sp_handle *h, double *sys, long ld, long stride, int S, i
 // rows r1..rend-1 of panel column c0: X = P L_d^-T in place (LT = diag_block's output)
 // neager: leading row tiles that also update their own diagonal block (trsm_quad_kernel)
 static int launch_trsm(sp_handle *h, double *sys, long ld, long stride, int S, int r1, int c0,
-                       int rend, const double *LT, long lts, hipStream_t st, int neager = 0) {
-  const int nrows = rend - r1;
-  if (nrows <= 0) return SP_OK;
+                       int rend, const double *LT, long lts, hipStream_t st, int neager = 0,
+                       double *inv_out = nullptr) {
+  const int nrows = rend - r1 > 0 ? rend - r1 : 0;
+  if (nrows <= 0 && !inv_out) return SP_OK;
   const int ntiles = (nrows + 63) / 64;
-  const long nblk = sp_xcd_grid(S, ntiles);
+  const long nblk = sp_xcd_grid(S, ntiles + (inv_out ? 1 : 0));
   // substitution: 64 x 64 multiply-adds per row; each eager update a 64 x 64 x 64 product
   SpProfScope prof(h, st, SP_PROF_CHAIN,
                    (double)S * (2.0 * nrows * 64 * 64 / 2 + 2.0 * neager * 64 * 64 * 64 / 2));
   hipLaunchKernelGGL(trsm_quad_kernel, dim3((unsigned)nblk), dim3(256), 0, st, sys, ld, stride,
-                     r1, c0, nrows, LT, lts, S, ntiles, neager);
+                     r1, c0, nrows, LT, lts, S, ntiles, neager, inv_out);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }
@@ -515,7 +530,8 @@ struct RecCtx {
   int K, Kp, nsteps;
   long ld, stride, lts;
 };
-inline double *rec_img(const RecCtx &c, int j) { return c.G->invL + (size_t)j * SP_LT_IMG; }
+// block j's slot: its L_d^T image, then L_d^-T
+inline double *rec_img(const RecCtx &c, int j) { return c.G->invL + (size_t)j * 2 * SP_LT_IMG; }
 
 int rec_base(const RecCtx &c, int b0, int b1) {
   const sp_chol_group &G = *c.G;
@@ -531,7 +547,7 @@ int rec_base(const RecCtx &c, int b0, int b1) {
       rc = launch_diag(c.h, G.sys, c.ld, c.stride, G.S, c0, nact, rec_img(c, j), c.lts, G.info, G.st);
     if (rc != SP_OK) return rc;
     rc = launch_trsm(c.h, G.sys, c.ld, c.stride, G.S, c0 + nact, c0, rend, rec_img(c, j), c.lts, G.st,
-                     nact == SP_NB ? neager : 0);
+                     nact == SP_NB ? neager : 0, rec_img(c, j) + SP_LT_IMG);
     if (rc != SP_OK) return rc;
   }
   return SP_OK;
@@ -546,7 +562,7 @@ int rec_trsm(const RecCtx &c, int r0, int r1, int b0, int b1) {
     const double rows = r1 - r0, w = nb * 64.0;
     SpProfScope prof(c.h, G.st, SP_PROF_STRIP, (double)G.S * rows * w * w);
     return sp_launch_strip(G.sys, c.ld, c.stride, G.S, r0, (r1 - r0) / SP_NB, b0 * SP_NB, nb,
-                           rec_img(c, b0), c.lts, G.st);
+                           rec_img(c, b0) + SP_LT_IMG, c.lts, G.st);
   }
   const int bm = b0 + (nb + 1) / 2;
   int rc = rec_trsm(c, r0, r1, b0, bm);
@@ -782,6 +798,18 @@ int sp_debug_phase(sp_handle *h, double *sys, int S, int K, int Kp, int32_t *inf
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return SP_OK;
+  }
+  if (phase == 6 || phase == 7 || phase == 8) {
+    // pieces of the recursive driver on whatever the workspace holds (timing only):
+    // 6 the top-level strip solve, 7 the top-level symmetric update, 8 base block j (4 panels)
+    sp_chol_group G{sys, info, invL, S, st};
+    RecCtx c{h, &G, K, Kp, (K + SP_NB - 1) / SP_NB, ld, stride, lts};
+    const int nb = c.nsteps, bm = ((nb / 2 + SP_REC_BASE - 1) / SP_REC_BASE) * SP_REC_BASE;
+    if (phase == 6) return rec_trsm(c, bm * SP_NB, nb * SP_NB, 0, bm);
+    if (phase == 7)
+      return bulk_update(h, sys, ld, stride, S, 0, bm * SP_NB, nb * SP_NB, bm * SP_NB, st, lts);
+    const int b0 = j * SP_REC_BASE, b1 = b0 + SP_REC_BASE < nb ? b0 + SP_REC_BASE : nb;
+    return b0 < nb ? rec_base(c, b0, b1) : SP_ERR_INVALID;
   }
   if (phase == 4)  // the rank-256 trailing update of the first super-panel, not fused
     return bulk_update(nullptr, sys, ld, stride, S, 0, 4 * SP_NB, Kp, 4 * SP_NB, st, lts);

@@ -374,12 +374,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
 namespace {
 // SGN: alpha is +1 or -1 and the accumulators start from +-C (no second register tile, exact);
 // otherwise the C tile waits in registers and is combined after the loop.
-template <int TM, int TN, int BK, int NS, int WR, bool SGN>
+template <class Core, bool SGN>
 __global__ __launch_bounds__(256) void mm_nt_kernel(
     const double *__restrict__ A, long lda, long strideA, const double *__restrict__ B, long ldb,
     long strideB, double *__restrict__ C, long ldc, long strideC, int Kd, double alpha, int beta,
     int lower_only, int batch, int ntn, int ntiles, int skip00) {
-  using Core = MM<TM, TN, BK, NS, WR>;
+  constexpr int TM = Core::TM_, TN = Core::TN_;
   __shared__ __attribute__((aligned(16))) double lds[Core::LDS_DOUBLES];
   int mtx, tile;
   if (!sp_xcd_decode(blockIdx.x, batch, ntiles, mtx, tile)) return;
@@ -537,20 +537,20 @@ static int wt_launch(const double *A, long lda, long strideA, const double *B, l
   return SP_OK;
 }
 
-template <int TM, int TN, int BK, int NS, int WR>
+template <class Core>
 int mm_launch(const double *A, long lda, long strideA, const double *B, long ldb, long strideB,
               double *C, long ldc, long strideC, int Mrows, int Nrows, int Kd, double alpha, int beta,
               int lower_only, int batch, hipStream_t st, int skip00) {
-  const int ntm = Mrows / TM, ntn = Nrows / TN;
+  const int ntm = Mrows / Core::TM_, ntn = Nrows / Core::TN_;
   const int ntiles = lower_only ? ntm * (ntm + 1) / 2 : ntm * ntn;
   const long nblk = sp_xcd_grid(batch, ntiles);
   if (nblk > 0x7fffffffL) return SP_ERR_INVALID;
   if (alpha == 1.0 || alpha == -1.0)
-    hipLaunchKernelGGL((mm_nt_kernel<TM, TN, BK, NS, WR, true>), dim3((unsigned)nblk), dim3(256), 0, st,
+    hipLaunchKernelGGL((mm_nt_kernel<Core, true>), dim3((unsigned)nblk), dim3(256), 0, st,
                        A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Kd, alpha, beta, lower_only,
                        batch, ntn, ntiles, skip00);
   else
-    hipLaunchKernelGGL((mm_nt_kernel<TM, TN, BK, NS, WR, false>), dim3((unsigned)nblk), dim3(256), 0, st,
+    hipLaunchKernelGGL((mm_nt_kernel<Core, false>), dim3((unsigned)nblk), dim3(256), 0, st,
                        A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Kd, alpha, beta, lower_only,
                        batch, ntn, ntiles, skip00);
   SP_LAUNCH_CHECK();
@@ -601,26 +601,36 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
                      alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00, nullptr, lts)
   if (g_mm_variant < 0) {
     const char *e = getenv("SP_MM");
-    g_mm_variant = e ? atoi(e) : 1;
+    g_mm_variant = e ? atoi(e) : 11;
   }
   const int mmv = g_mm_variant;
   if (fast && !fuse && abl == 0 && mmv > 0) {
     // pipelined kernels (sp_mm.h); tile shape by SP_MM (tools/microbench.py compares them)
 #define SP_MM_GO(TM, TN, BK, NS, WR)                                                              \
-  return mm_launch<TM, TN, BK, NS, WR>(A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, \
+  return mm_launch<MM<TM, TN, BK, NS, WR>>(A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, \
                                        Nrows, Kd, alpha, beta, lower_only, batch, st, skip00)
     if (mmv == 9 && (Kd % 16) == 0 && (alpha == 1.0 || alpha == -1.0))
       return wt_launch(A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd, alpha, beta,
                        lower_only, batch, st, skip00);
+#define SP_MM2_GO(TM, TN, BK, NS, WR)                                                              \
+  return mm_launch<MM2<TM, TN, BK, NS, WR>>(A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, \
+                                            Nrows, Kd, alpha, beta, lower_only, batch, st, skip00)
+    if (mmv == 10) SP_MM2_GO(64, 64, 16, 4, 4);
+    // default (11): 128 x 128 tiles for full products of that granularity (0.80 of peak against
+    // 0.73), 64 x 64 tiles otherwise (lower-triangular updates: no wasted half tiles)
+    if ((mmv == 12 || (mmv == 11 && !lower_only)) && (Mrows % 128) == 0 && (Nrows % 128) == 0)
+      SP_MM2_GO(128, 128, 8, 4, 2);
+    if (mmv == 11) SP_MM2_GO(64, 64, 8, 6, 4);
+#undef SP_MM2_GO
     const bool big = (Mrows % 128) == 0 && (Nrows % 128) == 0;
     if (mmv == 3 && big) SP_MM_GO(128, 128, 8, 4, 2);
     if (mmv == 8 && big) SP_MM_GO(128, 128, 8, 3, 2);
     if (mmv == 5 && big) SP_MM_GO(128, 128, 16, 3, 2);
     if (mmv == 4 && (Mrows % 128) == 0 && !lower_only) SP_MM_GO(128, 64, 16, 3, 4);
     if (mmv == 2) SP_MM_GO(64, 64, 32, 3, 4);
-    if (mmv == 6) SP_MM_GO(64, 64, 16, 3, 4);
     if (mmv == 7) SP_MM_GO(64, 64, 8, 6, 4);
-    SP_MM_GO(64, 64, 16, 4, 4);
+    if (mmv == 1) SP_MM_GO(64, 64, 16, 4, 4);
+    SP_MM_GO(64, 64, 16, 3, 4);
 #undef SP_MM_GO
   }
   if (abl > 0 && !fuse) {

@@ -102,8 +102,9 @@ struct SpProfScope {
 #define SP_STRIP_MAXB 8
 // diagonal blocks of at most this many panels are factored panel by panel
 #define SP_REC_BASE 4
+// inv_first: L_d^-T of the first column block (those of the following blocks 8192 doubles apart)
 int sp_launch_strip(double *sys, long ld, long stride, int batch, int r0, int nrt, int c0, int nb,
-                    const double *lt_first, long lts, hipStream_t st);
+                    const double *inv_first, long lts, hipStream_t st);
 
 const char *sp_set_hip_error(hipError_t e, const char *what);
 
@@ -178,7 +179,8 @@ int sp_launch_gemm_nt(const double *A, long lda, long strideA, const double *B,
                       int Mrows, int Nrows, int Kd, double alpha, int beta,
                       int lower_only, int batch, hipStream_t st, int skip_tile00 = 0);
 
-void sp_set_mm_variant(int v);   // tile shape of the pipelined product (sp_gemm.hip)
+void sp_set_mm_variant(int v);
+void sp_set_strip_flags(int f);  // ablations of the strip solve (sp_strip.hip)   // tile shape of the pipelined product (sp_gemm.hip)
 
 int sp_launch_gemm_nt_diag(const double *A, long lda, long strideA, const double *B, long ldb,
                            long strideB, double *C, long ldc, long strideC, int Mrows,
@@ -188,6 +190,7 @@ int sp_launch_gemm_nt_diag(const double *A, long lda, long strideA, const double
 
 // per-star scratch of the factorisation: one L_d^T image (64 x 64 doubles) per 64-column block
 // of the padded system, at least two (the ping-pong of the one-launch-per-panel mode).  Doubles.
-static inline long sp_lt_stride(int Kp) { const long nb = Kp / SP_NB; return (nb < 2 ? 2 : nb) * 4096L; }
+// (two images per block: L_d^T for the substitution solves and L_d^-T for the strip solves)
+static inline long sp_lt_stride(int Kp) { const long nb = Kp / SP_NB; return (nb < 1 ? 1 : nb) * 8192L; }
 
 #endif

@@ -49,6 +49,7 @@ __device__ __forceinline__ void mm_wait_vmcnt() {
 // NS: LDS stages (>= 2); WR: wavefronts along the rows (1, 2 or 4)
 template <int TM, int TN, int BK, int NS, int WR>
 struct MM {
+  static constexpr int TM_ = TM, TN_ = TN;
   static constexpr int WC = 4 / WR;
   static constexpr int MA = TM / (16 * WR), NA = TN / (16 * WC);
   static constexpr int G = BK / 2;        // 16-byte granules per row of a slice
@@ -161,12 +162,210 @@ struct MM {
     }
     __builtin_amdgcn_s_barrier();
   }
+  // (ablation for the microbenchmarks: the same product with every slice fetched from the first
+  //  BK columns -- operands that stay in L2 -- results are garbage)
+  __device__ __forceinline__ void prologue_same(double *lds, int kd) const {
+    const int nsl = kd / BK;
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+      if (p < nsl) issue(lds, p, 0);
+  }
+  __device__ __forceinline__ void loop_same(double *lds, int kd, mm_d4 (&acc)[MA][NA]) const {
+    const int nsl = kd / BK;
+    if (nsl <= 0) return;
+    int st = 0, stn = NS - 1;
+    for (int s = 0; s < nsl; ++s) {
+      if (s + NS - 2 < nsl)
+        mm_wait_vmcnt<(NS - 2) * LPW>();
+      else
+        mm_wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (s + NS - 1 < nsl) issue(lds, stn, 0);
+      consume(lds, st, acc);
+      st = st + 1 == NS ? 0 : st + 1;
+      stn = stn + 1 == NS ? 0 : stn + 1;
+    }
+    __builtin_amdgcn_s_barrier();
+  }
   __device__ __forceinline__ void run(double *lds, int k_begin, int k_end, mm_d4 (&acc)[MA][NA]) const {
     prologue(lds, k_begin, k_end);
     loop(lds, k_begin, k_end, acc);
   }
 
   // accumulator element (m, n, r) is C[row, col] with:
+  __device__ __forceinline__ int acc_row(int m, int r) const {
+    const int lane = threadIdx.x & 63;
+    return (wave / WC) * (TM / WR) + 16 * m + (lane >> 4) + 4 * r;
+  }
+  __device__ __forceinline__ int acc_col(int n) const {
+    const int lane = threadIdx.x & 63;
+    return (wave % WC) * (TN / WC) + 16 * n + (lane & 15);
+  }
+};
+
+// ---- second form: 16-byte fragment reads, fragments double-buffered in registers ---------------
+// Same DMA pipeline and LDS image as MM.  Differences on the consuming side:
+//   * the MFMA sums over its 4 k-entries whatever their order as long as A and B agree, so lane
+//     (r = lane & 15, q = lane >> 4) takes the k-PAIR {8 c + 2 q, 8 c + 2 q + 1} of each 8-column
+//     chunk c with ONE ds_read_b128 and feeds two MFMAs with it (.x then .y): half the LDS
+//     instructions, and the read is conflict-free on the same swizzled image;
+//   * the fragments of slice s + 1 are read into a second register set while the MFMAs of slice s
+//     run from the first: the matrix pipe never waits for an LDS read.  The barrier of iteration s
+//     therefore guarantees slice s + 1 (not s), and the slice issued after it is s + NS.
+template <int TM, int TN, int BK, int NS, int WR>
+struct MM2 {
+  static constexpr int TM_ = TM, TN_ = TN;
+  static constexpr int WC = 4 / WR;
+  static constexpr int MA = TM / (16 * WR), NA = TN / (16 * WC);
+  static constexpr int G = BK / 2, RPI = 64 / G, RPB = 32 / BK;
+  static constexpr int IA = TM / RPI, IB = TN / RPI, LA = IA / 4, LB = IB / 4, LPW = LA + LB;
+  static constexpr int STAGE_A = TM * BK, STAGE_B = TN * BK, STAGE = STAGE_A + STAGE_B;
+  static constexpr int LDS_DOUBLES = NS * STAGE;
+  static constexpr int NC = BK / 8;          // 8-column chunks per slice
+  static_assert(BK == 8 || BK == 16 || BK == 32, "slice depth");
+  static_assert(IA % 4 == 0 && IB % 4 == 0, "a slice must split evenly over four wavefronts");
+  static_assert(NS >= 3, "one slice in registers, one landing, one being issued");
+  typedef double v2 __attribute__((ext_vector_type(2)));
+  struct Frags {
+    v2 a[NC][MA], b[NC][NA];
+  };
+  __device__ static __forceinline__ int swz(int row) { return (row / RPB) & (G - 1); }
+
+  const double *srcA[LA > 0 ? LA : 1];
+  const double *srcB[LB > 0 ? LB : 1];
+  int rdA, rdB, fsw, q, wave;
+
+  __device__ __forceinline__ void init(const double *A, long lda, const double *B, long ldb) {
+    const int lane = threadIdx.x & 63;
+    wave = threadIdx.x >> 6;
+    const int r = lane / G, p = lane % G;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      const int row = (wave + 4 * i) * RPI + r;
+      srcA[i] = A + (size_t)row * lda + 2 * (p ^ swz(row));
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+      const int row = (wave + 4 * i) * RPI + r;
+      srcB[i] = B + (size_t)row * ldb + 2 * (p ^ swz(row));
+    }
+    const int wr = wave / WC, wc = wave % WC, fr = lane & 15;
+    rdA = (wr * (TM / WR) + fr) * BK;
+    rdB = STAGE_A + (wc * (TN / WC) + fr) * BK;
+    fsw = swz(fr);
+    q = lane >> 4;
+  }
+  __device__ __forceinline__ void issue(double *lds, int st, int k0) const {
+    double *base = lds + st * STAGE;
+#pragma unroll
+    for (int i = 0; i < LA; ++i)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void *)(srcA[i] + k0),
+          (__attribute__((address_space(3))) void *)(base + (wave + 4 * i) * 128), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < LB; ++i)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void *)(srcB[i] + k0),
+          (__attribute__((address_space(3))) void *)(base + STAGE_A + (wave + 4 * i) * 128), 16, 0, 0);
+  }
+  __device__ __forceinline__ void fetch(const double *lds, int st, Frags &f) const {
+    const double *base = lds + st * STAGE;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int goff = 2 * ((4 * c + q) ^ fsw);
+#pragma unroll
+      for (int m = 0; m < MA; ++m) f.a[c][m] = *reinterpret_cast<const v2 *>(base + rdA + m * 16 * BK + goff);
+#pragma unroll
+      for (int n = 0; n < NA; ++n) f.b[c][n] = *reinterpret_cast<const v2 *>(base + rdB + n * 16 * BK + goff);
+    }
+  }
+  __device__ __forceinline__ void mul(const Frags &f, mm_d4 (&acc)[MA][NA]) const {
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int m = 0; m < MA; ++m)
+#pragma unroll
+          for (int n = 0; n < NA; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(h ? f.a[c][m].y : f.a[c][m].x,
+                                                            h ? f.b[c][n].y : f.b[c][n].x, acc[m][n], 0, 0, 0);
+  }
+  // multiply the slice held in `cur` while the fragments of the next one are read into `nxt`:
+  // the reads sit BEHIND the first MFMAs in program order (one read per MFMA), so the wait that
+  // precedes the MFMAs covers only `cur`'s own, older reads
+  __device__ __forceinline__ void mul_fetch(const Frags &cur, Frags &nxt, const double *lds, int st,
+                                            mm_d4 (&acc)[MA][NA]) const {
+    const double *base = lds + st * STAGE;
+    constexpr int NR = NC * (MA + NA);
+    int issued = 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int m = 0; m < MA; ++m)
+#pragma unroll
+          for (int n = 0; n < NA; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(h ? cur.a[c][m].y : cur.a[c][m].x,
+                                                            h ? cur.b[c][n].y : cur.b[c][n].x, acc[m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (issued < NR) {
+              const int rc = issued / (MA + NA), ri = issued % (MA + NA);
+              const int goff = 2 * ((4 * rc + q) ^ fsw);
+              if (ri < MA)
+                nxt.a[rc][ri] = *reinterpret_cast<const v2 *>(base + rdA + ri * 16 * BK + goff);
+              else
+                nxt.b[rc][ri - MA] = *reinterpret_cast<const v2 *>(base + rdB + (ri - MA) * 16 * BK + goff);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              ++issued;
+            }
+          }
+    static_assert(NR <= NC * 2 * MA * NA, "more fragment reads than MFMAs to hide them behind");
+  }
+  // slices 0 .. NS - 2 on their way
+  __device__ __forceinline__ void prologue(double *lds, int k_begin, int k_end) const {
+    const int nsl = (k_end - k_begin) / BK;
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+      if (p < nsl) issue(lds, p, k_begin + p * BK);
+  }
+  // fence: the slices from index `fence` on read memory that this workgroup has just stored; the
+  // whole vector-memory queue (those stores included) is drained once, ahead of the barrier that
+  // precedes the issue of slice `fence`.  Slices issued by prologue() are not covered:
+  // fence < NS - 1 needs a drain + barrier before prologue().
+  __device__ __forceinline__ void loop(double *lds, int k_begin, int k_end, mm_d4 (&acc)[MA][NA],
+                                       int fence = 1 << 30) const {
+    const int nsl = (k_end - k_begin) / BK;
+    if (nsl <= 0) return;
+    Frags f0, f1;
+    // slice 0 into the first register set
+    if (nsl >= NS - 1) mm_wait_vmcnt<(NS - 2) * LPW>(); else mm_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    fetch(lds, 0, f0);
+    int st1 = 1 % NS;            // stage of slice s + 1
+    int stn = NS - 1;            // stage the next issue goes to
+    // (the number of slices is even: callers give a depth that is a multiple of 2 BK)
+    for (int s = 0; s < nsl; s += 2) {
+      // ---- even half: multiply slice s from f0 while slice s + 1 is read into f1
+      if (s + NS - 1 < nsl && s + NS - 1 != fence) mm_wait_vmcnt<(NS - 3) * LPW>(); else mm_wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();   // slice s + 1 landed everywhere; slice s - 1's stage is free
+      if (s + NS - 1 < nsl) issue(lds, stn, k_begin + (s + NS - 1) * BK);
+      mul_fetch(f0, f1, lds, st1, acc);
+      st1 = st1 + 1 == NS ? 0 : st1 + 1;
+      stn = stn + 1 == NS ? 0 : stn + 1;
+      // ---- odd half: multiply slice s + 1 from f1 while slice s + 2 is read into f0
+      if (s + 2 < nsl) {
+        if (s + NS < nsl && s + NS != fence) mm_wait_vmcnt<(NS - 3) * LPW>(); else mm_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (s + NS < nsl) issue(lds, stn, k_begin + (s + NS) * BK);
+      }
+      mul_fetch(f1, f0, lds, st1, acc);   // (past the last slice the reads fetch stale bytes: unused)
+      st1 = st1 + 1 == NS ? 0 : st1 + 1;
+      stn = stn + 1 == NS ? 0 : stn + 1;
+    }
+    __builtin_amdgcn_s_barrier();
+  }
   __device__ __forceinline__ int acc_row(int m, int r) const {
     const int lane = threadIdx.x & 63;
     return (wave / WC) * (TM / WR) + 16 * m + (lane >> 4) + 4 * r;

@@ -72,12 +72,12 @@ def run(name, b, M, N, K, lower, alpha=-1.0, beta=1, same=False, reps=20, varian
 
 
 if __name__ == "__main__":
-    variants = [int(x) for x in sys.argv[1:]] or [0, 1, 2, 3, 5, 6, 7, 8]
+    variants = [int(x) for x in sys.argv[1:]] or [0, 6, 8, 9, 10, 11, 12]
     run("syrk n=512 k=512 lower", 64, 512, 512, 512, True, same=True, variants=variants)
     run("syrk n=768 k=256 lower", 64, 768, 768, 256, True, same=True, variants=variants)
     run("syrk n=256 k=256 lower", 64, 256, 256, 256, True, same=True, variants=variants)
     run("gemm 512x512 k=512", 64, 512, 512, 512, False, variants=variants)
-    run("blockcol 960x64 k=448", 64, 960, 64, 448, False, variants=[v for v in variants if v in (0, 1, 2, 6, 7)])
+    run("blockcol 960x64 k=448", 64, 960, 64, 448, False, variants=[v for v in variants if v in (0, 1, 2, 6, 7, 10, 11)])
     run("cond A Sigma (1024x256x256)", 16, 1024, 256, 256, False, alpha=1.0, beta=0, variants=variants)
     run("cond B A^T (1024x1024x256)", 16, 1024, 1024, 256, False, alpha=1.0, beta=0, variants=variants)
     run("alpha=0.5 beta=1 general", 8, 256, 256, 128, False, alpha=0.5, beta=1, variants=variants)
