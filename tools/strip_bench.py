@@ -39,10 +39,6 @@ n2 = (nb - bm) * 64
 us = timeit(6, 0)
 fl = S * n2 * (bm * 64.0) ** 2
 print("strip solve  %4d rows x %4d cols: %7.1f us  %5.1f TFLOP/s algorithmic (%.2f of 78.6)" % (n2, bm * 64, us, fl / us * 1e-6, fl / us * 1e-6 / 78.6))
-for f, what in ((2, "no block solve"), (4, "no product"), (8, "staggered start"), (16, "drain at every block boundary"), (24, "drain + stagger")):
-    check(e._L.sp_debug_set_mm_variant(100 + f))
-    print("   ablation %d (%s): %7.1f us" % (f, what, timeit(6, 0)))
-check(e._L.sp_debug_set_mm_variant(100))
 us = timeit(7, 0)
 fl = S * n2 * (n2 + 1.0) * bm * 64
 print("sym. update  n = %4d, k = %4d:   %7.1f us  %5.1f TFLOP/s algorithmic (%.2f of 78.6)" % (n2, bm * 64, us, fl / us * 1e-6, fl / us * 1e-6 / 78.6))
