@@ -40,14 +40,28 @@ sys.path.insert(0, ROOT)
 
 YDEG, UDEG, K, STARS_PER_GPU, COVPTS = 15, 2, 1000, 64, 300
 FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix = vector peak (AMD CDNA4 datasheet)
+HBM_PEAK_TBS = 8.0       # MI355X_MICROARCH.md (spec; 6.3 measured for a streaming copy)
 
 
-def cpu_baseline(nstars, timeout=240.0):
-    """The oracle (a NumPy/SciPy/C port of the reference's CPU path, LAPACK potrf and
-    trtrs exactly like reference math.py:75-100) timed on the host cores: the stars are
-    farmed out to single-threaded worker processes (oracle/cpu_worker.py, plain child
-    processes that never touch the GPU), the way an ensemble would run on a CPU node;
-    value = stars / slowest worker's compute time, cores = workers."""
+def step_work(S, Kc, M=1, N=0):
+    """Algorithmic work of one step of S stars: (flops, HBM bytes).
+    N > 0: conditional branch (adds the design-matrix products 2 K N^2 + 2 K^2 N)."""
+    flops = S * (Kc ** 3 / 3.0 + 2.0 * M * Kc ** 2 + 20.0 * Kc ** 2
+                 + (2.0 * Kc * N * N + 2.0 * Kc * Kc * N if N else 0.0))
+    return flops, S * 24.0 * Kc ** 2
+
+
+def cpu_baseline(nstars, timeout=240.0, engine="c"):
+    """The CPU restatement of the reference's path timed on the host cores: the stars are farmed
+    out to single-threaded worker processes (oracle/cpu_worker.py, plain child processes that
+    never touch the GPU), the way an ensemble would run on a CPU node; value = stars / slowest
+    worker's compute time, cores = workers.
+      engine "c":     oracle/cpu_pipeline.c -- the per-star pipeline (assembly, normalisation,
+                      LAPACK potrf / trtrs, reduction) in C, kernel table from the NumPy oracle
+                      (a process per core rather than OpenMP threads because the
+                      SciPy-bundled OpenBLAS serialises concurrent callers of one process);
+      engine "numpy": oracle.OracleProcess.log_likelihood, NumPy / SciPy exactly as the reference
+                      composes them (math.py:75-100)."""
     import subprocess
 
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -59,7 +73,7 @@ def cpu_baseline(nstars, timeout=240.0):
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     env.pop("LD_PRELOAD", None)   # (a profiler's preload has no business in the CPU workers)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_worker.py"), mom,
-                               str(a), str(b), str(K), str(YDEG), str(UDEG)],
+                               str(a), str(b), str(K), str(YDEG), str(UDEG), engine],
                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
              for a, b in spans]
     vals = np.full(nstars, np.nan)
@@ -76,10 +90,201 @@ def cpu_baseline(nstars, timeout=240.0):
             pr.kill()
     if done == 0:
         return None, vals
+    what = ("oracle/cpu_pipeline.c (assembly, normalisation, LAPACK potrf/trtrs, reduction in C; kernel table "
+            "from the NumPy oracle once per worker)") if engine == "c" else \
+        "oracle.OracleProcess.log_likelihood with SciPy/LAPACK potrf/trtrs"
     return dict(value=done / slowest, unit="evals/s", cores=len(spans), kind="port",
                 sample="%d stars (ydeg=15, K=1000, marginal, normalized) over %d single-threaded worker "
-                       "processes, oracle.OracleProcess.log_likelihood with SciPy/LAPACK potrf/trtrs"
-                       % (done, len(spans))), vals
+                       "processes, %s" % (done, len(spans), what)), vals
+
+
+# ---------------------------------------------------------------------------------------------
+# The timed loop, independent of what a step is: the GPU benchmark below and the CPU dry run of
+# the multi-rank control flow (tests/test_bench_dist_gloo.py: gloo backend, a stub evaluator)
+# both go through it.
+# ---------------------------------------------------------------------------------------------
+class Harness(object):
+    """What the loop needs from the platform.  `slots[i].run()` enqueues one whole step on slot
+    i (its own stream / handle / outputs); `sync()` waits for every slot; `barrier()` and
+    `max_over_ranks(x)` are the two inter-rank operations of the timing."""
+
+    def __init__(self, slots, sync, barrier=None, max_over_ranks=None):
+        self.slots = slots
+        self.sync = sync
+        self.barrier = barrier or (lambda: None)
+        self.max_over_ranks = max_over_ranks or (lambda x: x)
+
+
+def timed_steps(h, steps, warmup, prewarm_ms=0.0, before_timed=None):
+    """W untimed warm-up steps, the stated untimed pre-warm, then EXACTLY `steps` steps between
+    barrier + sync on both sides; returns (elapsed seconds: max over ranks, host enqueue seconds,
+    pre-warm steps)."""
+    F = len(h.slots)
+    nwarm = max(warmup, F if warmup else 0)
+    for i in range(nwarm):
+        h.slots[i % F].run()
+    # Stated, untimed pre-warm (VERDICT r01 item 1): a fresh process reaches the timed region
+    # 5 ms after its first launch otherwise, with the memory / fabric clocks still at their idle
+    # state, and the bandwidth-bound in-flight mode then reads like the latency-bound one.
+    # Whole steps of the same workload, every slot at least 3 times, at least prewarm_ms.
+    prewarm_steps = 0
+    if prewarm_ms > 0:
+        h.sync()
+        tw = time.perf_counter()
+        spent = 0.0
+        while prewarm_steps < 3 * F or spent < prewarm_ms:
+            for _ in range(F):
+                h.slots[(nwarm + prewarm_steps) % F].run()
+                prewarm_steps += 1
+            h.sync()
+            # (the same verdict on every rank: each step issues a collective, so the ranks must run
+            #  the same number of them -- a per-rank clock would deadlock the all-gathers)
+            spent = h.max_over_ranks(1e3 * (time.perf_counter() - tw))
+    if before_timed:
+        before_timed()
+    h.barrier()
+    h.sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        h.slots[i % F].run()
+    host_enqueue = time.perf_counter() - t0
+    h.sync()
+    h.barrier()
+    elapsed = h.max_over_ranks(time.perf_counter() - t0)
+    return elapsed, host_enqueue, prewarm_steps
+
+
+class Slot(object):
+    """One step in flight on the GPU: handle, stream, workspace, outputs (inputs shared)."""
+
+    def __init__(self, torch, engine, stream, S, Kc, world, use_dist, dist, covpts, conditional=False):
+        self.torch, self.e, self.stream, self.dist, self.use_dist = torch, engine, stream, dist, use_dist
+        self.ws = engine.workspace(S, Kc, 1)
+        self.out = engine.empty(S)
+        self.status = torch.zeros(S, dtype=torch.int32, device=engine.device)
+        self.gathered = engine.empty(world * S) if use_dist else None
+        self.covpts, self.conditional = covpts, conditional
+        self.inputs = None
+
+    def bind(self, **inputs):
+        self.inputs = inputs
+
+    def step(self):
+        a, e = self.inputs, self.e
+        e.set_moments_dev(a["mu_d"], a["Sig_d"])
+        tab = mv = None
+        if not self.conditional:
+            tab, mv = e.kernel_table(a["rta1_d"], self.covpts)
+        e.lnlike_ensemble(a["t_d"], a["f_d"], a["stars_d"], conditional=self.conditional, covpts=self.covpts,
+                          tab=tab, meanvar=mv, rta1=a["rta1_d"], temporal=a.get("temporal"), normalized=True,
+                          out=self.out, status=self.status, workspace=self.ws)
+        if self.use_dist:
+            # issued from this step's stream: torch orders the collectives of one communicator in
+            # program order (the same on every rank), and only this step waits for its own
+            self.dist.all_gather_into_tensor(self.gathered, self.out)
+
+    def run(self):
+        with self.torch.cuda.stream(self.stream):
+            self.step()
+
+
+def prof_summary(engines, kinds):
+    """Per kind: launches, summed ms, summed algorithmic flops over the given engines."""
+    out = {}
+    for k in kinds:
+        n = ms = fl = 0.0
+        for e in engines:
+            a, b, c = e.profile_kind(k)
+            n, ms, fl = n + a, ms + b, fl + c
+        out[k] = dict(launches=int(n), ms=ms, flops=fl)
+    return out
+
+
+KERNEL_OF_KIND = {
+    "panels": "gemm_nt_kernel<32,false,2,...> (one launch per panel: left-looking block-column product + "
+              "substitution solve + eager rank-64 diagonal updates + next diagonal block)",
+    "chain": "panel chain (diag_kernel, gemm_nt_kernel<32,false,1,...> block-column update + diagonal block, "
+             "trsm_quad_kernel)",
+    "syrk": "mm_nt_kernel<MM2<64,64,8,6,4>> / gemm_nt_kernel (symmetric trailing update, v_mfma_f64_16x16x4_f64)",
+    "strip": "strip_kernel (strip solve X = A21 L11^-T)",
+}
+
+
+def roofline_entry(kind, rec, extra=None):
+    ach = (rec["flops"] / (rec["ms"] * 1e-3)) / 1e12 if rec["ms"] > 0 else 0.0
+    d = {"kernel": KERNEL_OF_KIND[kind], "bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS,
+         "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "launches": rec["launches"],
+         "avg_launch_ms": rec["ms"] / max(rec["launches"], 1),
+         "algorithmic_flops_per_launch": rec["flops"] / max(rec["launches"], 1)}
+    if extra:
+        d.update(extra)
+    return d
+
+
+def bench_shape(torch, dist, ydeg, Kc, S, tspan, tau, u, conditional, F, steps, device):
+    """evals/s and whole-step roofline fraction of another BASELINE shape on this GPU (same
+    in-flight scheme, its own handles; 6 untimed steps first)."""
+    from starry_process_amd.engine import engine_slots, make_stars
+    from starry_process_amd.synthetic import synthetic_star
+
+    mom = np.load(os.path.join(ROOT, "tests", "golden", "moments_L%d.npz" % ydeg))
+    mu, Sig = mom["default_mean_ylm"], mom["default_cov_ylm"]
+    sts = [synthetic_star(s, Kc, tspan) for s in range(S)]
+    pairs = engine_slots(ydeg, UDEG, device, F)
+    e0 = pairs[0][0]
+    stars_h = make_stars(S, period=[s["p"] for s in sts], inc_deg=[s["i"] for s in sts], tau=tau or 0.0,
+                         data_var=1e-6)
+    inputs = dict(
+        t_d=e0.f64(np.array([s["t"] for s in sts])),
+        f_d=e0.f64(np.array([s["flux"] for s in sts])[:, None, :]),
+        stars_d=e0.stars_to_device(stars_h),
+        mu_d=e0.f64(mu), Sig_d=e0.f64(Sig), rta1_d=e0.f64(e0.rTA1L(list(u))),
+        temporal="matern32" if tau else None)
+    slots = []
+    for ek, stream in pairs:
+        ek.set_moments(mu, Sig)
+        sl = Slot(torch, ek, stream, S, Kc, 1, False, dist, COVPTS, conditional)
+        sl.bind(**inputs)
+        slots.append(sl)
+    h = Harness(slots, torch.cuda.synchronize)
+    elapsed, _, _ = timed_steps(h, steps, 6, 0.0, None)
+    ms = 1e3 * elapsed / steps
+    N = (ydeg + 1) ** 2 if conditional else 0
+    fl, by = step_work(S, Kc, 1, N)
+    res = {"ydeg": ydeg, "K": Kc, "stars": S, "conditional": bool(conditional),
+           "temporal": "matern32" if tau else None, "u": list(u), "steps": steps, "steps_in_flight": F,
+           "evals_per_s": S * steps / elapsed, "ms_per_step": ms,
+           "whole_step_TFLOPs": fl / (ms * 1e-3) / 1e12,
+           "whole_step_frac": fl / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+           "finite": bool(torch.isfinite(slots[0].out).all().item())}
+    if conditional:
+        # the a12-a13 products alone (A Sigma_y, then (A Sigma_y) A^T on the matrix cores,
+        # flux.py:337-343), one at a time, HIP events on the launch stream
+        e, st = slots[0].e, slots[0].stream
+        with torch.cuda.stream(st):
+            A = e.design_matrix(np.array([s["t"] for s in sts]), stars_h, inputs["rta1_d"])
+            B1 = e.empty(S, Kc, N)
+            raw = e.empty(S, Kc, Kc)
+            SigB = inputs["Sig_d"].unsqueeze(0).expand(S, N, N).contiguous()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+            def products():
+                e.gemm_nt_batched(A, SigB, B1)
+                e.gemm_nt_batched(B1, A, raw)
+
+            for _ in range(3):
+                products()
+            ev[0].record(st)
+            for _ in range(10):
+                products()
+            ev[1].record(st)
+        torch.cuda.synchronize()
+        gms = ev[0].elapsed_time(ev[1]) / 10
+        gfl = S * (2.0 * Kc * N * N + 2.0 * Kc * Kc * N)
+        res["design_products_ms"] = gms
+        res["design_products_TFLOPs"] = gfl / (gms * 1e-3) / 1e12
+        res["design_products_frac"] = res["design_products_TFLOPs"] / FP64_PEAK_TFLOPS
+    return res
 
 
 def main():
@@ -93,8 +298,10 @@ def main():
                     help="untimed pre-warm after the --warmup steps: whole steps keep running until this "
                          "much wall time has passed and every slot has run 3 times (clocks and fabric "
                          "at their loaded state); the timed region is exactly --steps steps either way")
-    ap.add_argument("--cpu-stars", type=int, default=128)
+    ap.add_argument("--cpu-stars", type=int, default=256)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the cfg5-shape and conditional-branch measurements (after the headline)")
     args = ap.parse_args()
 
     import torch
@@ -128,11 +335,12 @@ def main():
     S = STARS_PER_GPU
     first = rank * S
     sts = [synthetic_star(s, K) for s in range(first, first + S)]
-    t_d = e.f64(np.array([s["t"] for s in sts]))
-    f_d = e.f64(np.array([s["flux"] for s in sts])[:, None, :])
-    stars_d = e.stars_to_device(make_stars(S, period=[s["p"] for s in sts], data_var=1e-6))
-    mu_d, Sig_d = e.f64(mu), e.f64(Sig)
-    rta1_d = e.f64(e.rTA1L([0.0, 0.0]))          # one flux operator: u = [0, 0]
+    inputs = dict(
+        t_d=e.f64(np.array([s["t"] for s in sts])),
+        f_d=e.f64(np.array([s["flux"] for s in sts])[:, None, :]),
+        stars_d=e.stars_to_device(make_stars(S, period=[s["p"] for s in sts], data_var=1e-6)),
+        mu_d=e.f64(mu), Sig_d=e.f64(Sig),
+        rta1_d=e.f64(e.rTA1L([0.0, 0.0])))          # one flux operator: u = [0, 0]
 
     # one slot per step in flight: library handle, stream, workspace, outputs (the inputs
     # above are read-only and shared)
@@ -140,116 +348,84 @@ def main():
     slots = []
     for ek, stream in engine_slots(YDEG, UDEG, local_rank, F):
         ek.set_moments(mu, Sig)  # first call allocates / uploads the lag grid
-        slots.append(dict(e=ek, stream=stream, ws=ek.workspace(S, K, 1),
-                          out=ek.empty(S), status=torch.zeros(S, dtype=torch.int32, device=ek.device),
-                          gathered=ek.empty(world * S) if use_dist else None))
+        sl = Slot(torch, ek, stream, S, K, world, use_dist, dist, COVPTS)
+        sl.bind(**inputs)
+        slots.append(sl)
     torch.cuda.synchronize()
-
-    def run_step(c):
-        ek = c["e"]
-        ek.set_moments_dev(mu_d, Sig_d)
-        tab, mv = ek.kernel_table(rta1_d, COVPTS)
-        ek.lnlike_ensemble(t_d, f_d, stars_d, covpts=COVPTS, tab=tab, meanvar=mv,
-                           normalized=True, out=c["out"], status=c["status"], workspace=c["ws"])
-        if use_dist:
-            dist.all_gather_into_tensor(c["gathered"], c["out"])
-            return c["gathered"].sum()
-        return c["out"].sum()
-
-    def step(i=0):
-        c = slots[i % F]
-        with torch.cuda.stream(c["stream"]):
-            return run_step(c)
-
     if use_dist:
         # communicator set-up (lazy in RCCL) must not land in the timed region even with --warmup 0
-        dist.all_gather_into_tensor(slots[0]["gathered"], slots[0]["out"])
-    nwarm = max(args.warmup, F if args.warmup else 0)
-    for i in range(nwarm):
-        step(i)
-    # Stated, untimed pre-warm: a fresh process reaches the timed region
-    # 5 ms after its first launch otherwise, with the memory / fabric clocks still at their idle
-    # state, and the bandwidth-bound in-flight mode then reads like the latency-bound one.
-    # Whole steps of the same workload, every slot at least 3 times, at least --prewarm-ms.
-    prewarm_steps = 0
-    if args.prewarm_ms > 0:
-        torch.cuda.synchronize()
-        tw = time.perf_counter()
-        while prewarm_steps < 3 * F or 1e3 * (time.perf_counter() - tw) < args.prewarm_ms:
-            for _ in range(F):
-                step(nwarm + prewarm_steps)
-                prewarm_steps += 1
-            torch.cuda.synchronize()
-    nsyrk = (K + 63) // 64  # upper bound on timed launches per step
-    for c in slots:
-        c["e"].profile_begin((args.steps // F + 1) * nsyrk)
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        total = step(i)
-    host_enqueue = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    launches, kern_ms, kern_flops = 0, 0.0, 0.0
-    for c in slots:
-        a, b, f = c["e"].profile_end()
-        launches, kern_ms, kern_flops = launches + a, kern_ms + b, kern_flops + f
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=e.device)
+        dist.all_gather_into_tensor(slots[0].gathered, slots[0].out)
+
+    def max_over_ranks(x):
+        if not use_dist:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=e.device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        return float(tt.item())
 
-    out, status = slots[0]["out"], slots[0]["status"]
-    torch.cuda.synchronize()
-    lnl_timed = out.cpu().numpy().copy()
+    harness = Harness(slots, torch.cuda.synchronize, dist.barrier if use_dist else None, max_over_ranks)
+    # kinds bracketed with HIP events INSIDE the timed region (on the launch streams): the symmetric
+    # trailing updates (one pair each), the panel kernels of each super-panel (one pair per
+    # super-panel) and the strip solves; the per-launch breakdown of the chain is taken outside it
+    timed_kinds = ("syrk", "panels", "strip")
+    nev = (args.steps // F + 2) * 8
+
+    def arm():
+        for sl in slots:
+            sl.e.profile_begin(nev, timed_kinds)
+
+    elapsed, host_enqueue, prewarm_steps = timed_steps(harness, args.steps, args.warmup, args.prewarm_ms, arm)
+    timed_prof = prof_summary([sl.e for sl in slots], timed_kinds)
+    nran = min(F, args.steps + max(args.warmup, F if args.warmup else 0) + prewarm_steps)   # slots that ran
+    out, status = slots[0].out, slots[0].status
+    lnl = out.cpu().numpy().copy()
     status_timed = status.cpu().numpy().copy()
-    slots_agree = all(torch.equal(c["out"], out) for c in slots[1:min(F, args.steps + nwarm + prewarm_steps)])
-
-    # the same steps one at a time on one stream (not `value`): what a strictly sequential
-    # caller gets, and the trailing update's rate when it has the GPU to itself
-    one = None
-    if world == 1:
-        c0 = dict(slots[0])
-        if F > 1:   # one evaluation at a time: the shared engine, in its latency-oriented mode
-            c0["e"] = e
-            c0["ws"] = e.workspace(S, K, 1)
-            # (its own outputs: the two panel modes agree to rounding, not bit for bit, and the
-            #  slots of the timed region are compared bit for bit below)
-            c0["out"] = e.empty(S)
-            c0["status"] = torch.zeros(S, dtype=torch.int32, device=e.device)
-            e.set_moments(mu, Sig)
-        nrep = max(10, min(50, args.steps))
-        for _ in range(5):
-            run_step(c0)
-        c0["e"].profile_begin(nrep * nsyrk)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(nrep):
-            run_step(c0)
-        torch.cuda.synchronize()
-        dt1 = time.perf_counter() - t1
-        a, b, f = c0["e"].profile_end()
-        one = {"evals_per_s": S * nrep / dt1, "ms_per_step": 1e3 * dt1 / nrep,
-               "trailing_update_TFLOPs": (f / (b * 1e-3)) / 1e12 if b > 0 else 0.0}
-        one["trailing_update_frac"] = one["trailing_update_TFLOPs"] / FP64_PEAK_TFLOPS
-
-    nran = min(F, args.steps + nwarm + prewarm_steps)   # slots that ran
-    lnl = lnl_timed   # (the slots of the timed region: same inputs, same bits)
+    slots_agree = all(torch.equal(sl.out, out) for sl in slots[1:nran])   # same inputs, same bits
     ok = bool(np.all(np.isfinite(lnl))) and not bool(status_timed.any()) and slots_agree
     if not ok and rank == 0:
         print("parity check failed: finite %s, status bits set on %d stars, slots agree %s; stars that differ "
               "between slots: %s" % (bool(np.all(np.isfinite(lnl))), int(np.count_nonzero(status_timed)),
-                                     slots_agree, [int((c["out"] != out).sum().item()) for c in slots[1:nran]]),
+                                     slots_agree, [int((sl.out != out).sum().item()) for sl in slots[1:nran]]),
               file=sys.stderr)
+
+    # the same steps one at a time on one stream (not `value`): what a strictly sequential
+    # caller gets, with every launch of the factorisation bracketed (kernel-level breakdown)
+    one = None
+    one_prof = None
+    c0 = None
+    if world == 1:
+        c0 = Slot(torch, e, torch.cuda.current_stream(), S, K, world, False, dist, COVPTS)
+        c0.bind(**inputs)
+        e.set_moments(mu, Sig)
+        nrep = max(10, min(50, args.steps))
+        for _ in range(5):
+            c0.step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(nrep):
+            c0.step()
+        torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t1
+        one = {"evals_per_s": S * nrep / dt1, "ms_per_step": 1e3 * dt1 / nrep}
+        # (a separate short pass with every launch bracketed: the events cost ~10 % of a step)
+        kinds1 = ("syrk", "chain", "strip")
+        e.profile_begin(10 * 64, kinds1)
+        for _ in range(10):
+            c0.step()
+        torch.cuda.synchronize()
+        one_prof = prof_summary([e], kinds1)
+        fl1, _ = step_work(S, K)
+        one["whole_step_TFLOPs"] = fl1 / (one["ms_per_step"] * 1e-3) / 1e12
+        one["whole_step_frac"] = one["whole_step_TFLOPs"] / FP64_PEAK_TFLOPS
+        one["per_kind"] = {k: {"ms_per_step": v["ms"] / 10, "launches_per_step": v["launches"] / 10,
+                               "TFLOPs": (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0)}
+                           for k, v in one_prof.items()}
 
     # PCIe-inclusive rate (never `value`): the same step fed from pinned host buffers
     # (t, flux up, log-likelihoods down) -- what a caller without resident data would see
     pcie_rate = None
     if world == 1:
+        t_d, f_d = inputs["t_d"], inputs["f_d"]
         t_h, f_h = t_d.cpu().pin_memory(), f_d.cpu().pin_memory()
         out_h = torch.empty(S, dtype=torch.float64).pin_memory()
         nrep = max(3, min(20, args.steps))
@@ -257,8 +433,8 @@ def main():
         def fed_step():
             t_d.copy_(t_h, non_blocking=True)
             f_d.copy_(f_h, non_blocking=True)
-            run_step(c0)
-            out_h.copy_(c0["out"], non_blocking=True)
+            c0.step()
+            out_h.copy_(c0.out, non_blocking=True)
 
         for _ in range(2):          # first use of the pinned buffers maps them (tens of ms, once)
             fed_step()
@@ -268,6 +444,19 @@ def main():
             fed_step()
         torch.cuda.synchronize()
         pcie_rate = S * nrep / (time.perf_counter() - t1)
+
+    # the other shapes of BASELINE.json, after the headline and never in `value`
+    extras = None
+    if world == 1 and not args.no_extras:
+        extras = {}
+        try:
+            extras["cfg5_shape"] = bench_shape(torch, dist, ydeg=20, Kc=3000, S=32, tspan=30.0, tau=3.0,
+                                               u=(0.4, 0.2), conditional=False, F=F, steps=12, device=local_rank)
+            extras["cfg3_conditional"] = bench_shape(torch, dist, ydeg=15, Kc=1000, S=64, tspan=4.0, tau=None,
+                                                     u=(0.0, 0.0), conditional=True, F=F, steps=24,
+                                                     device=local_rank)
+        except Exception as exc:   # (never lose the headline over an extra)
+            extras["error"] = repr(exc)
 
     # the hyperparameter-level step (mu_y, Sigma_y from r, a, b, c, n) is outside the timed
     # region by definition of the metric; its cost is reported beside it
@@ -291,14 +480,42 @@ def main():
 
     if rank == 0:
         evals = world * S * args.steps
-        achieved = (kern_flops / (kern_ms * 1e-3)) / 1e12 if kern_ms > 0 else 0.0
+        ms_per_step = 1e3 * elapsed / args.steps
+        # the dominant kernel of the timed region: the bracketed kind with the largest summed duration
+        cand = {k: v for k, v in timed_prof.items() if v["launches"] > 0}
+        dom = max(cand, key=lambda k: cand[k]["ms"]) if cand else "syrk"
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "r02_step_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("gemm_nt_bytes_per_launch")
+                traffic = json.load(open(pmc)).get("dominant_kernel_bytes_per_launch")
             except Exception:
                 traffic = None
+        alone = None
+        if one_prof is not None:
+            key = "chain" if dom == "panels" else dom
+            if one_prof.get(key, {}).get("launches", 0) > 0:
+                alone = roofline_entry(key, one_prof[key])
+        fl, by = step_work(S, K)
+        whole = {"flops": fl, "bytes": by, "ms": ms_per_step,
+                 "achieved_TFLOPs": fl / (ms_per_step * 1e-3) / 1e12,
+                 "frac": fl / (ms_per_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                 "algorithmic_TBs": by / (ms_per_step * 1e-3) / 1e12,
+                 "hbm_frac": by / (ms_per_step * 1e-3) / 1e12 / HBM_PEAK_TBS,
+                 "note": "per GPU: S (K^3/3 + 2 M K^2 + 20 K^2) flop and 24 S K^2 bytes (SURVEY 8d) over "
+                         "the timed ms_per_step (steps_in_flight steps share the GPU)"}
+        roof = roofline_entry(dom, cand.get(dom, dict(launches=0, ms=0.0, flops=0.0)), {
+            "traffic": traffic,
+            # with F > 1 the launches of F steps share the GPU: a launch's duration then includes
+            # the time its workgroups wait for CUs held by the other steps' kernels, so `frac` is
+            # that launch's share of the machine; the same kernel with the GPU to itself
+            # (one step at a time, every launch bracketed, measured in this run) is `alone`
+            "steps_in_flight": F,
+            "event_ms_by_kind": {k: v["ms"] for k, v in timed_prof.items()},
+            "alone": alone,
+            "secondary": {k: roofline_entry(k, v) for k, v in cand.items() if k != dom},
+            "whole_step": whole,
+        })
         line = {
             "metric": "log_likelihood evals/sec (ydeg=15, K=1000)",
             "value": evals / elapsed,
@@ -306,7 +523,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -325,29 +542,15 @@ def main():
             "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
             "pcie_inclusive_evals_per_s": pcie_rate,
             "upstream_ms_per_sample": upstream_ms,
-            "roofline": {
-                "kernel": "gemm_nt_kernel (Cholesky trailing update, v_mfma_f64_16x16x4_f64)",
-                "bound": "mfma",
-                "achieved": achieved,
-                "peak": FP64_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / FP64_PEAK_TFLOPS,
-                "traffic": traffic,
-                "launches": launches,
-                "avg_launch_ms": kern_ms / max(launches, 1),
-                "algorithmic_flops_per_launch": kern_flops / max(launches, 1),
-                # with F > 1 the launches of F steps share the GPU: a launch's duration then
-                # includes the time its workgroups wait for CUs held by the other steps' kernels,
-                # and `frac` is that launch's share of the machine, not the kernel's efficiency;
-                # the same kernel with the GPU to itself (one step at a time, measured in this run):
-                "steps_in_flight": F,
-                "frac_alone": one["trailing_update_frac"] if one else None,
-                "achieved_alone": one["trailing_update_TFLOPs"] if one else None,
-            },
+            "other_shapes": extras,
+            "roofline": roof,
         }
         if not args.no_cpu and world == 1:   # reported at N = 1 only (rank 0 would hold the others up)
-            base, ref_vals = cpu_baseline(args.cpu_stars)
+            base, ref_vals = cpu_baseline(args.cpu_stars, engine="c")
             line["cpu_baseline"] = base
+            base2, _ = cpu_baseline(min(args.cpu_stars, 64), engine="numpy")
+            if base2:
+                line["cpu_baseline_numpy_scipy"] = base2
             n = min(len(ref_vals), S)
             ok_ref = np.isfinite(ref_vals[:n])
             if ok_ref.any():

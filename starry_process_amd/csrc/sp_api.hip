@@ -611,6 +611,7 @@ int sp_profile_begin_kinds(sp_handle *h, int max_launches, unsigned kind_mask) {
   }
   h->prof_kind.assign(h->prof_ev.size() / 2, 0);
   h->prof_fl.assign(h->prof_ev.size() / 2, 0.0);
+  h->prof_n.assign(h->prof_ev.size() / 2, 0);
   h->prof_used = 0;
   h->prof_on = true;
   return SP_OK;
@@ -629,7 +630,7 @@ int sp_profile_kind(sp_handle *h, int kind, long *launches, double *total_ms, do
     SP_HIP(hipEventElapsedTime(&dt, h->prof_ev[i], h->prof_ev[i + 1]));
     ms += dt;
     fl += h->prof_fl[i / 2];
-    n += 1;
+    n += h->prof_n[i / 2];
   }
   if (launches) *launches = n;
   if (total_ms) *total_ms = ms;

@@ -644,6 +644,10 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
     }
     for (int s0 = 0; s0 < nsteps; s0 += w) {
       const int cS = s0 * SP_NB;
+      // one group (the usual case): the panel launches of the super-panel follow one another on
+      // the stream and can share ONE pair of profiling events (kind SP_PROF_PANELS)
+      {
+      SpProfScope sp_scope(ngroups == 1 ? h : nullptr, grp[0].st, SP_PROF_PANELS, 0.0, 0);
       for (int q = 0; q < w && s0 + q < nsteps; ++q) {
         const int j = s0 + q, c0 = j * SP_NB;
         const int nact = K - c0 < SP_NB ? K - c0 : SP_NB;
@@ -658,9 +662,11 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
           const double *lt_in = G.invL + (size_t)(j & 1) * SP_LT_IMG;
           double *lt_out = G.invL + (size_t)((j + 1) & 1) * SP_LT_IMG;
           const double rows = Kp - r1;
-          SpProfScope prof(h, G.st, SP_PROF_CHAIN,
-                           (double)G.S * (2.0 * rows * 64 * (q * 64.0) + rows * 64 * 64 +
-                                          neager * 64.0 * 64 * 64 + 64.0 * 64 * 64 / 3));
+          // left-looking product + substitution + eager rank-64 updates + the next diagonal block
+          const double fl = (double)G.S * (2.0 * rows * 64 * (q * 64.0) + rows * 64 * 64 +
+                                           neager * 64.0 * 64 * 64 + 64.0 * 64 * 64 / 3);
+          SpProfScope prof(h, G.st, SP_PROF_CHAIN, fl);
+          sp_scope.add(fl, nact < SP_NB ? 2 : 1);
           int rc;
           if (nact < SP_NB) {
             // partial last block: the rows of its own diagonal tile below the active ones
@@ -681,6 +687,7 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
           if (rc != SP_OK) return rc;
         }
       }
+      }   // (sp_scope ends here: the trailing update has its own pair)
       const int cE = (s0 + w) * SP_NB;
       if (cE < K) {
         for (int g = 0; g < ngroups; ++g) {

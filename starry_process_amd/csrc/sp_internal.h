@@ -73,23 +73,37 @@ struct sp_handle {
   std::vector<hipEvent_t> prof_ev;   // pairs (start, stop)
   std::vector<int> prof_kind;        // kind of pair i
   std::vector<double> prof_fl;       // algorithmic flops of pair i
+  std::vector<int> prof_n;           // launches bracketed by pair i
   size_t prof_used;                  // events handed out so far
 };
 
 // kinds of timed launches (sp_profile_kind)
-enum { SP_PROF_SYRK = 0, SP_PROF_STRIP = 1, SP_PROF_CHAIN = 2, SP_PROF_ASSEMBLE = 3, SP_PROF_NKINDS = 4 };
+// SP_PROF_PANELS: the one-launch-per-panel kernels of a whole super-panel under ONE pair of events
+// (cheap enough for a timed region: 2 pairs per K = 1000 factorisation)
+enum {
+  SP_PROF_SYRK = 0, SP_PROF_STRIP = 1, SP_PROF_CHAIN = 2, SP_PROF_ASSEMBLE = 3, SP_PROF_PANELS = 4,
+  SP_PROF_NKINDS = 5
+};
 
 // brackets the launches issued during its lifetime with a pair of events on `st`
 struct SpProfScope {
   sp_handle *h;
   hipStream_t st;
   bool on;
-  SpProfScope(sp_handle *h_, hipStream_t st_, int kind, double flops) : h(h_), st(st_), on(false) {
+  SpProfScope(sp_handle *h_, hipStream_t st_, int kind, double flops, int launches = 1)
+      : h(h_), st(st_), on(false) {
     if (!h || !h->prof_on || !((h->prof_mask >> kind) & 1u) || h->prof_used + 2 > h->prof_ev.size()) return;
     if (hipEventRecord(h->prof_ev[h->prof_used], st) != hipSuccess) return;
     h->prof_kind[h->prof_used / 2] = kind;
     h->prof_fl[h->prof_used / 2] = flops;
+    h->prof_n[h->prof_used / 2] = launches;
     on = true;
+  }
+  // (a scope around several launches: add each one's algorithmic flops as it is issued)
+  void add(double flops, int launches = 1) {
+    if (!on) return;
+    h->prof_fl[h->prof_used / 2] += flops;
+    h->prof_n[h->prof_used / 2] += launches;
   }
   ~SpProfScope() {
     if (!on) return;

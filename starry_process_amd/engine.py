@@ -216,8 +216,25 @@ class Engine(object):
         self._moments_owner = None
         check(self._L.sp_set_ylm_moments_dev(self._h, self._p(mean_ylm), self._p(cov_ylm), self._stream()))
 
-    def profile_begin(self, max_launches):
-        check(self._L.sp_profile_begin(self._h, int(max_launches)))
+    PROF_KINDS = {"syrk": 0, "strip": 1, "chain": 2, "assemble": 3, "panels": 4}
+
+    def profile_begin(self, max_launches, kinds=("syrk",)):
+        """Bracket the factorisation's launches of the given kinds with HIP events on their stream
+        ("syrk" trailing updates, "strip" strip solves, "chain" every launch of the panel chain,
+        "panels" the one-launch-per-panel kernels of a super-panel under ONE pair of events)."""
+        mask = 0
+        for k in kinds:
+            mask |= 1 << self.PROF_KINDS[k]
+        check(self._L.sp_profile_begin_kinds(self._h, int(max_launches), mask))
+
+    def profile_kind(self, kind):
+        """(launches, summed milliseconds, summed algorithmic flops) of one kind; ends the profile."""
+        n = ctypes.c_long()
+        ms = ctypes.c_double()
+        fl = ctypes.c_double()
+        check(self._L.sp_profile_kind(self._h, self.PROF_KINDS[kind], ctypes.byref(n), ctypes.byref(ms),
+                                      ctypes.byref(fl)))
+        return n.value, ms.value, fl.value
 
     def profile_end(self):
         n = ctypes.c_long()
@@ -307,6 +324,10 @@ class Engine(object):
         check(self._L.sp_cho_solve(self._h, self._p(Lb), K, K, K * K, self._p(bb), nrhs, B, self._stream()))
         return bb.reshape(shape)
 
+    def set_chol_mode(self, mode):
+        """0: super-panel driver (default), 2: recursive driver with strip solves."""
+        check(self._L.sp_set_chol_mode(self._h, int(mode)))
+
     def set_panel_mode(self, one_launch):
         """False: two launches per panel (shortest critical path, one evaluation at a time);
         True: one launch per panel (least HBM traffic, several evaluations in flight)."""
@@ -362,6 +383,17 @@ class Engine(object):
         check(self._L.sp_gemm_nt(self._h, self._p(A), K, 0, self._p(B), K, 0, self._p(out), N, 0, M, N,
                                  K, float(alpha), beta, int(bool(lower_only)), 1, self._stream()))
         return out
+
+    def gemm_nt_batched(self, A, B, C, alpha=1.0, beta=0, lower_only=False):
+        """C[b] = beta C[b] + alpha A[b] B[b]^T for contiguous device tensors A [b, M, K], B [b, N, K],
+        C [b, M, N] (in place)."""
+        b, M, K = A.shape
+        N = B.shape[1]
+        assert B.shape == (b, N, K) and C.shape == (b, M, N)
+        assert A.is_contiguous() and B.is_contiguous() and C.is_contiguous()
+        check(self._L.sp_gemm_nt(self._h, self._p(A), K, M * K, self._p(B), K, N * K, self._p(C), N, M * N,
+                                 M, N, K, float(alpha), int(beta), int(bool(lower_only)), b, self._stream()))
+        return C
 
     def gp_condition(self, Ktt, Kst, Kss, r):
         """mu = K_st K_tt^-1 r and the posterior covariance K_ss - K_st K_tt^-1 K_st^T

@@ -77,6 +77,11 @@ def sharded_log_likelihood(sp, t, flux, data_cov, p=None, i=None, u=None,
         x = np.asarray(x)
         return x[lo:hi] if x.ndim >= 1 and x.shape[0] == S else x
 
+    if hi == lo:
+        # more ranks than stars (or an uneven split that leaves this rank empty): nothing to
+        # evaluate, but the collective below is entered by every rank
+        local_t = torch.empty(0, dtype=torch.float64, device=sp._engine.device)
+        return all_gather_values(local_t, S, group).cpu().numpy()
     if ragged:
         tl = cut(t)
     else:

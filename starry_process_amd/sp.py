@@ -388,6 +388,8 @@ class StarryProcess(object):
         e = self._engine
         f = self._flux
         nobs = 0
+        if isinstance(flux, (list, tuple)) and len(flux) == 0:
+            return Eager(np.empty(0))
         if isinstance(flux, (list, tuple)):
             S = len(flux)
             lens = np.array([np.size(x) for x in flux], dtype=np.int32)

@@ -1,0 +1,191 @@
+"""
+GPU parity of the fused log-likelihood path under EVERY factorisation driver and panel mode, at
+the BASELINE sizes ("close the pytest holes"):
+
+  * super-panel driver in its two-launch and one-launch-per-panel forms (sp_set_panel_mode) at
+    K = 1000 with the full 64-star batch of cfg3 and at K = 3000 (cfg5), against the golden
+    values of the executed reference (tests/golden/lnlike.npz) and against each other;
+  * the recursive driver with its strip-solve kernel (sp_set_chol_mode 2) on the same, plus a
+    sweep of awkward sizes (partial last block, residual rows spilling into blocks of their own,
+    fewer panels than a base block) against the super-panel driver;
+  * the cfg5 share of one GPU (32 stars, ydeg 20, K 3000, Matern-3/2, u = [0.4, 0.2]);
+  * three K = 1000, 64-star steps in flight on three (handle, stream) pairs.
+
+North-star bar: fp64 log_likelihood within 1e-8 relative of the reference; drivers among
+themselves: 1e-11 (they differ in summation order only).
+"""
+import numpy as np
+import pytest
+
+from conftest import golden
+from starry_process_amd.synthetic import synthetic_star
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-8
+TOL_DRIVERS = 1e-11
+
+
+def make_engine(L, chol=0, panel=0):
+    from starry_process_amd._lib import check
+    from starry_process_amd.engine import Engine
+
+    e = Engine(L, 2, 0)
+    mom = golden("moments_L%d" % L)
+    e.set_moments(mom["default_mean_ylm"], mom["default_cov_ylm"])
+    check(e._L.sp_set_chol_mode(e._h, chol))
+    e.set_panel_mode(bool(panel))
+    return e
+
+
+@pytest.fixture(scope="module")
+def engines():
+    cache = {}
+
+    def get(L, chol, panel):
+        key = (L, chol, panel)
+        if key not in cache:
+            cache[key] = make_engine(L, chol, panel)
+        return cache[key]
+
+    return get
+
+
+MODES = [(0, 0), (0, 1), (2, 0)]   # (chol_mode, panel_mode)
+
+
+def lnl(e, K, idx, tspan=4.0, u=(0.0, 0.0), tau=None, M=1, data_var=None):
+    from starry_process_amd.engine import make_stars
+
+    sts = [synthetic_star(int(s), K, tspan) for s in idx]
+    S = len(sts)
+    t = np.array([st["t"] for st in sts])
+    if M == 1:
+        flux = np.array([st["flux"] for st in sts])[:, None, :]
+    else:   # M light curves sharing the star's covariance: the star's own curve plus shifted copies
+        flux = np.array([[np.roll(st["flux"], 7 * m) * (1.0 + 0.01 * m) for m in range(M)] for st in sts])
+    stars = make_stars(S, period=[st["p"] for st in sts], tau=tau or 0.0,
+                       data_var=data_var if data_var is not None else 1e-6)
+    rta1 = e.f64(e.rTA1L(u))
+    tab, mv = e.kernel_table(rta1, 300)
+    out, status = e.lnlike_ensemble(e.f64(t), e.f64(flux), e.stars_to_device(stars), covpts=300, tab=tab,
+                                    meanvar=mv, temporal="matern32" if tau else None, normalized=True)
+    return out.cpu().numpy(), status.cpu().numpy()
+
+
+def test_cfg3_full_batch_every_driver(engines):
+    """64 stars, ydeg 15, K 1000: golden stars within 1e-8 of the reference, a star's value
+    independent of the batch (bit for bit), drivers within 1e-11 of one another."""
+    g = golden("lnlike")
+    gs = [int(s) for s in g["cfg2_L15_K1000_stars"]]
+    res = {}
+    for chol, panel in MODES:
+        e = engines(15, chol, panel)
+        v, st = lnl(e, 1000, range(64))
+        assert not st.any() and np.all(np.isfinite(v))
+        assert np.max(np.abs(v[gs] / g["cfg2_L15_K1000"] - 1)) < TOL, (chol, panel)
+        # SURVEY Appendix B anchor (star 0's period, RandomState(0) noise) is a different light curve;
+        # the batch-independence property: the same stars alone / in a smaller batch
+        v8, _ = lnl(e, 1000, range(8))
+        assert np.array_equal(v8, v[:8]), (chol, panel)
+        v1, _ = lnl(e, 1000, [63])
+        assert v1[0] == v[63], (chol, panel)
+        res[(chol, panel)] = v
+    ref = res[MODES[0]]
+    for k, v in res.items():
+        assert np.max(np.abs(v / ref - 1)) < TOL_DRIVERS, k
+
+
+def test_cfg5_share_every_driver(engines):
+    """cfg5's share of one GPU: 32 stars, ydeg 20, K 3000, Matern-3/2 (tau 3), u = [0.4, 0.2]."""
+    g = golden("lnlike")
+    gs = [int(s) for s in g["cfg5_L20_K3000_stars"]]
+    res = {}
+    for chol, panel in MODES:
+        e = engines(20, chol, panel)
+        v, st = lnl(e, 3000, range(32), tspan=30.0, u=(0.4, 0.2), tau=3.0)
+        assert not st.any() and np.all(np.isfinite(v))
+        assert np.max(np.abs(v[gs] / g["cfg5_L20_K3000"] - 1)) < TOL, (chol, panel)
+        v3, _ = lnl(e, 3000, range(3), tspan=30.0, u=(0.4, 0.2), tau=3.0)
+        assert np.array_equal(v3, v[:3]), (chol, panel)
+        res[(chol, panel)] = v
+    ref = res[MODES[0]]
+    for k, v in res.items():
+        assert np.max(np.abs(v / ref - 1)) < TOL_DRIVERS, k
+
+
+@pytest.mark.parametrize("K,M", [(40, 1), (63, 1), (64, 1), (65, 1), (200, 1), (257, 3), (448, 1), (511, 2),
+                                 (513, 1), (960, 70), (1000, 1), (1023, 1), (1024, 1), (1100, 5), (1345, 1)])
+def test_awkward_sizes_recursive_vs_superpanel(engines, K, M):
+    """Partial last blocks, residual rows in the last pivot block's rows or in blocks of their own
+    (K + M beyond the last pivot block), fewer panels than a base block, uneven recursion."""
+    S = 5 if K > 600 else 9
+    ref, st0 = lnl(engines(15, 0, 0), K, range(3, 3 + S), M=M)
+    one, st1 = lnl(engines(15, 0, 1), K, range(3, 3 + S), M=M)
+    rec, st2 = lnl(engines(15, 2, 0), K, range(3, 3 + S), M=M)
+    assert not st0.any() and not st1.any() and not st2.any()
+    assert np.all(np.isfinite(ref))
+    assert np.max(np.abs(one / ref - 1)) < TOL_DRIVERS
+    assert np.max(np.abs(rec / ref - 1)) < TOL_DRIVERS
+
+
+def test_failure_semantics_every_driver(engines):
+    """A covariance that is not positive definite gives -inf and the NOT_PD bit for THAT star only
+    (math.py:82-91, sp.py:1186-1188), whichever driver factors it."""
+    for chol, panel in MODES:
+        e = engines(15, chol, panel)
+        dv = np.full(6, 1e-6)
+        dv[2] = -1.0
+        v, st = lnl(e, 700, range(6), data_var=dv)
+        assert v[2] == -np.inf and (st[2] & 1), (chol, panel)
+        ok = np.arange(6) != 2
+        assert np.all(np.isfinite(v[ok])) and not st[ok].any(), (chol, panel)
+        good, _ = lnl(e, 700, [0, 1, 3, 4, 5])
+        assert np.array_equal(good, v[ok]), (chol, panel)
+
+
+def test_three_steps_in_flight_K1000():
+    """bench.py's default configuration: three independent 64-star, K = 1000 steps on three
+    (handle, stream) pairs, enqueued before anything is synchronised, repeated; every step gives
+    exactly the bits of the same step run alone on its handle."""
+    import torch
+    from starry_process_amd.engine import engine_slots, make_stars
+
+    S, K = 64, 1000
+    mom = golden("moments_L15")
+    slots = engine_slots(15, 2, None, 3)
+    e0 = slots[0][0]
+    sts = [synthetic_star(s, K) for s in range(S)]
+    t_d = e0.f64(np.array([s["t"] for s in sts]))
+    f_d = e0.f64(np.array([s["flux"] for s in sts])[:, None, :])
+    stars = e0.stars_to_device(make_stars(S, period=[s["p"] for s in sts], data_var=1e-6))
+    rta1 = e0.f64(e0.rTA1L([0.0, 0.0]))
+    names = ["default", "hilat", "spread"]
+    wss = [e.workspace(S, K, 1) for e, _ in slots]
+
+    def evaluate(e, name, out, ws):
+        e.set_moments_dev(e.f64(mom[name + "_mean_ylm"]), e.f64(mom[name + "_cov_ylm"]))
+        tab, mv = e.kernel_table(rta1, 300)
+        e.lnlike_ensemble(t_d, f_d, stars, covpts=300, tab=tab, meanvar=mv, normalized=True, out=out,
+                          workspace=ws)
+
+    for e, _ in slots:
+        e.set_moments(mom["default_mean_ylm"], mom["default_cov_ylm"])   # (lag grid, first-use set-up)
+        e.kernel_table(rta1, 300)
+    torch.cuda.synchronize()
+    alone = []
+    for (e, stream), name, ws in zip(slots, names, wss):
+        out = e.empty(S)
+        with torch.cuda.stream(stream):
+            evaluate(e, name, out, ws)
+        torch.cuda.synchronize()
+        alone.append(out.clone())
+    outs = [e.empty(S) for e, _ in slots]
+    for rep in range(4):
+        for (e, stream), name, out, ws in zip(slots, names, outs, wss):
+            with torch.cuda.stream(stream):
+                evaluate(e, name, out, ws)
+    torch.cuda.synchronize()
+    for a, b in zip(alone, outs):
+        assert torch.equal(a, b)
+        assert bool(torch.isfinite(a).all())
+    assert len({float(a[0]) for a in alone}) == 3
