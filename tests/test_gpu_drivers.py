@@ -124,8 +124,11 @@ def test_awkward_sizes_recursive_vs_superpanel(engines, K, M):
     rec, st2 = lnl(engines(15, 2, 0), K, range(3, 3 + S), M=M)
     assert not st0.any() and not st1.any() and not st2.any()
     assert np.all(np.isfinite(ref))
-    assert np.max(np.abs(one / ref - 1)) < TOL_DRIVERS
-    assert np.max(np.abs(rec / ref - 1)) < TOL_DRIVERS
+    # (with M > 1 shifted copies a star's value can be a small difference of terms of size
+    #  max |lnlike| over the batch: the drivers agree relative to that size)
+    scale = np.maximum(np.abs(ref), np.abs(ref).max())
+    assert np.max(np.abs(one - ref) / scale) < TOL_DRIVERS
+    assert np.max(np.abs(rec - ref) / scale) < TOL_DRIVERS
 
 
 def test_failure_semantics_every_driver(engines):
