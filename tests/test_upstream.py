@@ -116,3 +116,36 @@ def test_moments_are_expectations_of_rotations():
         assert np.abs(mu - mr).max() < tol_mu * np.abs(mr).max()
         assert np.abs(S - Sr)[:25].max() < tol_lo * scale
         assert np.abs(S - Sr).max() < tol_all * scale
+
+
+@pytest.mark.parametrize("name", ["default", "hilat", "spread"])
+def test_extended_precision_arbiter(name):
+    """tests/golden/upstream_extended.npz (tools/upstream_extended.py: the defining expectations in
+    80-bit arithmetic with 50-digit Gauss-Jacobi nodes; refining the rule changes it by < 1e-16):
+      * the double-precision quadrature of rotations (the oracle's CPU counterpart of
+        upstream_device.py) agrees with it to 5e-14 max|Sigma_y| in EVERY degree;
+      * the reference's algorithm (fixture from the executed reference) is off by an amount that
+        grows with the degree, up to 1e-3 - 1e-2 max|Sigma_y| at l = 15 for the first two
+        hyperparameter sets: its eigen-square-root / polynomial-Wigner route is ill conditioned,
+        the integrals themselves are not."""
+    from oracle import sp_oracle as orc
+    from starry_process_amd import upstream
+
+    g = golden("moments_L15")
+    x = golden("upstream_extended")
+    r, dr, a, b, c, n = g[name + "_hyper"]
+    dr = None if np.isnan(dr) else dr
+    s1, eigS = upstream.size_moments(r, dr, 15)
+    cols = eigS.T[np.abs(eigS).sum(axis=0) > 0.0] if dr is not None else s1[None, :]
+    alpha, beta = upstream.ab_to_alphabeta(a, b)
+    mu_q, S_q = orc.ylm_moments_quadrature(s1, cols, alpha, beta, c, n, 15)
+    me, Se, Sr = x[name + "_mean_ylm"], x[name + "_cov_ylm"], g[name + "_cov_ylm"]
+    assert float(x[name + "_rule_convergence"]) < 1e-15
+    assert np.abs(mu_q - me).max() < 1e-13 * np.abs(me).max()
+    scale = np.abs(Se).max()
+    dq = np.array([np.abs(S_q[l * l:(l + 1) ** 2] - Se[l * l:(l + 1) ** 2]).max() / scale for l in range(16)])
+    dref = np.array([np.abs(Sr[l * l:(l + 1) ** 2] - Se[l * l:(l + 1) ** 2]).max() / scale for l in range(16)])
+    assert dq.max() < 5e-14
+    assert np.all(dq <= dref + 1e-15)
+    if name != "spread":
+        assert dref[15] > 1e-4 and dref[12] > 1e-6      # the reference's noise, as recorded in DESIGN.md 8
