@@ -403,6 +403,7 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
   h->prof_mask = 1u;
   h->prof_used = 0;
   h->chol_mode = 0;
+  h->rec_base = SP_REC_BASE_DEFAULT;
   const int N = h->N;
   h->l_of.resize(N);
   h->m_of.resize(N);
@@ -447,6 +448,9 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
     h->onelaunch = e7 ? atoi(e7) : 0;
     const char *e3 = getenv("SP_GROUPS");
     h->groups = e3 ? atoi(e3) : 1;
+    const char *e9 = getenv("SP_REC_BASE");
+    h->rec_base = e9 ? atoi(e9) : SP_REC_BASE_DEFAULT;
+    if (h->rec_base < 1) h->rec_base = 1;
     const char *e8 = getenv("SP_CHOL");
     h->chol_mode = e8 ? atoi(e8) : 0;
     const char *e2 = getenv("SP_SUPER");

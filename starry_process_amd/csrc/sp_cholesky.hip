@@ -584,9 +584,9 @@ int rec_factor(const RecCtx &c, int b0, int b1) {
   const sp_chol_group &G = *c.G;
   const int nb = b1 - b0;
   if (nb <= 0) return SP_OK;
-  if (nb <= SP_REC_BASE) return rec_base(c, b0, b1);
+  if (nb <= c.h->rec_base) return rec_base(c, b0, b1);
   // split on a multiple of the base size where possible (equal halves at K = 1000)
-  int bm = b0 + ((nb / 2 + SP_REC_BASE - 1) / SP_REC_BASE) * SP_REC_BASE;
+  int bm = b0 + ((nb / 2 + c.h->rec_base - 1) / c.h->rec_base) * c.h->rec_base;
   if (bm >= b1) bm = b0 + nb / 2;
   int rc = rec_factor(c, b0, bm);
   if (rc != SP_OK) return rc;
@@ -811,11 +811,11 @@ int sp_debug_phase(sp_handle *h, double *sys, int S, int K, int Kp, int32_t *inf
     // 6 the top-level strip solve, 7 the top-level symmetric update, 8 base block j (4 panels)
     sp_chol_group G{sys, info, invL, S, st};
     RecCtx c{h, &G, K, Kp, (K + SP_NB - 1) / SP_NB, ld, stride, lts};
-    const int nb = c.nsteps, bm = ((nb / 2 + SP_REC_BASE - 1) / SP_REC_BASE) * SP_REC_BASE;
+    const int nb = c.nsteps, bm = ((nb / 2 + c.h->rec_base - 1) / c.h->rec_base) * c.h->rec_base;
     if (phase == 6) return rec_trsm(c, bm * SP_NB, nb * SP_NB, 0, bm);
     if (phase == 7)
       return bulk_update(h, sys, ld, stride, S, 0, bm * SP_NB, nb * SP_NB, bm * SP_NB, st, lts);
-    const int b0 = j * SP_REC_BASE, b1 = b0 + SP_REC_BASE < nb ? b0 + SP_REC_BASE : nb;
+    const int b0 = j * c.h->rec_base, b1 = b0 + c.h->rec_base < nb ? b0 + c.h->rec_base : nb;
     return b0 < nb ? rec_base(c, b0, b1) : SP_ERR_INVALID;
   }
   if (phase == 4)  // the rank-256 trailing update of the first super-panel, not fused

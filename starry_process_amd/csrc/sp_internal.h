@@ -67,6 +67,7 @@ struct sp_handle {
   std::vector<hipEvent_t> gdone;
   hipEvent_t gfork;
   int chol_mode;                // 2: recursive driver (strip solves), 0: super-panel driver (SP_CHOL)
+  int rec_base;                 // recursive driver: panels per base block
   // optional per-launch timing of the factorisation's launches by kind (bench roofline)
   bool prof_on;
   unsigned prof_mask;                // kinds that are bracketed (bit k = kind k)
@@ -114,8 +115,8 @@ struct SpProfScope {
 
 // strip solve: at most this many 64-column blocks per launch (wider triangles are split)
 #define SP_STRIP_MAXB 8
-// diagonal blocks of at most this many panels are factored panel by panel
-#define SP_REC_BASE 4
+// diagonal blocks of at most this many panels are factored panel by panel (h->rec_base; SP_REC_BASE)
+#define SP_REC_BASE_DEFAULT 8
 // inv_first: L_d^-T of the first column block (those of the following blocks 8192 doubles apart)
 int sp_launch_strip(double *sys, long ld, long stride, int batch, int r0, int nrt, int c0, int nb,
                     const double *inv_first, long lts, hipStream_t st);
