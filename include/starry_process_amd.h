@@ -369,6 +369,19 @@ int sp_profile_begin_kinds(sp_handle *h, int max_launches, unsigned kind_mask);
  * Results agree to rounding (different summation order).  Environment: SP_CHOL.             */
 int sp_set_chol_mode(sp_handle *h, int mode);
 
+/* Normalised likelihoods (sp.py:705-727: C = c1 Sigma + z ((alpha + beta) p p^T - alpha q q^T),
+ * q = row sums / (K m)), per handle:
+ *   1 (default): deferred -- the assembly writes the raw covariance ONCE and takes its row sums in
+ *                the same pass; the factorisation is that of Sigma + N / c1 and the rank-2 (and
+ *                baseline) part is applied to the result by the matrix-determinant / Sherman-
+ *                Morrison identities from three extra rows of the system (p, q, 1).  A workspace
+ *                sized for this mode also serves the other one.
+ *   0: the separate row-sum pass, then the normalised matrix assembled and factored as such.
+ * The two agree to rounding (1e-12 relative on the BASELINE configurations); -inf for a matrix
+ * that is not positive definite or z > zmax either way.  Set before sizing the workspace
+ * (sp_lnlike_workspace_bytes).  Environment: SP_DEFER_NORM.                                 */
+int sp_set_defer_norm(sp_handle *h, int on);
+
 /* ---- multi-GPU ------------------------------------------------------
  * The only exchange of the path: every rank contributes the log-likelihoods of
  * its `count` stars and receives all `count * nranks` of them, in rank order

@@ -33,7 +33,11 @@ int sp_launch_assemble(int S, int K, int M, int Kp, int system,
                        const double *xp, int temporal, const double *raw,
                        int normalized, const double *qv, const void *coef,
                        const double *diag, int add_noise, const double *flux,
-                       double *out, long ldo, long strideo, hipStream_t st);
+                       double *out, long ldo, long strideo, hipStream_t st, double *part = nullptr);
+int sp_launch_defer_finish(int S, int K, int M, int Kp, const sp_star *stars, const double *meanvar,
+                           const double *condmean, int order, double zmax, const double *part,
+                           const double *diag, double *sys, void *coef, uint32_t *status,
+                           double *rowsum, hipStream_t st);
 int sp_launch_cholesky_systems(sp_handle *h, double *sys, int S, int K, int Kp,
                                int32_t *info, double *invL, hipStream_t st);
 int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *grp, int K,
@@ -43,7 +47,7 @@ int sp_debug_phase(sp_handle *h, double *sys, int S, int K, int Kp, int32_t *inf
 int sp_launch_lnlike_reduce(const double *sys, int S, int K, int M, int Kp,
                             const int32_t *info, double *lnlike, uint32_t *status,
                             hipStream_t st, uint32_t *status_out = nullptr,
-                            const sp_star *stars = nullptr);
+                            const sp_star *stars = nullptr, const void *defer_coef = nullptr);
 int sp_launch_pad_in(const double *A, int K, long lda, long strideA, double *sys,
                      int Kp, int M, const double *resid, int S, hipStream_t st);
 int sp_launch_pad_out(const double *sys, int Kp, double *A, int K, long lda,
@@ -155,15 +159,18 @@ inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 struct Layout {
   int S, K, M, Kp, N, NWIG;
   size_t theta, rowsum, qv, coef, info, status, condmean, cs, vrow, Rinc, invL, A,
-      B1, raw, sys, total;
+      B1, raw, part, sys, total;
 };
+
+// rows below the matrix that the deferred normalisation adds (p, q, 1; sp_assemble.hip)
+#define SP_DEFER_ROWS 3
 
 Layout make_layout(const sp_handle *h, int S, int K, int M, bool with_sys) {
   Layout L;
   L.S = S;
   L.K = K;
   L.M = M;
-  L.Kp = sp_roundup(K + M, SP_NB);
+  L.Kp = sp_roundup(K + M + (with_sys && h->defer_norm ? SP_DEFER_ROWS : 0), SP_NB);
   L.N = h->N;
   L.NWIG = h->NWIG;
   size_t off = 0;
@@ -187,6 +194,7 @@ Layout make_layout(const sp_handle *h, int S, int K, int M, bool with_sys) {
   L.A = take(d * (size_t)S * K * L.N);
   L.B1 = take(d * (size_t)S * K * L.N);
   L.raw = take(d * (size_t)S * K * K);
+  L.part = (with_sys && h->defer_norm) ? take(d * (size_t)S * (L.Kp / SP_NB) * K) : off;
   L.sys = with_sys ? take(d * (size_t)S * L.Kp * L.Kp) : off;
   L.total = off;
   return L;
@@ -292,6 +300,7 @@ Layout sub_layout(const Layout &L, int s0, int Sg) {
   G.A += z * L.K * L.N * d;
   G.B1 += z * L.K * L.N * d;
   G.raw += z * (size_t)L.K * L.K * d;
+  G.part += z * (size_t)(L.Kp / SP_NB) * L.K * d;
   G.sys += z * (size_t)L.Kp * L.Kp * d;
   return G;
 }
@@ -321,6 +330,17 @@ int lnlike_assemble(sp_handle *h, const Layout &L, void *ws, int K, int M, const
     condmean = cm;
   }
   const int cp = conditional ? 1 : covpts;
+  if (normalized && h->defer_norm) {
+    // deferred normalisation: ONE pass over the K^2 entries (raw tiles + their row / column sums),
+    // then the normalisation's vectors as three more rows of the system (sp_assemble.hip)
+    double *part = at<double>(ws, L.part);
+    if ((rc = sp_launch_assemble(S, K, M, L.Kp, 1, theta, t_dev, stars_dev, cp, tab_dev, meanvar_dev,
+                                 h->d_xp, temporal, rawp, 1, qv, coef, diag_dev, 1, flux_dev, sys,
+                                 L.Kp, (long)L.Kp * L.Kp, st, part)))
+      return rc;
+    return sp_launch_defer_finish(S, K, M, L.Kp, stars_dev, meanvar_dev, condmean, norm_order, zmax,
+                                  part, diag_dev, sys, coef, status, rowsum, st);
+  }
   if (normalized)
     if ((rc = sp_launch_rowsum(S, K, theta, t_dev, stars_dev, cp, tab_dev, meanvar_dev,
                                h->d_xp, temporal, rawp, rowsum, st)))
@@ -335,13 +355,14 @@ int lnlike_assemble(sp_handle *h, const Layout &L, void *ws, int K, int M, const
 
 // stage C: reduction of one group's factored systems
 int lnlike_finish(const Layout &L, void *ws, int K, int M, double *lnlike_dev,
-                  uint32_t *status_dev, hipStream_t st, const sp_star *stars_dev) {
+                  uint32_t *status_dev, hipStream_t st, const sp_star *stars_dev, bool deferred) {
   const int S = L.S;
   int rc;
   uint32_t *status = at<uint32_t>(ws, L.status);
   if ((rc = sp_launch_lnlike_reduce(at<double>(ws, L.sys), S, K, M, L.Kp,
                                     at<int32_t>(ws, L.info), lnlike_dev, status, st,
-                                    status_dev, stars_dev)))
+                                    status_dev, stars_dev,
+                                    deferred ? at<double>(ws, L.coef) : nullptr)))
     return rc;
   return SP_OK;
 }
@@ -404,6 +425,7 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
   h->prof_used = 0;
   h->chol_mode = 0;
   h->rec_base = SP_REC_BASE_DEFAULT;
+  h->defer_norm = 1;
   const int N = h->N;
   h->l_of.resize(N);
   h->m_of.resize(N);
@@ -448,6 +470,8 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
     h->onelaunch = e7 ? atoi(e7) : 0;
     const char *e3 = getenv("SP_GROUPS");
     h->groups = e3 ? atoi(e3) : 1;
+    const char *e10 = getenv("SP_DEFER_NORM");
+    h->defer_norm = e10 ? atoi(e10) : 1;
     const char *e9 = getenv("SP_REC_BASE");
     h->rec_base = e9 ? atoi(e9) : SP_REC_BASE_DEFAULT;
     if (h->rec_base < 1) h->rec_base = 1;
@@ -644,6 +668,13 @@ int sp_profile_kind(sp_handle *h, int kind, long *launches, double *total_ms, do
 
 int sp_profile_end(sp_handle *h, long *launches, double *total_ms, double *flops) {
   return sp_profile_kind(h, SP_PROF_SYRK, launches, total_ms, flops);
+}
+
+int sp_set_defer_norm(sp_handle *h, int on) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || (on != 0 && on != 1)) return SP_ERR_INVALID;
+  h->defer_norm = on;
+  return SP_OK;
 }
 
 int sp_set_chol_mode(sp_handle *h, int mode) {
@@ -978,7 +1009,8 @@ int sp_lnlike_ensemble(sp_handle *h, int S, int K, int M, const double *t_dev,
   for (int g = 0; g < G; ++g) {
     const int s0 = first[g];
     int rc = lnlike_finish(LG[g], ws, K, M, lnlike_dev + s0,
-                           status_dev ? status_dev + s0 : nullptr, CG[g].st, stars_dev + s0);
+                           status_dev ? status_dev + s0 : nullptr, CG[g].st, stars_dev + s0,
+                           normalized && h->defer_norm);
     if (rc) return rc;
     if (g > 0) {
       SP_HIP(hipEventRecord(h->gdone[g - 1], CG[g].st));

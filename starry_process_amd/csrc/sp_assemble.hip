@@ -234,7 +234,15 @@ __global__ __launch_bounds__(256) void norm_coef_kernel(
 //   SYSTEM = false: plain K x K covariance, every tile (sp.cov()).
 //   SYSTEM = true : the padded (Kp x Kp) Cholesky system: lower-triangle tiles
 //                   only, residual rows K..K+M-1, unit diagonal on the padding.
-template <bool FROM_MATRIX, bool SYSTEM>
+//   DEFER  = true : (SYSTEM only) deferred normalisation.  The tile is written RAW (spline x temporal
+//                   factor, no normalisation, no noise) and its row sums -- and, for tiles below
+//                   the diagonal, its column sums, which are the row sums of the mirror tile --
+//                   go to part[s][column tile][row]: the separate row-sum pass over all K^2
+//                   entries disappears.  defer_finish_kernel turns the sums into the
+//                   normalisation's vectors, which then ride through the factorisation as three
+//                   more rows (sp.py:705-727 is  c1 Sigma + rank 2;  lnlike_reduce_kernel applies
+//                   the rank-2 (+ baseline) part by the matrix determinant / Woodbury identities).
+template <bool FROM_MATRIX, bool SYSTEM, bool DEFER = false>
 __global__ __launch_bounds__(256) void assemble_kernel(
     int K, int M, int Kp, const double *__restrict__ theta,
     const double *__restrict__ t, const sp_star *__restrict__ stars, int covpts,
@@ -242,11 +250,16 @@ __global__ __launch_bounds__(256) void assemble_kernel(
     const double *__restrict__ xp, int temporal, const double *__restrict__ raw,
     int normalized, const double *__restrict__ qv, const Coef *__restrict__ coef,
     const double *__restrict__ diag, int add_noise, const double *__restrict__ flux,
-    double *__restrict__ out, long ldo, long strideo, int ntr) {
+    double *__restrict__ out, long ldo, long strideo, int ntr, double *__restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int s = blockIdx.y, np = covpts + 4;
   const sp_star st = stars[s];
-  const Coef c = coef[s];
+  Coef c;
+  if (DEFER) {
+    c.c1 = 1.0; c.zab = 0.0; c.za = 0.0; c.z = 0.0; c.gpmean = 0.0; c.m = 0.0; c.mu = 1.0; c.pad = 0.0;
+  } else {
+    c = coef[s];
+  }
   int ti, tj;
   if (SYSTEM) {
     const int tile = blockIdx.x;
@@ -263,19 +276,20 @@ __global__ __launch_bounds__(256) void assemble_kernel(
   double *s_thi = lds + (FROM_MATRIX ? 0 : 4 * np);     // 64 each below
   double *s_thj = s_thi + 64, *s_ti = s_thj + 64, *s_tj = s_ti + 64;
   double *s_qi = s_tj + 64, *s_qj = s_qi + 64;
+  double *s_col = s_qj + 64;   // DEFER: [16][64] column-sum partials
   if (!FROM_MATRIX) load_tables(tab + (size_t)st.table * 5 * np, np, xp, s_tab);
   if (threadIdx.x < 64) {
     const int i = i0 + threadIdx.x;
     const bool ok = i < K;
     s_thi[threadIdx.x] = (ok && !FROM_MATRIX) ? theta[(size_t)s * K + i] : 0.0;
     s_ti[threadIdx.x] = (ok && temporal != SP_TEMPORAL_NONE) ? t[(size_t)s * K + i] : 0.0;
-    s_qi[threadIdx.x] = (ok && normalized) ? qv[(size_t)s * K + i] : 0.0;
+    s_qi[threadIdx.x] = (ok && normalized && !DEFER) ? qv[(size_t)s * K + i] : 0.0;
   } else if (threadIdx.x < 128) {
     const int l = threadIdx.x - 64, j = j0 + l;
     const bool ok = j < K;
     s_thj[l] = (ok && !FROM_MATRIX) ? theta[(size_t)s * K + j] : 0.0;
     s_tj[l] = (ok && temporal != SP_TEMPORAL_NONE) ? t[(size_t)s * K + j] : 0.0;
-    s_qj[l] = (ok && normalized) ? qv[(size_t)s * K + j] : 0.0;
+    s_qj[l] = (ok && normalized && !DEFER) ? qv[(size_t)s * K + j] : 0.0;
   }
   __syncthreads();
   SplineGen g{s_tab, 2 * np, 6.283185307179586 / covpts,
@@ -286,11 +300,13 @@ __global__ __launch_bounds__(256) void assemble_kernel(
   // thread -> 4 consecutive columns, 16 rows per pass
   const int cj = (threadIdx.x & 15) * 4, ri = threadIdx.x >> 4;
   const int lim = SYSTEM ? Kp : K;
+  double csum[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
     const int li = ri + 16 * pass, i = i0 + li;
-    if (i >= lim) continue;
+    if (!DEFER && i >= lim) continue;
     double v[4];
+    double rsum = 0.0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int lj = cj + e, j = j0 + lj;
@@ -304,14 +320,18 @@ __global__ __launch_bounds__(256) void assemble_kernel(
         else
           rawv = g(s_thi[li], s_thj[lj]);
         rawv *= temporal_factor(temporal, s_ti[li], s_tj[lj], st.tau);
-        if (normalized) {
+        if (DEFER) {
+          val = rawv;
+          rsum += rawv;
+          csum[e] += rawv;
+        } else if (normalized) {
           const double qi = s_qi[li], qj = s_qj[lj];
           const double pp = (1.0 - qi) * (1.0 - qj), qq = qi * qj;
           val = c.c1 * rawv + c.z * (c.zab * pp - c.za * qq);
         } else {
           val = rawv;
         }
-        if (add_noise) {
+        if (add_noise && !DEFER) {
           if (i == j) val += diag ? diag[(size_t)s * K + i] : st.data_var;
           val += st.baseline_var;
         }
@@ -323,6 +343,15 @@ __global__ __launch_bounds__(256) void assemble_kernel(
       }
       v[e] = val;
     }
+    if (DEFER) {
+      // row sum of this tile's 64 columns: the 16 lanes that share the row
+      rsum += __shfl_xor(rsum, 8, 16);
+      rsum += __shfl_xor(rsum, 4, 16);
+      rsum += __shfl_xor(rsum, 2, 16);
+      rsum += __shfl_xor(rsum, 1, 16);
+      if ((threadIdx.x & 15) == 0 && i < K) part[((size_t)s * ntr + tj) * K + i] = rsum;
+      if (i >= lim) continue;
+    }
     double *dst = ob + (size_t)i * ldo + j0 + cj;
     if (j0 + cj + 3 < lim && (((size_t)dst) & 15) == 0) {
       *reinterpret_cast<dd2 *>(dst) = dd2{v[0], v[1]};
@@ -332,6 +361,97 @@ __global__ __launch_bounds__(256) void assemble_kernel(
       for (int e = 0; e < 4; ++e)
         if (j0 + cj + e < lim) dst[e] = v[e];
     }
+  }
+  if (DEFER && ti > tj) {
+    // column sums = row sums of the mirror tile (tj, ti), which is never formed
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s_col[ri * 64 + cj + e] = csum[e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      double a = 0.0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a += s_col[r * 64 + threadIdx.x];
+      const int j = j0 + threadIdx.x;
+      if (j < K) part[((size_t)s * ntr + ti) * K + j] = a;
+    }
+  }
+}
+
+// Deferred normalisation, second half: one workgroup per star.
+//   rowsum_r = sum over the column tiles of part[s][c][r]            (fixed order: deterministic)
+//   m, z, alpha(z), beta(z), c1 = alpha / mu^2                       (sp.py:705-727, ops/norm/norm.py:26-44)
+//   the system holds  B'' = Sigma + N / c1  (N: data variance): the diagonal gets N / c1 here
+//   three more rows below the residuals:  p = 1 - q,  q = rowsum / (K m),  1
+// C = c1 (B'' + d_p p p^T + d_q q q^T + d_1 1 1^T) with d_p = z (alpha + beta) / c1,
+// d_q = -z alpha / c1, d_1 = baseline_var / c1: lnlike_reduce_kernel finishes the job.
+__global__ __launch_bounds__(1024) void defer_finish_kernel(
+    int K, int M, int Kp, int ntr, const sp_star *__restrict__ stars,
+    const double *__restrict__ meanvar, const double *__restrict__ condmean, int order, double zmax,
+    const double *__restrict__ part, const double *__restrict__ diag, double *__restrict__ sys,
+    Coef *__restrict__ coef, uint32_t *__restrict__ status, double *__restrict__ rowsum) {
+  __shared__ double red[16];
+  const int s = blockIdx.x;
+  const sp_star st = stars[s];
+  const int nobs = star_nobs(st, K);
+  double *Mx = sys + (size_t)s * Kp * Kp;
+  const double *P = part + (size_t)s * ntr * K;
+  // (ragged stars: tiles beyond nobs contribute zeros)
+  double mine = 0.0;
+  double *rs = rowsum + (size_t)s * K;   // (each thread re-reads only what it wrote itself)
+  for (int r = threadIdx.x; r < K; r += 1024) {
+    // the column tiles eight at a time: the loads of a group are independent, the sum keeps its order
+    double a = 0.0;
+    for (int c0 = 0; c0 < ntr; c0 += 8) {
+      double v[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] = c0 + c < ntr ? P[(size_t)(c0 + c) * K + r] : 0.0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) a += v[c];
+    }
+    if (r >= nobs) a = 0.0;
+    rs[r] = a;
+    mine += a;
+  }
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  double total = 0.0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) total += red[w];
+  const double fmean = condmean ? condmean[s] : meanvar[2 * st.table];
+  const double mu = 1.0 + fmean;
+  const double m = total / ((double)nobs * (double)nobs);
+  const double z = m / (mu * mu);
+  double fac = 1.0, alpha = 0.0, beta = 0.0;
+  for (int n = 0; n <= order; ++n) {
+    alpha += fac;
+    beta += 2 * n * fac;
+    fac *= z * (2 * n + 3);
+  }
+  const double c1 = alpha / (mu * mu);
+  const double km = (double)nobs * m;
+  double *rowp = Mx + (size_t)(K + M) * Kp, *rowq = rowp + Kp, *row1 = rowq + Kp;
+  for (int r = threadIdx.x; r < K; r += 1024) {
+    const double a = rs[r];
+    const bool ok = r < nobs;
+    const double q = ok ? a / km : 0.0;
+    rowp[r] = ok ? 1.0 - q : 0.0;
+    rowq[r] = q;
+    row1[r] = ok ? 1.0 : 0.0;
+    if (ok) Mx[(size_t)r * Kp + r] += (diag ? diag[(size_t)s * K + r] : st.data_var) / c1;
+  }
+  if (threadIdx.x == 0) {
+    Coef c;
+    c.c1 = c1;
+    c.zab = z * (alpha + beta) / c1;   // d_p
+    c.za = -z * alpha / c1;            // d_q
+    c.z = z;
+    c.gpmean = 0.0;
+    c.m = m;
+    c.mu = mu;
+    c.pad = st.baseline_var / c1;      // d_1
+    coef[s] = c;
+    if (status && z > zmax) atomicOr(&status[s], SP_STAR_ZMAX);
   }
 }
 
@@ -407,22 +527,27 @@ int sp_launch_assemble(int S, int K, int M, int Kp, int system,
                        const double *xp, int temporal, const double *raw,
                        int normalized, const double *qv, const void *coef,
                        const double *diag, int add_noise, const double *flux,
-                       double *out, long ldo, long strideo, hipStream_t st) {
+                       double *out, long ldo, long strideo, hipStream_t st, double *part) {
   const int np = covpts + 4;
-  const size_t lds = sizeof(double) * ((raw ? 0 : 4 * (size_t)np) + 6 * 64);
+  const size_t lds = sizeof(double) * ((raw ? 0 : 4 * (size_t)np) + 6 * 64 + (part ? 16 * 64 : 0));
   if (lds > attr_lds_limit) return SP_ERR_INVALID;
   const int ntr = ((system ? Kp : K) + 63) / 64;
   const int ntiles = system ? ntr * (ntr + 1) / 2 : ntr * ntr;
   dim3 grid(ntiles, S);
-#define SP_ASM(FM, SY)                                                          \
-  do {                                                                          \
-    allow_big_lds(assemble_kernel<FM, SY>);                                     \
-    hipLaunchKernelGGL((assemble_kernel<FM, SY>), grid, dim3(256), lds, st, K,  \
-                       M, Kp, theta, t, stars, covpts, tab, meanvar, xp,        \
-                       temporal, raw, normalized, qv, (const Coef *)coef, diag, \
-                       add_noise, flux, out, ldo, strideo, ntr);                \
+#define SP_ASM(FM, SY, ...)                                                                \
+  do {                                                                                     \
+    allow_big_lds(assemble_kernel<FM, SY, ##__VA_ARGS__>);                                 \
+    hipLaunchKernelGGL((assemble_kernel<FM, SY, ##__VA_ARGS__>), grid, dim3(256), lds, st, K, \
+                       M, Kp, theta, t, stars, covpts, tab, meanvar, xp,                   \
+                       temporal, raw, normalized, qv, (const Coef *)coef, diag,            \
+                       add_noise, flux, out, ldo, strideo, ntr, part);                     \
   } while (0)
-  if (raw && system)
+  if (part && !system) return SP_ERR_INVALID;
+  if (part && raw)
+    SP_ASM(true, true, true);
+  else if (part)
+    SP_ASM(false, true, true);
+  else if (raw && system)
     SP_ASM(true, true);
   else if (raw)
     SP_ASM(true, false);
@@ -431,6 +556,16 @@ int sp_launch_assemble(int S, int K, int M, int Kp, int system,
   else
     SP_ASM(false, false);
 #undef SP_ASM
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}
+
+int sp_launch_defer_finish(int S, int K, int M, int Kp, const sp_star *stars, const double *meanvar,
+                           const double *condmean, int order, double zmax, const double *part,
+                           const double *diag, double *sys, void *coef, uint32_t *status,
+                           double *rowsum, hipStream_t st) {
+  hipLaunchKernelGGL(defer_finish_kernel, dim3(S), dim3(1024), 0, st, K, M, Kp, Kp / 64, stars, meanvar,
+                     condmean, order, zmax, part, diag, sys, (Coef *)coef, status, rowsum);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }

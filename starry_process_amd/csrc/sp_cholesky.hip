@@ -190,43 +190,119 @@ __global__ __launch_bounds__(256) void trsm_quad_kernel(double *sys, long ld, lo
 
 // lnlike = -1/2 sum_m |y_m|^2 - M sum_i log L_ii - K M / 2 log(2 pi)
 // (sp.py:1157-1188).  One workgroup per star.
+//
+// coef != nullptr: deferred normalisation (sp_assemble.hip, defer_finish_kernel).  The factored
+// matrix is B'' = Sigma + N / c1 and the true covariance is
+//     C = c1 (B'' + d_p p p^T + d_1 1 1^T + d_q q q^T),
+// with y_p, y_q, y_1 = L''^-1 p, q, 1 in the three rows below the residuals.  The matrix
+// determinant lemma and the Sherman-Morrison formula, one rank at a time (the two non-negative
+// terms first), give log det C and r^T C^-1 r from the Gram matrix of those rows and the
+// residuals'; a rank-1 step whose pivot 1 + d u^T B^-1 u is not positive means C is not positive
+// definite: the same -inf the reference's failed Cholesky gives (math.py:82-91, sp.py:1186-1188).
+struct RedCoef {   // = Coef of sp_assemble.hip
+  double c1, dp, dq, z, gpmean, m, mu, d1;
+};
+
 __global__ __launch_bounds__(256) void lnlike_reduce_kernel(
     const double *__restrict__ sys, long ld, long stride, int K, int M,
     const int32_t *__restrict__ info, double *__restrict__ lnlike,
     uint32_t *__restrict__ status, uint32_t *__restrict__ status_out,
-    const sp_star *__restrict__ stars) {
-  __shared__ double red[8];
+    const sp_star *__restrict__ stars, const RedCoef *__restrict__ coef) {
+  __shared__ double red[4][12];
   const int s = blockIdx.x;
   const double *Mx = sys + (size_t)s * stride;
-  double ld_part = 0.0, q_part = 0.0;
-  for (int i = threadIdx.x; i < K; i += 256) ld_part += log(Mx[(size_t)i * ld + i]);
+  const int wave = threadIdx.x >> 6;
+  // sums of v[0 .. 12) over the workgroup, in every thread (all twelve always: constant indices
+  // keep v in registers; the unused ones are zero)
+  auto block_sum = [&](double (&v)[12]) {
+#pragma unroll
+    for (int a = 0; a < 12; ++a)
+      for (int off = 32; off > 0; off >>= 1) v[a] += __shfl_down(v[a], off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int a = 0; a < 12; ++a) red[wave][a] = v[a];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 12; ++a) v[a] = (red[0][a] + red[1][a]) + (red[2][a] + red[3][a]);
+  };
+  double v[12];
+  for (int a = 0; a < 12; ++a) v[a] = 0.0;
+  const double *yp = Mx + (size_t)(K + M) * ld, *yq = yp + ld, *y1 = yq + ld;
+  const double *y0 = Mx + (size_t)K * ld;       // the first light curve's residuals ride in the same pass
+  for (int i = threadIdx.x; i < K; i += 256) {
+    v[0] += log(Mx[(size_t)i * ld + i]);
+    const double r = y0[i];
+    v[7] += r * r;
+    if (coef) {
+      const double a = yp[i], b = yq[i], c = y1[i];
+      v[1] += a * a; v[2] += a * b; v[3] += a * c; v[4] += b * b; v[5] += b * c; v[6] += c * c;
+      v[8] += r * a; v[9] += r * c; v[10] += r * b;
+    }
+  }
+  block_sum(v);
+  const double logdet = v[0];
+  // rank-1 steps on the 3 x 3 Gram matrix H (0 = p, 1 = 1, 2 = q): factor f_k and old column c_k
+  double f[3] = {0.0, 0.0, 0.0}, col[3][3], logs = 0.0;
+  bool notpd = false;
+  double c1 = 1.0;
+  if (coef) {
+    const RedCoef rc = coef[s];
+    c1 = rc.c1;
+    double H[3][3] = {{v[1], v[3], v[2]}, {v[3], v[6], v[5]}, {v[2], v[5], v[4]}};
+    const double d[3] = {rc.dp, rc.d1, rc.dq};
+    for (int k = 0; k < 3; ++k) {
+      for (int a = 0; a < 3; ++a) col[k][a] = H[a][k];
+      if (d[k] == 0.0) continue;
+      const double piv = 1.0 + d[k] * H[k][k];
+      if (!(piv > 0.0)) notpd = true;
+      logs += log(piv);
+      f[k] = d[k] / piv;
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) H[a][b] -= f[k] * col[k][a] * col[k][b];
+    }
+  }
+  double quad = 0.0;
   for (int m = 0; m < M; ++m) {
     const double *y = Mx + (size_t)(K + m) * ld;
-    for (int k = threadIdx.x; k < K; k += 256) q_part += y[k] * y[k];
+    double w[12];
+    for (int a = 0; a < 12; ++a) w[a] = 0.0;
+    if (m == 0) {
+      w[0] = v[7]; w[1] = v[8]; w[2] = v[9]; w[3] = v[10];
+    } else {
+      for (int k = threadIdx.x; k < K; k += 256) {
+        const double r = y[k];
+        w[0] += r * r;
+        if (coef) {
+          w[1] += r * yp[k];
+          w[2] += r * y1[k];
+          w[3] += r * yq[k];
+        }
+      }
+      block_sum(w);
+    }
+    double g = w[0], h[3] = {w[1], w[2], w[3]};
+    for (int k = 0; k < 3; ++k) {
+      if (f[k] == 0.0) continue;
+      const double hk = h[k];
+      g -= f[k] * hk * hk;
+      for (int a = 0; a < 3; ++a) h[a] -= f[k] * hk * col[k][a];
+    }
+    quad += g;
   }
-  for (int off = 32; off > 0; off >>= 1) {
-    ld_part += __shfl_down(ld_part, off, 64);
-    q_part += __shfl_down(q_part, off, 64);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    red[threadIdx.x >> 6] = ld_part;
-    red[4 + (threadIdx.x >> 6)] = q_part;
-  }
-  __syncthreads();
   if (threadIdx.x == 0) {
-    const double logdet = (red[0] + red[1]) + (red[2] + red[3]);
-    const double quad = (red[4] + red[5]) + (red[6] + red[7]);
-    double v = -0.5 * quad;
-    v -= M * logdet;
     // (ragged ensembles: the padding rows have unit pivots and zero residuals, only
-    //  the constant knows the number of valid cadences)
+    //  the constants know the number of valid cadences)
     const int nobs = (stars && stars[s].nobs > 0 && stars[s].nobs < K) ? stars[s].nobs : K;
-    v -= 0.5 * nobs * M * 1.8378770664093453;  // log(2 pi)
+    double val = -0.5 * quad / c1;
+    val -= M * (logdet + 0.5 * nobs * log(c1) + 0.5 * logs);
+    val -= 0.5 * nobs * M * 1.8378770664093453;  // log(2 pi)
     uint32_t st = status ? status[s] : 0u;
-    if (info && info[s]) st |= SP_STAR_NOT_PD;
-    if (v != v) st |= SP_STAR_NAN;
-    if (st & (SP_STAR_NOT_PD | SP_STAR_ZMAX | SP_STAR_NAN)) v = -INFINITY;
-    lnlike[s] = v;
+    if ((info && info[s]) || notpd) st |= SP_STAR_NOT_PD;
+    if (val != val) st |= SP_STAR_NAN;
+    if (st & (SP_STAR_NOT_PD | SP_STAR_ZMAX | SP_STAR_NAN)) val = -INFINITY;
+    lnlike[s] = val;
     if (status) status[s] = st;
     if (status_out) status_out[s] = st;
   }
@@ -863,9 +939,11 @@ int sp_debug_phase(sp_handle *h, double *sys, int S, int K, int Kp, int32_t *inf
 
 int sp_launch_lnlike_reduce(const double *sys, int S, int K, int M, int Kp,
                             const int32_t *info, double *lnlike, uint32_t *status,
-                            hipStream_t st, uint32_t *status_out, const sp_star *stars) {
+                            hipStream_t st, uint32_t *status_out, const sp_star *stars,
+                            const void *defer_coef) {
   hipLaunchKernelGGL(lnlike_reduce_kernel, dim3(S), dim3(256), 0, st, sys,
-                     (long)Kp, (long)Kp * Kp, K, M, info, lnlike, status, status_out, stars);
+                     (long)Kp, (long)Kp * Kp, K, M, info, lnlike, status, status_out, stars,
+                     (const RedCoef *)defer_coef);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }

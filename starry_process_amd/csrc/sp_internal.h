@@ -68,6 +68,7 @@ struct sp_handle {
   hipEvent_t gfork;
   int chol_mode;                // 2: recursive driver (strip solves), 0: super-panel driver (SP_CHOL)
   int rec_base;                 // recursive driver: panels per base block
+  int defer_norm;               // likelihood path: deferred normalisation (SP_DEFER_NORM, default 1)
   // optional per-launch timing of the factorisation's launches by kind (bench roofline)
   bool prof_on;
   unsigned prof_mask;                // kinds that are bracketed (bit k = kind k)

@@ -328,6 +328,13 @@ class Engine(object):
         """0: super-panel driver (default), 2: recursive driver with strip solves."""
         check(self._L.sp_set_chol_mode(self._h, int(mode)))
 
+    def set_defer_norm(self, on):
+        """True (default): normalised likelihoods assemble the raw covariance once and apply the
+        normalisation's rank-2 part to the result; False: separate row-sum pass (sp_set_defer_norm).
+        Invalidates the cached workspace size."""
+        check(self._L.sp_set_defer_norm(self._h, int(bool(on))))
+        self._ws = None
+
     def set_panel_mode(self, one_launch):
         """False: two launches per panel (shortest critical path, one evaluation at a time);
         True: one launch per panel (least HBM traffic, several evaluations in flight)."""

