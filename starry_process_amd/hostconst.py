@@ -17,7 +17,7 @@ same per-entry floating-point operation order as the reference (SciPy's
 polynomial d-matrices), but organised as whole-row array operations instead of
 per-entry Python loops, and with the second-moment contraction reduced to the
 m' = 0 rows that actually enter W (flux.py:181-187) instead of the 4-index
-tensor Q of flux.py:151-171.  tests/test_hostconst.py checks the outcome
+tensor Q of flux.py:151-171.  tests/test_host.py (test_marginal_constants_match_reference) checks the outcome
 against golden vectors from the executed reference.
 """
 import numpy as np

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Refresh the round-2 evidence: run ON THE GPU BOX from the repository root
+#   bash tools/profile_r02.sh
+# Raw output goes to gpurun_out/r02 (scratch); tools/collect_r02.py copies the summaries that are
+# judged into profiles/ (tracked).  Every rocprofv3 pass has the program directly after `--` and its
+# own timeout; the PMC passes use --kernel-trace only.  Kernel-level PMC evidence is taken one step
+# at a time in the one-launch-per-panel mode the in-flight handles use (with several steps in flight
+# a dispatch shares its counters' window with the other steps' kernels).
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r02
+rm -rf $O; mkdir -p $O
+# the driver's exact command
+timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/driver_cmd_bench.json 2> $O/bench.err
+# the same command under the kernel trace (no CPU leg, no extra shapes: same GPU work in the timed region)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_inflight -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-extras > $O/stats_inflight.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_one -- python3 bench.py --no-cpu --no-extras --in-flight 1 --steps 20 --warmup 5 > $O/stats_one.log 2>&1
+SP_ONELAUNCH=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_one_onelaunch -- python3 bench.py --no-cpu --no-extras --in-flight 1 --steps 20 --warmup 5 > $O/stats_one_onelaunch.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  SP_ONELAUNCH=1 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc $c -d $O/pmc_$c -- python3 bench.py --no-cpu --no-extras --in-flight 1 --steps 4 --warmup 1 --prewarm-ms 0 > $O/pmc_$c.log 2>&1
+done
+SP_ONELAUNCH=1 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $O/pmc_sq -- python3 bench.py --no-cpu --no-extras --in-flight 1 --steps 4 --warmup 1 --prewarm-ms 0 > $O/pmc_sq.log 2>&1
+timeout 300 python3 tools/mm_bench.py 0 6 10 11 12 > $O/mm_bench.txt 2>&1
+SP_CHOL=2 timeout 300 python3 tools/strip_bench.py > $O/strip_bench.txt 2>&1
+SP_CHOL=2 timeout 300 python3 bench.py --steps 40 --warmup 5 --no-cpu --no-extras > $O/recursive_bench.json 2>/dev/null
+timeout 300 python3 tools/check_modes.py > $O/check_modes.txt 2>&1
+python3 tools/collect_r02.py $O
+ls $O
