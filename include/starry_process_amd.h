@@ -361,11 +361,12 @@ int sp_profile_kind(sp_handle *h, int kind, long *launches, double *total_ms, do
 int sp_profile_begin_kinds(sp_handle *h, int max_launches, unsigned kind_mask);
 
 /* Driver of the blocked factorisation (math.py:75-91), per handle:
- *   2 (default): recursive -- diagonal blocks of 4 panels factored panel by panel, everything
- *                between them one strip solve (X = A21 L11^-T, a long-lived workgroup per 64-row
- *                strip) and one symmetric update per level;
- *   0: super-panels of 8 panels, left-looking inside, one trailing update per super-panel
- *      (round 1's driver; sp_set_panel_mode selects its one- or two-launch form).
+ *   0 (default): super-panels of 8 panels, left-looking inside, one trailing update per
+ *      super-panel (sp_set_panel_mode selects its one- or two-launch form);
+ *   2: recursive -- diagonal blocks of SP_REC_BASE (8) panels factored panel by panel,
+ *      everything between them one strip solve (X = A21 L11^-T, a long-lived workgroup per
+ *      64-row strip) and one symmetric update per level.  Measured equal to mode 0 within 2 %
+ *      at the north-star sizes, hence not the default.
  * Results agree to rounding (different summation order).  Environment: SP_CHOL.             */
 int sp_set_chol_mode(sp_handle *h, int mode);
 

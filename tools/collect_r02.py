@@ -16,7 +16,7 @@ P = os.path.join(ROOT, "profiles")
 
 
 def last(pattern):
-    f = sorted(glob.glob(os.path.join(O, pattern), recursive=True))
+    f = sorted(glob.glob(os.path.join(O, pattern), recursive=True), key=os.path.getmtime)
     return f[-1] if f else None
 
 

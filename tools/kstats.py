@@ -2,7 +2,8 @@
 """Summarise a rocprofv3 --kernel-trace --stats output directory:
 python tools/kstats.py <dir> [steps]"""
 import csv, glob, sys
-f = sorted(glob.glob(sys.argv[1] + '/**/*kernel_stats.csv', recursive=True))[-1]
+import os
+f = sorted(glob.glob(sys.argv[1] + '/**/*kernel_stats.csv', recursive=True), key=os.path.getmtime)[-1]
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 8
 rows = list(csv.DictReader(open(f)))
 tot = sum(int(r['TotalDurationNs']) for r in rows)

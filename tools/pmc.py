@@ -4,7 +4,8 @@ python tools/pmc.py <dir> [name-substring]"""
 import csv, glob, sys, collections
 d = sys.argv[1]
 sub = sys.argv[2] if len(sys.argv) > 2 else ""
-f = sorted(glob.glob(d + '/**/*counter_collection.csv', recursive=True))[-1]
+import os
+f = sorted(glob.glob(d + '/**/*counter_collection.csv', recursive=True), key=os.path.getmtime)[-1]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)
 for r in csv.DictReader(open(f)):

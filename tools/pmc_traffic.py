@@ -22,7 +22,8 @@ import sys
 
 
 def load(d, counter):
-    f = sorted(glob.glob(d + '/**/*counter_collection.csv', recursive=True))[-1]
+    import os
+    f = sorted(glob.glob(d + '/**/*counter_collection.csv', recursive=True), key=os.path.getmtime)[-1]
     out = collections.OrderedDict()
     for r in csv.DictReader(open(f)):
         if 'gemm_nt_kernel' not in r['Kernel_Name'] or r['Counter_Name'] != counter:

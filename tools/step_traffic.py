@@ -15,7 +15,8 @@ import sys
 
 
 def load(d, counter):
-    f = sorted(glob.glob(d + '/**/*counter_collection.csv', recursive=True))[-1]
+    import os
+    f = sorted(glob.glob(d + '/**/*counter_collection.csv', recursive=True), key=os.path.getmtime)[-1]
     out = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] != counter:

@@ -42,5 +42,6 @@ print("strip solve  %4d rows x %4d cols: %7.1f us  %5.1f TFLOP/s algorithmic (%.
 us = timeit(7, 0)
 fl = S * n2 * (n2 + 1.0) * bm * 64
 print("sym. update  n = %4d, k = %4d:   %7.1f us  %5.1f TFLOP/s algorithmic (%.2f of 78.6)" % (n2, bm * 64, us, fl / us * 1e-6, fl / us * 1e-6 / 78.6))
-for j in range((nb + 3) // 4):
-    print("base block %d (4 panels): %7.1f us" % (j, timeit(8, j)))
+base = int(os.environ.get("SP_REC_BASE", "8"))
+for j in range((nb + base - 1) // base):
+    print("base block %d (%d panels): %7.1f us" % (j, base, timeit(8, j)))
