@@ -38,7 +38,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-YDEG, UDEG, K, STARS_PER_GPU, COVPTS = 15, 2, 1000, 64, 300
+YDEG, UDEG, K, STARS_PER_GPU, COVPTS = 15, 2, 1000, int(os.environ.get("SP_BENCH_STARS", "64")), 300
 FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix = vector peak (AMD CDNA4 datasheet)
 HBM_PEAK_TBS = 8.0       # MI355X_MICROARCH.md (spec; 6.3 measured for a streaming copy)
 

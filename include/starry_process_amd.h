@@ -366,7 +366,10 @@ int sp_profile_begin_kinds(sp_handle *h, int max_launches, unsigned kind_mask);
  *   2: recursive -- diagonal blocks of SP_REC_BASE (8) panels factored panel by panel,
  *      everything between them one strip solve (X = A21 L11^-T, a long-lived workgroup per
  *      64-row strip) and one symmetric update per level.  Measured equal to mode 0 within 2 %
- *      at the north-star sizes, hence not the default.
+ *      at the north-star sizes, hence not the default;
+ *   3: dataflow panel chain -- ONE launch per super-panel: every 64-row strip is a long-lived
+ *      workgroup that walks the panels, ordered by flags in memory instead of kernel boundaries
+ *      (every wait bounded).  Measured slower than mode 0 here: an experiment.
  * Results agree to rounding (different summation order).  Environment: SP_CHOL.             */
 int sp_set_chol_mode(sp_handle *h, int mode);
 
@@ -408,6 +411,9 @@ int sp_debug_cholesky_phase(sp_handle *h, int S, int K, int M, void *workspace_d
  * (default), 2-8 = the other shapes tools/mm_bench.py compares.  Results do not depend on it
  * beyond the summation order.  Environment: SP_MM.                                        */
 int sp_debug_set_mm_variant(int variant);
+/* (debug) in-kernel wall-clock timestamps of the dataflow panel chain (sp_set_chol_mode 3): `buf` = device
+ * buffer of (super-panels) x (Kp / 64) x 128 int64, or NULL to switch off.  tools/chain_trace.py */
+int sp_debug_chain_trace(sp_handle *h, void *buf);
 
 #ifdef __cplusplus
 }

@@ -86,6 +86,7 @@ PROTOTYPES = {
     "sp_get_polar_moments": (_I, [_V, _V, _V]),
     "sp_debug_cholesky_phase": (_I, [_V, _I, _I, _I, _V, _I, _I, _V]),
     "sp_debug_set_mm_variant": (_I, [_I]),
+    "sp_debug_chain_trace": (_I, [_V, _V]),
     "sp_profile_kind": (_I, [_V, _I, ctypes.POINTER(ctypes.c_long), c_double_p, c_double_p]),
     "sp_set_chol_mode": (_I, [_V, _I]),
     "sp_set_defer_norm": (_I, [_V, _I]),

@@ -220,6 +220,9 @@ int ensure_big(sp_handle *h, size_t bytes, void **out) {
     SP_HIP(hipDeviceSynchronize());
     if (h->big_ptr) SP_HIP(hipFree(h->big_ptr));
     h->big_ptr = nullptr;
+  h->chain_mem = nullptr;
+  h->chain_dbg = nullptr;
+  h->chain_ints = 0;
     h->big_bytes = 0;
     hipError_t e = hipMalloc(&h->big_ptr, bytes);
     if (e != hipSuccess) {
@@ -509,6 +512,7 @@ void sp_destroy(sp_handle *h) {
   for (hipStream_t s2 : h->gstream) (void)hipStreamDestroy(s2);
   if (h->gfork) (void)hipEventDestroy(h->gfork);
   if (h->big_ptr) (void)hipFree(h->big_ptr);
+  if (h->chain_mem) (void)hipFree(h->chain_mem);
   for (auto &c : h->cs_ring) {
     if (c.host) (void)hipHostFree(c.host);
     if (c.dev) (void)hipFree(c.dev);
@@ -679,8 +683,16 @@ int sp_set_defer_norm(sp_handle *h, int on) {
 
 int sp_set_chol_mode(sp_handle *h, int mode) {
   if (h && h->device < 0) return SP_ERR_NO_DEVICE;
-  if (!h || (mode != 0 && mode != 2)) return SP_ERR_INVALID;
+  if (!h || (mode != 0 && mode != 2 && mode != 3)) return SP_ERR_INVALID;
   h->chol_mode = mode;
+  return SP_OK;
+}
+
+// (debug, tools/chain_trace.py) device buffer of nlaunch x ntile x 128 int64 that the dataflow
+// chain fills with wall-clock timestamps of star 0's strips; null switches it off
+int sp_debug_chain_trace(sp_handle *h, void *buf) {
+  if (!h) return SP_ERR_INVALID;
+  h->chain_dbg = (long long *)buf;
   return SP_OK;
 }
 

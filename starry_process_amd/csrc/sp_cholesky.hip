@@ -687,6 +687,69 @@ static int cholesky_recursive(sp_handle *h, int ngroups, const sp_chol_group *gr
   return SP_OK;
 }
 
+// ---- dataflow driver (h->chol_mode == 3): one launch per super-panel (sp_chain.hip) -------------
+// super-panels of w pivot blocks; between two of them the rank-64w update of the trailing matrix
+// (its tile (0, 0), the next pivot block, was completed and factored by the chain).
+static int ensure_chain_mem(sp_handle *h, size_t ints) {
+  if (h->chain_ints >= ints) return SP_OK;
+  // (growing synchronises the device: launches of this handle may still read the old buffer)
+  SP_HIP(hipDeviceSynchronize());
+  if (h->chain_mem) SP_HIP(hipFree(h->chain_mem));
+  h->chain_mem = nullptr;
+  h->chain_ints = 0;
+  hipError_t e = hipMalloc((void **)&h->chain_mem, ints * sizeof(int));
+  if (e != hipSuccess) {
+    sp_set_hip_error(e, "hipMalloc(chain flags)");
+    return SP_ERR_ALLOC;
+  }
+  h->chain_ints = ints;
+  return SP_OK;
+}
+
+static int cholesky_dataflow(sp_handle *h, const sp_chol_group &G, int K, int Kp, int w) {
+  const long ld = Kp, stride = (long)Kp * Kp, lts = sp_lt_stride(Kp);
+  const int nsteps = (K + SP_NB - 1) / SP_NB, ntile = Kp / SP_NB;
+  const int nact_last = K - (nsteps - 1) * SP_NB;
+  const int nlaunch = (nsteps + w - 1) / w;
+  const size_t ints = sp_chain_mem_ints(G.S, ntile, nlaunch);
+  int rc = ensure_chain_mem(h, ints);
+  if (rc != SP_OK) return rc;
+  SP_HIP(hipMemsetAsync(h->chain_mem, 0, ints * sizeof(int), G.st));
+  int *flags = h->chain_mem, *tickets = flags + (size_t)G.S * 2 * ntile;
+  int *abort_flag = tickets + 8 * (size_t)nlaunch;
+  int launch = 0;
+  for (int s0 = 0; s0 < nsteps; s0 += w, ++launch) {
+    const int wq = nsteps - s0 < w ? nsteps - s0 : w;
+    {
+      // algorithmic work of the launch, panel by panel as the per-panel drivers count it:
+      // left-looking product + substitution + eager rank-64 updates + diagonal blocks
+      double fl = 0.0;
+      int nd = 0;
+      for (int q = 0; q < wq; ++q) {
+        const double rows = Kp - (s0 + q + 1) * SP_NB;
+        int last = s0 + w;
+        if (last > nsteps - 1) last = nsteps - 1;
+        const int neager = last > s0 + q ? last - (s0 + q) : 0;
+        fl += 2.0 * rows * 64 * (q * 64.0) + rows * 64 * 64 + neager * 64.0 * 64 * 64;
+      }
+      nd = (s0 == 0 ? 1 : 0) + (s0 + wq < nsteps ? wq : wq - 1);
+      fl += nd * 64.0 * 64 * 64 / 3;
+      SpProfScope prof(h, G.st, SP_PROF_PANELS, (double)G.S * fl);
+      rc = sp_launch_chain(G.sys, ld, stride, G.S, ntile, s0, wq, nsteps, nact_last, G.invL, lts,
+                           flags, tickets + 8 * launch, abort_flag, G.info,
+                           h->chain_dbg ? h->chain_dbg + (size_t)launch * ntile * 128 : nullptr, G.st);
+      if (rc != SP_OK) return rc;
+    }
+    const int cE = (s0 + w) * SP_NB;
+    if (cE < K) {
+      rc = bulk_update(h, G.sys, ld, stride, G.S, s0 * SP_NB, cE, Kp, w * SP_NB, G.st, lts, 0, nullptr,
+                       nullptr, 0, 1);
+      if (rc != SP_OK) return rc;
+    }
+  }
+  return SP_OK;
+}
+
 // In-place factorisation of S padded systems (Kp x Kp, ld = Kp): the leading
 // K x K part is factored, rows K..Kp-1 only receive the triangular solve.
 //
@@ -709,6 +772,7 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
   // measured with the eager diagonal updates: K = 1000 (16 panels) w = 2 / 4 / 6 / 8 /
   // 12 / 16 -> 1.17 / 1.10 / 1.085 / 1.08 / 1.12 / 1.14 ms per step; K = 3000 (47 panels): 8 best as well
   const int w = (h && h->superpanel > 0) ? h->superpanel : (nsteps >= 16 ? 8 : 4);
+  if (h && h->chol_mode == 3 && ngroups == 1) return cholesky_dataflow(h, grp[0], K, Kp, w);
   if (h && h->onelaunch && h->fuse_diag > 1 && h->eager) {
     // ONE launch per panel (sp_launch_panel): update + solve + eager diagonal updates + the
     // next diagonal block; the L_d^T images ping-pong between the two slots of a star

@@ -212,9 +212,10 @@ __device__ __forceinline__ void below_quad(double *sD, const double *sRd, const 
 // identity padding of a partial block) and a barrier behind the stores.
 // Returns 1 in every thread of wavefronts that saw a non-positive pivot
 // (callers OR it through global memory).
+// (tid_in: a caller inside a long loop passes a laundered copy of threadIdx.x, sp_chain.hip)
 __device__ __forceinline__ int diag_block(double *sD, double *sRd, double *__restrict__ lt,
-                                          long long *dbg = nullptr) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+                                          long long *dbg = nullptr, int tid_in = threadIdx.x) {
+  const int tid = tid_in, lane = tid & 63, wave = tid >> 6;
   int notpd = 0;
 #pragma unroll 1
   for (int kb = 0; kb < 4; ++kb) {

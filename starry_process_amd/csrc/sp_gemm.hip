@@ -170,6 +170,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
     }
   }
 
+  // (one launch per panel) the image of the solve is in memory since the previous launch: its
+  // fetch rides behind the product instead of standing between the product and the solve
+  LtRegs lt_pre;
+  if (FUSE == 2 && FAST) lt_load(lt_pre, lt_in + (size_t)mtx * lts);
+
   const bool vecA = ((lda & 1) == 0) && ((reinterpret_cast<uintptr_t>(Ab) & 15) == 0);
   const bool vecB = ((ldb & 1) == 0) && ((reinterpret_cast<uintptr_t>(Bb) & 15) == 0);
 
@@ -246,8 +251,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
     for (int n = 0; n < 4; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r) sT[(16 * wave + fk + 4 * r) * XW + 16 * n + fr] = acc[n][r];
-    LtRegs lt;
-    lt_load(lt, lt_in + (size_t)mtx * lts);
+    if (!FAST) lt_load(lt_pre, lt_in + (size_t)mtx * lts);
+    const LtRegs &lt = lt_pre;
     __syncthreads();
     double x[16];
 #pragma unroll

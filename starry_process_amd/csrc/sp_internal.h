@@ -66,9 +66,13 @@ struct sp_handle {
   std::vector<hipStream_t> gstream;
   std::vector<hipEvent_t> gdone;
   hipEvent_t gfork;
-  int chol_mode;                // 2: recursive driver (strip solves), 0: super-panel driver (SP_CHOL)
+  int chol_mode;                // 0: super-panel driver, 2: recursive driver (strip solves), 3: dataflow chain (SP_CHOL)
   int rec_base;                 // recursive driver: panels per base block
   int defer_norm;               // likelihood path: deferred normalisation (SP_DEFER_NORM, default 1)
+  // dataflow panel chain (chol_mode 3, sp_chain.hip): flags, tickets and the abort word
+  int *chain_mem;
+  size_t chain_ints;
+  long long *chain_dbg;         // (debug) caller's buffer for in-kernel timestamps, or null
   // optional per-launch timing of the factorisation's launches by kind (bench roofline)
   bool prof_on;
   unsigned prof_mask;                // kinds that are bracketed (bit k = kind k)
@@ -121,6 +125,11 @@ struct SpProfScope {
 // inv_first: L_d^-T of the first column block (those of the following blocks 8192 doubles apart)
 int sp_launch_strip(double *sys, long ld, long stride, int batch, int r0, int nrt, int c0, int nb,
                     const double *inv_first, long lts, hipStream_t st);
+// dataflow panel chain of one super-panel (sp_chain.hip): pivot blocks s0 .. s0 + wq - 1
+size_t sp_chain_mem_ints(int S, int ntile, int nlaunch);
+int sp_launch_chain(double *sys, long ld, long stride, int S, int ntile, int s0, int wq, int nsteps,
+                    int nact_last, double *img, long lts, int *flags, int *tickets, int *abort_flag,
+                    int32_t *info, long long *dbg, hipStream_t st);
 
 const char *sp_set_hip_error(hipError_t e, const char *what);
 

@@ -79,20 +79,22 @@ struct TrsmStep<64> {
 struct LtRegs {
   d2v v[8];
 };
-__device__ __forceinline__ void lt_load(LtRegs &R, const double *LT) {
+// (tid: callers inside long loops pass a laundered copy of threadIdx.x so that the index
+//  arithmetic is redone per use instead of being hoisted and kept in registers)
+__device__ __forceinline__ void lt_load(LtRegs &R, const double *LT, int tid = threadIdx.x) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     // row k of the image is zero left of the diagonal (lt[k][c] = L_ck / L_cc, c >= k): those
     // pairs are not fetched -- the image is a third of a solve workgroup's traffic
-    const int e = 2 * (threadIdx.x + 256 * i), k = e >> 6, c = e & 63;
+    const int e = 2 * (tid + 256 * i), k = e >> 6, c = e & 63;
     R.v[i] = (c + 1 >= k) ? *reinterpret_cast<const d2v *>(LT + e) : d2v{0.0, 0.0};
   }
 }
 // sLT[64 * 64] gets the image with a zero diagonal, sRd[64] the diagonal (1 / L_kk)
-__device__ __forceinline__ void lt_store(const LtRegs &R, double *sLT, double *sRd) {
+__device__ __forceinline__ void lt_store(const LtRegs &R, double *sLT, double *sRd, int tid = threadIdx.x) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const int e = 2 * (threadIdx.x + 256 * i);
+    const int e = 2 * (tid + 256 * i);
     const int k = e >> 6, c = e & 63;
     d2v v = R.v[i];
     const bool d0 = c == k, d1 = c + 1 == k;
@@ -105,8 +107,9 @@ __device__ __forceinline__ void lt_store(const LtRegs &R, double *sLT, double *s
 
 // rows of a 64-row tile, quad layout: thread t holds row t >> 2, columns 8 i + 2 (t & 3) + {0, 1}
 __device__ __forceinline__ void quad_solve_store(double (&x)[16], const double *sLT,
-                                                 const double *sRd, double *Xrow, bool valid) {
-  const int q = threadIdx.x & 3;
+                                                 const double *sRd, double *Xrow, bool valid,
+                                                 int tid = threadIdx.x) {
+  const int q = tid & 3;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const d2v rd = *reinterpret_cast<const d2v *>(sRd + 8 * i + 2 * q);

@@ -325,7 +325,7 @@ class Engine(object):
         return bb.reshape(shape)
 
     def set_chol_mode(self, mode):
-        """0: super-panel driver (default), 2: recursive driver with strip solves."""
+        """0: super-panel driver (default), 2: recursive driver with strip solves, 3: dataflow panel chain."""
         check(self._L.sp_set_chol_mode(self._h, int(mode)))
 
     def set_defer_norm(self, on):

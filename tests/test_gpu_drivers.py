@@ -5,6 +5,8 @@ the BASELINE sizes ("close the pytest holes"):
   * super-panel driver in its two-launch and one-launch-per-panel forms (sp_set_panel_mode) at
     K = 1000 with the full 64-star batch of cfg3 and at K = 3000 (cfg5), against the golden
     values of the executed reference (tests/golden/lnlike.npz) and against each other;
+  * the dataflow panel chain (sp_set_chol_mode 3: one launch per super-panel, workgroups ordered
+    by flags in memory) on the same, with every one of its waits bounded;
   * the recursive driver with its strip-solve kernel (sp_set_chol_mode 2) on the same, plus a
     sweep of awkward sizes (partial last block, residual rows spilling into blocks of their own,
     fewer panels than a base block) against the super-panel driver;
@@ -50,7 +52,7 @@ def engines():
     return get
 
 
-MODES = [(0, 0), (0, 1), (2, 0)]   # (chol_mode, panel_mode)
+MODES = [(0, 0), (0, 1), (2, 0), (3, 0)]   # (chol_mode, panel_mode); 3: dataflow chain (sp_chain.hip)
 
 
 def lnl(e, K, idx, tspan=4.0, u=(0.0, 0.0), tau=None, M=1, data_var=None):
@@ -122,13 +124,28 @@ def test_awkward_sizes_recursive_vs_superpanel(engines, K, M):
     ref, st0 = lnl(engines(15, 0, 0), K, range(3, 3 + S), M=M)
     one, st1 = lnl(engines(15, 0, 1), K, range(3, 3 + S), M=M)
     rec, st2 = lnl(engines(15, 2, 0), K, range(3, 3 + S), M=M)
-    assert not st0.any() and not st1.any() and not st2.any()
+    flow, st3 = lnl(engines(15, 3, 0), K, range(3, 3 + S), M=M)
+    assert not st0.any() and not st1.any() and not st2.any() and not st3.any()
     assert np.all(np.isfinite(ref))
     # (with M > 1 shifted copies a star's value can be a small difference of terms of size
     #  max |lnlike| over the batch: the drivers agree relative to that size)
     scale = np.maximum(np.abs(ref), np.abs(ref).max())
     assert np.max(np.abs(one - ref) / scale) < TOL_DRIVERS
     assert np.max(np.abs(rec - ref) / scale) < TOL_DRIVERS
+    assert np.max(np.abs(flow - ref) / scale) < TOL_DRIVERS
+
+
+@pytest.mark.parametrize("S", [1, 3, 8, 13, 64])
+def test_dataflow_chain_batch_sizes(engines, S):
+    """The dataflow chain deals stars to per-XCD queues (S >= 8: star s to XCD s % 8, uneven when 8
+    does not divide S) or to one queue with device-scope releases (S < 8): same values as the
+    super-panel driver, bit-identical when repeated."""
+    ref, st0 = lnl(engines(15, 0, 0), 700, range(S))
+    a, st1 = lnl(engines(15, 3, 0), 700, range(S))
+    b, _ = lnl(engines(15, 3, 0), 700, range(S))
+    assert not st0.any() and not st1.any()
+    assert np.array_equal(a, b)
+    assert np.max(np.abs(a / ref - 1)) < TOL_DRIVERS
 
 
 def test_failure_semantics_every_driver(engines):
@@ -146,16 +163,21 @@ def test_failure_semantics_every_driver(engines):
         assert np.array_equal(good, v[ok]), (chol, panel)
 
 
-def test_three_steps_in_flight_K1000():
+@pytest.mark.parametrize("chol", [0, 3])
+def test_three_steps_in_flight_K1000(chol):
     """bench.py's default configuration: three independent 64-star, K = 1000 steps on three
     (handle, stream) pairs, enqueued before anything is synchronised, repeated; every step gives
-    exactly the bits of the same step run alone on its handle."""
+    exactly the bits of the same step run alone on its handle.  chol = 3: three dataflow chains
+    share the GPU (their workgroups wait on flags while holding their CU slots: progress must not
+    depend on all of them being resident)."""
     import torch
     from starry_process_amd.engine import engine_slots, make_stars
 
     S, K = 64, 1000
     mom = golden("moments_L15")
     slots = engine_slots(15, 2, None, 3)
+    for e, _ in slots:
+        e.set_chol_mode(chol)
     e0 = slots[0][0]
     sts = [synthetic_star(s, K) for s in range(S)]
     t_d = e0.f64(np.array([s["t"] for s in sts]))

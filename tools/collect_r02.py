@@ -36,13 +36,15 @@ if os.path.exists(fn):
         json.dump(line, open(os.path.join(P, "r02_driver_cmd_bench.json"), "w"), indent=1)
 for name in ("stats_inflight", "stats_one", "stats_one_onelaunch"):
     copy(last(name + "/**/*kernel_stats.csv"), "r02_%s_kernel_stats.csv" % name.replace("stats_", ""))
-for name in ("mm_bench.txt", "strip_bench.txt", "check_modes.txt"):
+for name in ("mm_bench.txt", "strip_bench.txt", "check_modes.txt", "chain_trace.txt"):
     copy(os.path.join(O, name), "r02_" + name)
-fn = os.path.join(O, "recursive_bench.json")
-if os.path.exists(fn):
-    for l in open(fn):
-        if l.startswith("{"):
-            json.dump(json.loads(l), open(os.path.join(P, "r02_recursive_driver_bench.json"), "w"), indent=1)
+for src, dst in (("recursive_bench.json", "r02_recursive_driver_bench.json"),
+                 ("dataflow_bench.json", "r02_dataflow_driver_bench.json")):
+    fn = os.path.join(O, src)
+    if os.path.exists(fn):
+        for l in open(fn):
+            if l.startswith("{"):
+                json.dump(json.loads(l), open(os.path.join(P, dst), "w"), indent=1)
 
 # launches per step in the PMC runs: count the lnlike_reduce dispatches (one per step)
 def steps_of(d):
