@@ -414,6 +414,10 @@ int sp_debug_set_mm_variant(int variant);
 /* (debug) in-kernel wall-clock timestamps of the dataflow panel chain (sp_set_chol_mode 3): `buf` = device
  * buffer of (super-panels) x (Kp / 64) x 128 int64, or NULL to switch off.  tools/chain_trace.py */
 int sp_debug_chain_trace(sp_handle *h, void *buf);
+/* (debug) wall-clock stamps of the one-launch-per-panel kernel; only in a library built with
+ * -DSP_PANEL_TRACE (tools/ab_build.sh), SP_ERR_INVALID otherwise.  out == NULL resets; else 64 x 4 x 16
+ * int64 (launch, workgroup {pivot strip, strip 3}, stamp).  tools/panel_trace.py */
+int sp_debug_panel_trace(long long *out);
 
 #ifdef __cplusplus
 }

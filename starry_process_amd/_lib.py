@@ -12,6 +12,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsp_hip.so")
+# (debug: an A/B variant built by tools/ab_build.sh)
+if os.environ.get("SP_LIB_VARIANT"):
+    LIB_PATH = os.path.join(_HERE, "libsp_hip_%s.so" % os.environ["SP_LIB_VARIANT"])
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
@@ -87,6 +90,7 @@ PROTOTYPES = {
     "sp_debug_cholesky_phase": (_I, [_V, _I, _I, _I, _V, _I, _I, _V]),
     "sp_debug_set_mm_variant": (_I, [_I]),
     "sp_debug_chain_trace": (_I, [_V, _V]),
+    "sp_debug_panel_trace": (_I, [_V]),
     "sp_profile_kind": (_I, [_V, _I, ctypes.POINTER(ctypes.c_long), c_double_p, c_double_p]),
     "sp_set_chol_mode": (_I, [_V, _I]),
     "sp_set_defer_norm": (_I, [_V, _I]),

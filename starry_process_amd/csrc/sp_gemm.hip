@@ -27,6 +27,28 @@
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 #define GT 64   // tile edge
+// one-launch-per-panel kernel: workgroups per CU asked of the compiler (0: whatever it needs), and
+// whether the image of the solve is fetched ahead of the product (32 more registers)
+#ifndef SP_PANEL_WGS
+#define SP_PANEL_WGS 0
+#endif
+#ifndef SP_PANEL_PREFETCH
+#define SP_PANEL_PREFETCH 0
+#endif
+
+#ifdef SP_PANEL_TRACE
+// (variant build only, tools/ab_build.sh -DSP_PANEL_TRACE: wall-clock stamps of the workgroups of
+//  star 0 in the one-launch-per-panel kernel; rows = launches in order, read by sp_debug_panel_trace)
+__device__ long long g_panel_trace[64 * 4 * 16];
+__device__ int g_panel_trace_n;
+#define PT_STAMP(k)                                                                              \
+  do {                                                                                           \
+    if (FUSE == 2 && mtx == 0 && (ti == 0 || ti == 3) && threadIdx.x == 0 && pt_row < 64)         \
+      g_panel_trace[(pt_row * 4 + (ti == 0 ? 0 : 1)) * 16 + (k)] = wall_clock64();                \
+  } while (0)
+#else
+#define PT_STAMP(k) do { } while (0)
+#endif
 
 namespace {
 
@@ -104,7 +126,7 @@ __device__ __forceinline__ void stage_store(const PanelRegs<BK> &R, double scale
 // LDS staging stores / barriers in the loop, 3: also no LDS fragment reads (MFMA
 // issue only), 4: everything but the C tile load / store.  Results are garbage.
 template <int BK, bool DEFER_C, int FUSE, int ABL = 0, bool FAST = false>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(
+__global__ __launch_bounds__(256, (FUSE == 2 && SP_PANEL_WGS > 0) ? SP_PANEL_WGS : 1) void gemm_nt_kernel(
     const double *A, long lda, long strideA,
     const double *__restrict__ B, long ldb, long strideB, double *C,
     long ldc, long strideC, int Mrows, int Nrows, int Kd, double alpha,
@@ -136,6 +158,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
     tj = tile % ntn;
   }
   const int row0 = ti * GT, col0 = tj * GT;
+#ifdef SP_PANEL_TRACE
+  const int pt_row = (FUSE == 2) ? __hip_atomic_load(&g_panel_trace_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 64;
+#endif
+  PT_STAMP(0);
   // (one-launch-per-panel mode: the first diagonal block of the next super-panel has
   //  been updated eagerly AND factored by the last panel launch -- leave it alone)
   if (FUSE == 0 && skip00 && lower_only && ti == 0 && tj == 0) return;
@@ -173,7 +199,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
   // (one launch per panel) the image of the solve is in memory since the previous launch: its
   // fetch rides behind the product instead of standing between the product and the solve
   LtRegs lt_pre;
-  if (FUSE == 2 && FAST) lt_load(lt_pre, lt_in + (size_t)mtx * lts);
+  if (FUSE == 2 && FAST && SP_PANEL_PREFETCH) lt_load(lt_pre, lt_in + (size_t)mtx * lts);
 
   const bool vecA = ((lda & 1) == 0) && ((reinterpret_cast<uintptr_t>(Ab) & 15) == 0);
   const bool vecB = ((ldb & 1) == 0) && ((reinterpret_cast<uintptr_t>(Bb) & 15) == 0);
@@ -236,6 +262,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[n] += cin[n];
   }
+  PT_STAMP(1);
 
   if (FUSE == 2) {
     // One launch per panel: the updated 64 x 64 tile never goes back to memory unsolved.
@@ -251,7 +278,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
     for (int n = 0; n < 4; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r) sT[(16 * wave + fk + 4 * r) * XW + 16 * n + fr] = acc[n][r];
-    if (!FAST) lt_load(lt_pre, lt_in + (size_t)mtx * lts);
+    if (!(FAST && SP_PANEL_PREFETCH)) lt_load(lt_pre, lt_in + (size_t)mtx * lts);
     const LtRegs &lt = lt_pre;
     __syncthreads();
     double x[16];
@@ -263,9 +290,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
     __syncthreads();
     lt_store(lt, sT, sT + 4096);
     __syncthreads();
+    PT_STAMP(2);
     const bool valid = row0 + lrow < Mrows;
     double *prow = Cb + (size_t)(row0 + (valid ? lrow : 0)) * ldc + col0 + 2 * q;
     quad_solve_store(x, sT, sT + 4096, prow, valid);
+    PT_STAMP(3);
     const int neager = skip00;
     if (ti >= neager) return;
     __syncthreads();
@@ -303,6 +332,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         D[(size_t)(16 * wave + fk + 4 * r) * ldc + 16 * n + fr] = dac[n][r];
+    PT_STAMP(4);
     if (ti > 0 || nact <= 0) return;
     // the next pivot block: complete now -- factor it (nact = its active columns; rows and
     // columns beyond them keep the updated values just stored)
@@ -318,7 +348,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
         sD[li * BLD + lj] = v;
       }
     __syncthreads();
+    PT_STAMP(5);
     const int notpd = diag_block(sD, sRd, invL_all + (size_t)mtx * lts);
+    PT_STAMP(6);
     if (notpd && info) info[mtx] = 1;
     {
       const int cj = (threadIdx.x & 15) * 4, ri = threadIdx.x >> 4;
@@ -331,6 +363,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
           if (r < nact && cj + e <= r) dst[e] = sD[r * BLD + cj + e];
       }
     }
+    PT_STAMP(7);
+#ifdef SP_PANEL_TRACE
+    if (mtx == 0 && threadIdx.x == 0) atomicAdd(&g_panel_trace_n, 1);
+#endif
     return;
   }
 
@@ -672,6 +708,26 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
 // columns of the panels before it in the super-panel (A: those rows, B: the 64 rows of the
 // pivot block), solved against lt_in, eagerly applied to the leading `neager` diagonal
 // tiles, and the first of those is factored (next_nact > 0) into lt_out.
+// (debug) stamps of the one-launch-per-panel kernel, variant builds with -DSP_PANEL_TRACE only:
+// reset (out == null) or copy out 64 x 4 x 16 int64
+int sp_debug_panel_trace(long long *out) {
+#ifdef SP_PANEL_TRACE
+  if (!out) {
+    static long long zeros[64 * 4 * 16];
+    int z = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_panel_trace), zeros, sizeof(zeros)) != hipSuccess) return SP_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_panel_trace_n), &z, sizeof(z)) != hipSuccess) return SP_ERR_HIP;
+    return SP_OK;
+  }
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_panel_trace), sizeof(long long) * 64 * 4 * 16) != hipSuccess)
+    return SP_ERR_HIP;
+  return SP_OK;
+#else
+  (void)out;
+  return SP_ERR_INVALID;
+#endif
+}
+
 int sp_launch_panel(const double *A, long lda, const double *B, long ldb, double *C, long ldc,
                     long stride, int Mrows, int Kd, int batch, const double *lt_in, double *lt_out,
                     long lts, int neager, int next_nact, int32_t *info, hipStream_t st) {
