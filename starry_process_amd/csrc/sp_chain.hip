@@ -141,7 +141,6 @@ __global__ __launch_bounds__(256, 3) void chain_kernel(ChainArgs a) {
   __shared__ int s_tk, s_ok;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
-  const int q = tid & 3, lrow = tid >> 2;
   const bool local = a.ngrp == 8;
   const int grp = local ? chain_xcc_id() : 0;
   const int nst = local ? (a.S >> 3) + (grp < (a.S & 7) ? 1 : 0) : a.S;

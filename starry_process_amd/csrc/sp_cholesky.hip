@@ -31,7 +31,7 @@ namespace {
 // Stand-alone diagonal-block kernel: one workgroup per star (used for the first
 // panel of every super-panel; the other panels get their diagonal block from the
 // fused tile-(0,0) workgroup of the block-column update, sp_gemm.hip).
-template <bool TIMED>
+template <bool TIMED, bool INV = false>
 __global__ __launch_bounds__(256) void diag_kernel(double *__restrict__ sys, long ld,
                                                    long stride, int c0, int nact,
                                                    double *__restrict__ invL_all, long lts,
@@ -78,6 +78,11 @@ __global__ __launch_bounds__(256) void diag_kernel(double *__restrict__ sys, lon
         if (c <= r && r < nact) dst[e] = sD[r * BLD + c];
       }
     }
+  }
+  if (INV) {
+    // L_d^-T behind the image: the one-launch-per-panel kernel solves with it (sp_gemm.hip)
+    __syncthreads();
+    diag_inverse(lds, sD, sRd, invL_all + (size_t)blockIdx.x * lts + SP_LT_IMG);
   }
   if (TIMED) {
     __syncthreads();
@@ -551,10 +556,14 @@ static int launch_trsm(sp_handle *h, double *sys, long ld, long stride, int S, i
 }
 
 static int launch_diag(sp_handle *h, double *sys, long ld, long stride, int S, int c0, int nact,
-                       double *invL, long lts, int32_t *info, hipStream_t st) {
+                       double *invL, long lts, int32_t *info, hipStream_t st, bool inverse = false) {
   SpProfScope prof(h, st, SP_PROF_CHAIN, (double)S * nact * (double)nact * nact / 3.0);
-  hipLaunchKernelGGL(diag_kernel<false>, dim3(S), dim3(256), 0, st, sys, ld, stride, c0, nact, invL,
-                     lts, info, nullptr);
+  if (inverse)
+    hipLaunchKernelGGL((diag_kernel<false, true>), dim3(S), dim3(256), 0, st, sys, ld, stride, c0, nact,
+                       invL, lts, info, nullptr);
+  else
+    hipLaunchKernelGGL((diag_kernel<false, false>), dim3(S), dim3(256), 0, st, sys, ld, stride, c0, nact,
+                       invL, lts, info, nullptr);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }
@@ -779,7 +788,7 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
     for (int g = 0; g < ngroups; ++g) {
       const sp_chol_group &G = grp[g];
       int rc = launch_diag(h, G.sys, ld, stride, G.S, 0, K < SP_NB ? K : SP_NB, G.invL, lts, G.info,
-                           G.st);
+                           G.st, SP_PANEL_MFMA_SOLVE != 0);
       if (rc != SP_OK) return rc;
     }
     for (int s0 = 0; s0 < nsteps; s0 += w) {
@@ -799,8 +808,9 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
         const int next_nact = (j + 1 < nsteps) ? (K - c1 < SP_NB ? K - c1 : SP_NB) : 0;
         for (int g = 0; g < ngroups; ++g) {
           const sp_chol_group &G = grp[g];
-          const double *lt_in = G.invL + (size_t)(j & 1) * SP_LT_IMG;
-          double *lt_out = G.invL + (size_t)((j + 1) & 1) * SP_LT_IMG;
+          // (image, L_d^-T) pairs, two per star, used in turn
+          const double *lt_in = G.invL + (size_t)(j & 1) * 2 * SP_LT_IMG;
+          double *lt_out = G.invL + (size_t)((j + 1) & 1) * 2 * SP_LT_IMG;
           const double rows = Kp - r1;
           // left-looking product + substitution + eager rank-64 updates + the next diagonal block
           const double fl = (double)G.S * (2.0 * rows * 64 * (q * 64.0) + rows * 64 * 64 +

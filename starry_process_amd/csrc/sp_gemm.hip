@@ -273,7 +273,64 @@ __global__ __launch_bounds__(256, (FUSE == 2 && SP_PANEL_WGS > 0) ? SP_PANEL_WGS
     //   other parity, while the rest of this launch still reads lt_in).
     constexpr int XW = 65;
     double *sT = smem;                         // 64 x 65 doubles <= SP_TILE_LDS_DOUBLES
+#if !SP_PANEL_MFMA_SOLVE
     const int tid = threadIdx.x, q = tid & 3, lrow = tid >> 2;
+#endif
+#if SP_PANEL_MFMA_SOLVE
+    // X = T L_d^-T as a product: L_d^-T (row k, column n; zero for n < k) was left behind the
+    // image by the workgroup that factored the block (diag_inverse, sp_tile.h).  Its fragments
+    // come straight from memory (L2) into registers while T goes through LDS to become the A
+    // operand; the 16 x 16 blocks below the diagonal are skipped: 40 MFMAs per wavefront instead
+    // of 64 dependent vector steps that kept the LDS pipe busy for every resident workgroup.
+    const double *iv = lt_in + (size_t)mtx * lts + SP_LT_IMG + fk * 64 + fr;
+    double bq[40];
+    {
+      int e = 0;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            if (n >= kb) bq[e++] = iv[(16 * kb + 4 * s4) * 64 + 16 * n];
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sT[(16 * wave + fk + 4 * r) * XW + 16 * n + fr] = acc[n][r];
+    __syncthreads();
+    d4 xo[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) xo[n] = d4{0.0, 0.0, 0.0, 0.0};
+    {
+      const double *pa = sT + (16 * wave + fr) * XW + fk;
+      int e = 0;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const double a = pa[16 * kb + 4 * s4];
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            if (n >= kb) xo[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq[e++], xo[n], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = row0 + 16 * wave + fk + 4 * r;
+        if (FAST || gi < Mrows) Cb[(size_t)gi * ldc + col0 + 16 * n + fr] = xo[n][r];
+      }
+    const int neager = skip00;
+    if (ti >= neager) return;
+    __syncthreads();                           // T has been read by every wavefront
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sT[(16 * wave + fk + 4 * r) * XW + 16 * n + fr] = xo[n][r];
+    __syncthreads();
+#else
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll
@@ -307,6 +364,8 @@ __global__ __launch_bounds__(256, (FUSE == 2 && SP_PANEL_WGS > 0) ? SP_PANEL_WGS
       }
     }
     __syncthreads();
+#endif
+    PT_STAMP(3);
     // my own diagonal tile: rows / columns (GT + row0 ..) relative to the block column
     double *D = Cb + (size_t)row0 * ldc + GT + row0;
     d4 dac[4];
@@ -363,6 +422,11 @@ __global__ __launch_bounds__(256, (FUSE == 2 && SP_PANEL_WGS > 0) ? SP_PANEL_WGS
           if (r < nact && cj + e <= r) dst[e] = sD[r * BLD + cj + e];
       }
     }
+#if SP_PANEL_MFMA_SOLVE
+    // ... and its L_d^-T for the next launch's solves, behind the image
+    __syncthreads();
+    diag_inverse(smem, sD, sRd, invL_all + (size_t)mtx * lts + SP_LT_IMG);
+#endif
     PT_STAMP(7);
 #ifdef SP_PANEL_TRACE
     if (mtx == 0 && threadIdx.x == 0) atomicAdd(&g_panel_trace_n, 1);

@@ -118,6 +118,14 @@ struct SpProfScope {
   }
 };
 
+// one-launch-per-panel kernel (sp_gemm.hip): the panel solve by substitution on the vector ALU, four
+// lanes per row (0, default), or as a product against L_d^-T on the matrix cores (1: the workgroup
+// that factors a block also inverts it; measured: solve + image 9-13 us -> 4-6 us per workgroup,
+// +4.4 us on the tail of every launch, 0.98 -> 1.01 ms alone, +-1 % with three steps in flight)
+#ifndef SP_PANEL_MFMA_SOLVE
+#define SP_PANEL_MFMA_SOLVE 0
+#endif
+
 // strip solve: at most this many 64-column blocks per launch (wider triangles are split)
 #define SP_STRIP_MAXB 8
 // diagonal blocks of at most this many panels are factored panel by panel (h->rec_base; SP_REC_BASE)
@@ -216,6 +224,7 @@ int sp_launch_gemm_nt_diag(const double *A, long lda, long strideA, const double
 // per-star scratch of the factorisation: one L_d^T image (64 x 64 doubles) per 64-column block
 // of the padded system, at least two (the ping-pong of the one-launch-per-panel mode).  Doubles.
 // (two images per block: L_d^T for the substitution solves and L_d^-T for the strip solves)
-static inline long sp_lt_stride(int Kp) { const long nb = Kp / SP_NB; return (nb < 1 ? 1 : nb) * 8192L; }
+// (at least two blocks: the one-launch-per-panel mode ping-pongs between two (image, inverse) pairs)
+static inline long sp_lt_stride(int Kp) { const long nb = Kp / SP_NB; return (nb < 2 ? 2 : nb) * 8192L; }
 
 #endif

@@ -131,4 +131,33 @@ __device__ __forceinline__ void quad_solve_store(double (&x)[16], const double *
   }
 }
 
+// L_d^-T of the block diag_block has just factored: sD holds L (rows of BLD doubles), sRd the
+// reciprocal diagonal.  The rows of the identity are solved like any other tile, X = I L_d^-T, so
+// inv_out (64 x 64, row-major) gets row k, column n = (L_d^-1)[n][k] -- the operand with which a
+// panel solve becomes a product on the matrix cores (sp_gemm.hip one-launch-per-panel kernel,
+// sp_strip.hip).  All 256 threads; `work` (>= 4160 doubles) may alias sD, which is overwritten.
+__device__ __forceinline__ void diag_inverse(double *work, const double *sD, const double *sRd,
+                                             double *__restrict__ inv_out, int tid = threadIdx.x) {
+  LtRegs R;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int e = 2 * (tid + 256 * i), k = e >> 6, c = e & 63;
+    d2v v;
+    v.x = c > k ? sD[c * BLD + k] * sRd[c] : (c == k ? sRd[k] : 0.0);
+    v.y = c + 1 > k ? sD[(c + 1) * BLD + k] * sRd[c + 1] : (c + 1 == k ? sRd[k] : 0.0);
+    R.v[i] = v;
+  }
+  __syncthreads();
+  lt_store(R, work, work + 4096, tid);
+  __syncthreads();
+  const int q = tid & 3, row = tid >> 2;
+  double x[16];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    x[2 * i] = (8 * i + 2 * q == row) ? 1.0 : 0.0;
+    x[2 * i + 1] = (8 * i + 2 * q + 1 == row) ? 1.0 : 0.0;
+  }
+  quad_solve_store(x, work, work + 4096, inv_out + (size_t)row * 64 + 2 * q, true, tid);
+}
+
 #endif
