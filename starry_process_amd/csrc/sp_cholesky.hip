@@ -816,15 +816,18 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
           const double fl = (double)G.S * (2.0 * rows * 64 * (q * 64.0) + rows * 64 * 64 +
                                            neager * 64.0 * 64 * 64 + 64.0 * 64 * 64 / 3);
           SpProfScope prof(h, G.st, SP_PROF_CHAIN, fl);
-          sp_scope.add(fl, nact < SP_NB ? 2 : 1);
+          sp_scope.add(fl, (nact < SP_NB && (j == 0 || SP_PANEL_MFMA_SOLVE)) ? 2 : 1);
           int rc;
           if (nact < SP_NB) {
             // partial last block: the rows of its own diagonal tile below the active ones
             // (residual rows, padding) already carry every update -- the eager updates cover
             // the whole tile -- and are only solved; the rows beyond the tile get the product
-            rc = sp_launch_panel(G.sys + (size_t)r1 * ld + cS, ld, G.sys + (size_t)c0 * ld + cS, ld,
-                                 G.sys + (size_t)r1 * ld + c0, ld, stride, c1 - r1, 0, G.S, lt_in,
-                                 lt_out, lts, 0, 0, G.info, G.st);
+            // (a block factored by the previous panel launch had them solved on the spot)
+            rc = SP_OK;
+            if (j == 0 || SP_PANEL_MFMA_SOLVE)
+              rc = sp_launch_panel(G.sys + (size_t)r1 * ld + cS, ld, G.sys + (size_t)c0 * ld + cS, ld,
+                                   G.sys + (size_t)r1 * ld + c0, ld, stride, c1 - r1, 0, G.S, lt_in,
+                                   lt_out, lts, 0, 0, G.info, G.st);
             if (rc != SP_OK) return rc;
             rc = sp_launch_panel(G.sys + (size_t)c1 * ld + cS, ld, G.sys + (size_t)c0 * ld + cS, ld,
                                  G.sys + (size_t)c1 * ld + c0, ld, stride, Kp - c1, q * SP_NB, G.S,

@@ -426,6 +426,31 @@ __global__ __launch_bounds__(256, (FUSE == 2 && SP_PANEL_WGS > 0) ? SP_PANEL_WGS
     // ... and its L_d^-T for the next launch's solves, behind the image
     __syncthreads();
     diag_inverse(smem, sD, sRd, invL_all + (size_t)mtx * lts + SP_LT_IMG);
+#else
+    if (nact < GT) {
+      // partial last block: the rows of this tile below the active ones (residual rows,
+      // padding) carry every update already (the eager updates cover the whole tile) and are
+      // solved against the block just factored, here, instead of by a launch of their own
+      // (identity padding: their columns >= nact stay as they are)
+      const int tid2 = threadIdx.x, q2 = tid2 & 3, lrow2 = tid2 >> 2;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile and diag_block's image are in memory
+      __syncthreads();                                   // ... and L has been copied out of sD
+      LtRegs lt2;
+      lt_load(lt2, invL_all + (size_t)mtx * lts);
+      double x2[16];
+      {
+        const double *prow = D + (size_t)lrow2 * ldc + 2 * q2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const d2v v = *reinterpret_cast<const d2v *>(prow + 8 * i);
+          x2[2 * i] = v.x;
+          x2[2 * i + 1] = v.y;
+        }
+      }
+      lt_store(lt2, sT, sT + 4096);
+      __syncthreads();
+      quad_solve_store(x2, sT, sT + 4096, D + (size_t)lrow2 * ldc + 2 * q2, lrow2 >= nact);
+    }
 #endif
     PT_STAMP(7);
 #ifdef SP_PANEL_TRACE
