@@ -45,33 +45,38 @@ def run(e, args, reps=1):
     return outs, status.cpu().numpy()
 
 
-e0, e3 = engine(0, 1), engine(3)
-cases = [(8, 200, 1), (9, 40, 1), (5, 64, 1), (3, 65, 1), (16, 513, 1), (8, 960, 70), (64, 1000, 1), (7, 1345, 1),
-         (12, 1100, 5), (1, 700, 1)]
-if len(sys.argv) > 1 and sys.argv[1] == "quick":
-    cases = cases[:2]
-for S, K, M in cases:
-    a0 = setup(e0, S, K, M)
-    ref, st0 = run(e0, a0)
-    t0 = time.time()
-    outs, st3 = run(e3, setup(e3, S, K, M), reps=3)
-    dt = time.time() - t0
-    scale = np.maximum(np.abs(ref[0]), np.abs(ref[0]).max())
-    err = np.max(np.abs(outs[0] - ref[0]) / scale)
-    same = all(np.array_equal(outs[0], o) for o in outs[1:])
-    print("S %3d K %5d M %2d: max rel diff %.2e  repeats %s  status %d/%d  finite %s  (%.2f s)"
-          % (S, K, M, err, same, int(np.count_nonzero(st0)), int(np.count_nonzero(st3)),
-             bool(np.all(np.isfinite(outs[0]))), dt), flush=True)
+def main():
+    e0, e3 = engine(0, 1), engine(3)
+    cases = [(8, 200, 1), (9, 40, 1), (5, 64, 1), (3, 65, 1), (16, 513, 1), (8, 960, 70), (64, 1000, 1), (7, 1345, 1),
+             (12, 1100, 5), (1, 700, 1)]
+    if len(sys.argv) > 1 and sys.argv[1] == "quick":
+        cases = cases[:2]
+    for S, K, M in cases:
+        a0 = setup(e0, S, K, M)
+        ref, st0 = run(e0, a0)
+        t0 = time.time()
+        outs, st3 = run(e3, setup(e3, S, K, M), reps=3)
+        dt = time.time() - t0
+        scale = np.maximum(np.abs(ref[0]), np.abs(ref[0]).max())
+        err = np.max(np.abs(outs[0] - ref[0]) / scale)
+        same = all(np.array_equal(outs[0], o) for o in outs[1:])
+        print("S %3d K %5d M %2d: max rel diff %.2e  repeats %s  status %d/%d  finite %s  (%.2f s)"
+              % (S, K, M, err, same, int(np.count_nonzero(st0)), int(np.count_nonzero(st3)),
+                 bool(np.all(np.isfinite(outs[0]))), dt), flush=True)
 
-# time per step, one at a time
-for name, e in (("super-panel, two launches", engine(0, 0)), ("super-panel, one launch", e0), ("dataflow chain", e3)):
-    a = setup(e, 64, 1000)
-    for w in (0,):
-        run(e, a, reps=30)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n = 200
-        for _ in range(n):
-            e.lnlike_ensemble(a[0], a[1], a[2], tab=a[3], meanvar=a[4])
-        torch.cuda.synchronize()
-        print("%-28s %.4f ms per 64-star step" % (name, (time.perf_counter() - t0) / n * 1e3), flush=True)
+    # time per step, one at a time
+    for name, e in (("super-panel, two launches", engine(0, 0)), ("super-panel, one launch", e0), ("dataflow chain", e3)):
+        a = setup(e, 64, 1000)
+        for w in (0,):
+            run(e, a, reps=30)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 200
+            for _ in range(n):
+                e.lnlike_ensemble(a[0], a[1], a[2], tab=a[3], meanvar=a[4])
+            torch.cuda.synchronize()
+            print("%-28s %.4f ms per 64-star step" % (name, (time.perf_counter() - t0) / n * 1e3), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -24,7 +24,7 @@ SP_CHOL=2 timeout 300 python3 tools/strip_bench.py > $O/strip_bench.txt 2>&1
 SP_CHOL=2 timeout 300 python3 bench.py --steps 40 --warmup 5 --no-cpu --no-extras > $O/recursive_bench.json 2>/dev/null
 timeout 300 python3 tools/check_modes.py > $O/check_modes.txt 2>&1
 # the dataflow panel chain (experiment): values, times, in-kernel timeline of star 0; in flight
-(cd tools && timeout 300 python3 chain_trace.py) > $O/chain_trace.txt 2>&1
+(cd tools && timeout 300 python3 chain_check.py && timeout 300 python3 chain_trace.py && timeout 300 python3 graph_step.py) > $O/chain_trace.txt 2>&1
 SP_CHOL=3 timeout 300 python3 bench.py --steps 40 --warmup 5 --no-cpu --no-extras > $O/dataflow_bench.json 2>/dev/null
 python3 tools/collect_r02.py $O
 ls $O
