@@ -81,8 +81,12 @@ __global__ __launch_bounds__(256) void diag_kernel(double *__restrict__ sys, lon
   }
   if (INV) {
     // L_d^-T behind the image: the one-launch-per-panel kernel solves with it (sp_gemm.hip)
+#if SP_PANEL_MFMA_SOLVE == 2
+    diag_solve_operand(sD, sRd, invL_all + (size_t)blockIdx.x * lts + SP_LT_IMG);
+#else
     __syncthreads();
     diag_inverse(lds, sD, sRd, invL_all + (size_t)blockIdx.x * lts + SP_LT_IMG);
+#endif
   }
   if (TIMED) {
     __syncthreads();

@@ -276,7 +276,53 @@ __global__ __launch_bounds__(256, (FUSE == 2 && SP_PANEL_WGS > 0) ? SP_PANEL_WGS
 #if !SP_PANEL_MFMA_SOLVE
     const int tid = threadIdx.x, q = tid & 3, lrow = tid >> 2;
 #endif
-#if SP_PANEL_MFMA_SOLVE
+#if SP_PANEL_MFMA_SOLVE == 2
+    // X = T L_d^-T as a block substitution on the matrix cores (diag_solve_operand, sp_tile.h):
+    //   X_c = (T_c - sum_{k<c} X_k L_ck^T) M_c^T,   c = 0..3 (16 columns each),
+    // with the 16 x 16 blocks L_ck and the leaf inverses M_c read as MFMA operands straight from
+    // memory (L2) into registers.  A wavefront works on its own 16 rows throughout: T_c is its
+    // accumulator n = c, X_k goes through ITS rows of the LDS tile to become an A operand -- no
+    // workgroup barrier, no image staged in LDS, 40 MFMAs instead of 64 dependent vector steps.
+    const double *Wop = lt_in + (size_t)mtx * lts + SP_LT_IMG + (size_t)fr * 64 + fk;
+    double bq[40];
+    {
+      int e = 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k <= c; ++k)
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) bq[e++] = Wop[(16 * c) * 64 + 16 * k + 4 * s4];
+    }
+    {
+      double *mine = sT + (16 * wave) * XW;         // this wavefront's 16 rows of the tile
+      int e = 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        d4 u = acc[c];
+#pragma unroll
+        for (int k = 0; k < c; ++k)
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4)
+            u = __builtin_amdgcn_mfma_f64_16x16x4f64(-mine[fr * XW + 16 * k + 4 * s4 + fk], bq[e++], u, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[(fk + 4 * r) * XW + 16 * c + fr] = u[r];
+        d4 x = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          x = __builtin_amdgcn_mfma_f64_16x16x4f64(mine[fr * XW + 16 * c + 4 * s4 + fk], bq[e++], x, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          mine[(fk + 4 * r) * XW + 16 * c + fr] = x[r];
+          const int gi = row0 + 16 * wave + fk + 4 * r;
+          if (FAST || gi < Mrows) Cb[(size_t)gi * ldc + col0 + 16 * c + fr] = x[r];
+        }
+      }
+    }
+    const int neager = skip00;
+    if (ti >= neager) return;
+    __syncthreads();                           // the solved tile, row layout, complete in LDS
+#elif SP_PANEL_MFMA_SOLVE
     // X = T L_d^-T as a product: L_d^-T (row k, column n; zero for n < k) was left behind the
     // image by the workgroup that factored the block (diag_inverse, sp_tile.h).  Its fragments
     // come straight from memory (L2) into registers while T goes through LDS to become the A
@@ -422,7 +468,10 @@ __global__ __launch_bounds__(256, (FUSE == 2 && SP_PANEL_WGS > 0) ? SP_PANEL_WGS
           if (r < nact && cj + e <= r) dst[e] = sD[r * BLD + cj + e];
       }
     }
-#if SP_PANEL_MFMA_SOLVE
+#if SP_PANEL_MFMA_SOLVE == 2
+    // ... and the operand of the next launch's solves (L's blocks, the leaves inverted), behind the image
+    diag_solve_operand(sD, sRd, invL_all + (size_t)mtx * lts + SP_LT_IMG);
+#elif SP_PANEL_MFMA_SOLVE
     // ... and its L_d^-T for the next launch's solves, behind the image
     __syncthreads();
     diag_inverse(smem, sD, sRd, invL_all + (size_t)mtx * lts + SP_LT_IMG);

@@ -121,7 +121,8 @@ struct SpProfScope {
 // one-launch-per-panel kernel (sp_gemm.hip): the panel solve by substitution on the vector ALU, four
 // lanes per row (0, default), or as a product against L_d^-T on the matrix cores (1: the workgroup
 // that factors a block also inverts it; measured: solve + image 9-13 us -> 4-6 us per workgroup,
-// +4.4 us on the tail of every launch, 0.98 -> 1.01 ms alone, +-1 % with three steps in flight)
+// +4.4 us on the tail of every launch, 0.98 -> 1.01 ms alone, +-1 % with three steps in flight;
+// 2: as a block substitution with the four 16 x 16 leaves inverted: 1.02 ms alone, -4 % in flight)
 #ifndef SP_PANEL_MFMA_SOLVE
 #define SP_PANEL_MFMA_SOLVE 0
 #endif

@@ -160,4 +160,57 @@ __device__ __forceinline__ void diag_inverse(double *work, const double *sD, con
   quad_solve_store(x, work, work + 4096, inv_out + (size_t)row * 64 + 2 * q, true, tid);
 }
 
+// ---- operand of the panel solve as a BLOCK substitution on the matrix cores (SP_PANEL_MFMA_SOLVE 2) ----
+// W (64 x 64, row-major): the 16 x 16 blocks of L_d below the diagonal as they are, and in place
+// of each diagonal block L_cc its inverse M_c.  A solve X = T L_d^-T is then, block column by
+// block column,  X_c = (T_c - sum_{k<c} X_k L_ck^T) M_c^T : 40 MFMAs per wavefront, no inverse of
+// the whole block to form -- only the four 16 x 16 leaves are inverted, each by one wavefront
+// (lane = row, four columns per 16-lane group, x_k handed round by DPP row broadcasts).
+template <int K>
+struct LeafInvStep {
+  static __device__ __forceinline__ void run(double (&s)[4], double (&res)[4], const double (&Lrow)[16],
+                                             double rd, int i) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const double m = s[t] * rd;                 // row K of column t: final in lane K
+      res[t] = (i == K) ? m : res[t];
+      s[t] = fma(-Lrow[K], row_bcast<K>(m), s[t]);
+    }
+    LeafInvStep<K + 1>::run(s, res, Lrow, rd, i);
+  }
+};
+template <>
+struct LeafInvStep<16> {
+  static __device__ __forceinline__ void run(double (&)[4], double (&)[4], const double (&)[16], double, int) {}
+};
+
+// after diag_block: sD holds L (rows of BLD doubles, zero above the diagonal), sRd 1 / L_cc.
+// All 256 threads; reads LDS only, writes W.
+__device__ __forceinline__ void diag_solve_operand(const double *sD, const double *sRd,
+                                                   double *__restrict__ W, int tid = threadIdx.x) {
+  for (int e = tid; e < 4096; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    if ((r >> 4) > (c >> 4)) W[e] = sD[r * BLD + c];
+  }
+  const int wave = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4, o = 16 * wave;
+  double Lrow[16];
+#pragma unroll
+  for (int k = 0; k < 16; k += 2) {
+    const d2v v = *reinterpret_cast<const d2v *>(sD + (o + i) * BLD + o + k);
+    Lrow[k] = v.x;
+    Lrow[k + 1] = v.y;
+  }
+  const double rd = sRd[o + i];
+  double s[4], res[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    s[t] = (i == 4 * g + t) ? 1.0 : 0.0;
+    res[t] = 0.0;
+  }
+  LeafInvStep<0>::run(s, res, Lrow, rd, i);
+  double *dst = W + (size_t)(o + i) * 64 + o + 4 * g;
+  *reinterpret_cast<d2v *>(dst) = d2v{res[0], res[1]};
+  *reinterpret_cast<d2v *>(dst + 2) = d2v{res[2], res[3]};
+}
+
 #endif
