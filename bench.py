@@ -376,6 +376,16 @@ def main():
 
     elapsed, host_enqueue, prewarm_steps = timed_steps(harness, args.steps, args.warmup, args.prewarm_ms, arm)
     timed_prof = prof_summary([sl.e for sl in slots], timed_kinds)
+    # Untimed repeat of the same steps in flight with EVERY panel kernel under its own pair of
+    # events (the pairs cost a few per cent of a step, hence not in the timed region)
+    launch_prof = None
+    if F > 1:
+        for sl in slots:
+            sl.e.profile_begin((args.steps // F + 2) * 24, ("panel_launch",))
+        for i in range(args.steps):
+            slots[i % F].run()
+        torch.cuda.synchronize()
+        launch_prof = prof_summary([sl.e for sl in slots], ("panel_launch",))["panel_launch"]
     nran = min(F, args.steps + max(args.warmup, F if args.warmup else 0) + prewarm_steps)   # slots that ran
     out, status = slots[0].out, slots[0].status
     lnl = out.cpu().numpy().copy()
@@ -512,6 +522,18 @@ def main():
             # (one step at a time, every launch bracketed, measured in this run) is `alone`
             "steps_in_flight": F,
             "event_ms_by_kind": {k: v["ms"] for k, v in timed_prof.items()},
+            "avg_launch_ms_note": "events on the launch stream: with several steps in flight a launch's bracket "
+                                  "includes the time its workgroups wait for CUs held by the other steps' kernels "
+                                  "(rocprofv3's kernel trace times a kernel from its first wavefront: "
+                                  "profiles/*_inflight_kernel_stats.csv shows ~25 % less); `per_launch` = every "
+                                  "launch under its own pair in an untimed repeat (the timed region uses one pair "
+                                  "per super-panel): same figure, so the grouping is not what differs; one step "
+                                  "at a time (`alone`) events and kernel trace agree",
+            "per_launch": (None if not launch_prof or not launch_prof["launches"] else {
+                "launches": launch_prof["launches"],
+                "avg_launch_ms": launch_prof["ms"] / launch_prof["launches"],
+                "achieved": launch_prof["flops"] / (launch_prof["ms"] * 1e-3) / 1e12,
+                "frac": launch_prof["flops"] / (launch_prof["ms"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}),
             "alone": alone,
             "secondary": {k: roofline_entry(k, v) for k, v in cand.items() if k != dom},
             "whole_step": whole,

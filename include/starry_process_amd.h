@@ -352,8 +352,9 @@ int sp_profile_end(sp_handle *h, long *launches, double *total_ms, double *flops
 /* The same for one KIND of launch of the factorisation (every launch is bracketed while
  * profiling is on): 0 symmetric trailing updates (what sp_profile_end reports), 1 strip solves
  * X = A L^-T, 2 the panel chain (diagonal blocks, block-column updates, panel solves),
- * 3 covariance assembly (row sums + assembly).  Stops the profile like sp_profile_end; may be
- * called for several kinds in a row.                                                     */
+ * 3 covariance assembly (row sums + assembly), 4 the one-launch-per-panel kernels of a whole
+ * super-panel under ONE pair of events, 5 each of those kernels under its own pair.  Stops the
+ * profile like sp_profile_end; may be called for several kinds in a row.                   */
 int sp_profile_kind(sp_handle *h, int kind, long *launches, double *total_ms, double *flops);
 /* sp_profile_begin for a chosen set of kinds (bit k of kind_mask = kind k; sp_profile_begin
  * = kind 0 only).  An event pair costs a few microseconds of stream time: bracket the panel

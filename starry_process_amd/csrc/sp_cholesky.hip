@@ -820,6 +820,7 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
           const double fl = (double)G.S * (2.0 * rows * 64 * (q * 64.0) + rows * 64 * 64 +
                                            neager * 64.0 * 64 * 64 + 64.0 * 64 * 64 / 3);
           SpProfScope prof(h, G.st, SP_PROF_CHAIN, fl);
+          SpProfScope prof1(h, G.st, SP_PROF_PANEL_LAUNCH, fl, (nact < SP_NB && (j == 0 || SP_PANEL_MFMA_SOLVE)) ? 2 : 1);
           sp_scope.add(fl, (nact < SP_NB && (j == 0 || SP_PANEL_MFMA_SOLVE)) ? 2 : 1);
           int rc;
           if (nact < SP_NB) {

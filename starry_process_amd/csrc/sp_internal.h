@@ -88,7 +88,8 @@ struct sp_handle {
 // (cheap enough for a timed region: 2 pairs per K = 1000 factorisation)
 enum {
   SP_PROF_SYRK = 0, SP_PROF_STRIP = 1, SP_PROF_CHAIN = 2, SP_PROF_ASSEMBLE = 3, SP_PROF_PANELS = 4,
-  SP_PROF_NKINDS = 5
+  SP_PROF_PANEL_LAUNCH = 5,   // every one-launch-per-panel kernel under its own pair (comparable with rocprofv3's durations)
+  SP_PROF_NKINDS = 6
 };
 
 // brackets the launches issued during its lifetime with a pair of events on `st`

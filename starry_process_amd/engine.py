@@ -251,7 +251,7 @@ class Engine(object):
         self._moments_owner = None
         check(self._L.sp_set_ylm_moments_dev(self._h, self._p(mean_ylm), self._p(cov_ylm), self._stream()))
 
-    PROF_KINDS = {"syrk": 0, "strip": 1, "chain": 2, "assemble": 3, "panels": 4}
+    PROF_KINDS = {"syrk": 0, "strip": 1, "chain": 2, "assemble": 3, "panels": 4, "panel_launch": 5}
 
     def profile_begin(self, max_launches, kinds=("syrk",)):
         """Bracket the factorisation's launches of the given kinds with HIP events on their stream
