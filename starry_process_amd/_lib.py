@@ -93,6 +93,7 @@ PROTOTYPES = {
     "sp_debug_panel_trace": (_I, [_V]),
     "sp_profile_kind": (_I, [_V, _I, ctypes.POINTER(ctypes.c_long), c_double_p, c_double_p]),
     "sp_set_chol_mode": (_I, [_V, _I]),
+    "sp_set_lazy_cov": (_I, [_V, _I]),
     "sp_set_defer_norm": (_I, [_V, _I]),
     "sp_profile_begin_kinds": (_I, [_V, _I, ctypes.c_uint]),
     "sp_profile_begin": (_I, [_V, _I]),

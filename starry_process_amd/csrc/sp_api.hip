@@ -9,6 +9,7 @@
 #include <new>
 
 #include "sp_internal.h"
+#include "sp_cov.h"
 
 // launchers defined in the other translation units
 int sp_launch_kernel_table(sp_handle *h, const double *rta1_dev, int ntab,
@@ -16,7 +17,8 @@ int sp_launch_kernel_table(sp_handle *h, const double *rta1_dev, int ntab,
                            double *meanvar_dev, hipStream_t st);
 int sp_launch_theta(int S, int K, const double *t, const sp_star *stars,
                     double *theta, hipStream_t st, int32_t *info = nullptr,
-                    uint32_t *status = nullptr);
+                    uint32_t *status = nullptr, const double *tab = nullptr, int covpts = 0,
+                    double *ptab = nullptr);
 int sp_launch_spline_index(int K, const double *theta, double dx, long long *out,
                            hipStream_t st);
 int sp_launch_rowsum(int S, int K, const double *theta, const double *t,
@@ -33,7 +35,8 @@ int sp_launch_assemble(int S, int K, int M, int Kp, int system,
                        const double *xp, int temporal, const double *raw,
                        int normalized, const double *qv, const void *coef,
                        const double *diag, int add_noise, const double *flux,
-                       double *out, long ldo, long strideo, hipStream_t st, double *part = nullptr);
+                       double *out, long ldo, long strideo, hipStream_t st, double *part = nullptr,
+                       int lazy_nfull = 0);
 int sp_launch_defer_finish(int S, int K, int M, int Kp, const sp_star *stars, const double *meanvar,
                            const double *condmean, int order, double zmax, const double *part,
                            const double *diag, double *sys, void *coef, uint32_t *status,
@@ -313,7 +316,7 @@ int lnlike_assemble(sp_handle *h, const Layout &L, void *ws, int K, int M, const
                     const double *flux_dev, const double *diag_dev, const sp_star *stars_dev,
                     int conditional, int covpts, const double *tab_dev,
                     const double *meanvar_dev, const double *rta1_dev, int temporal,
-                    int normalized, int norm_order, double zmax, hipStream_t st) {
+                    int normalized, int norm_order, double zmax, hipStream_t st, int lazy_nfull = 0) {
   const int S = L.S;
   double *theta = at<double>(ws, L.theta), *rowsum = at<double>(ws, L.rowsum);
   double *qv = at<double>(ws, L.qv), *coef = at<double>(ws, L.coef);
@@ -322,7 +325,11 @@ int lnlike_assemble(sp_handle *h, const Layout &L, void *ws, int K, int M, const
   int32_t *info = at<int32_t>(ws, L.info);
   uint32_t *status = at<uint32_t>(ws, L.status);
   int rc;
-  if ((rc = sp_launch_theta(S, K, t_dev, stars_dev, theta, st, info, status))) return rc;
+  // (tiles formed at first touch: the stars' tables packed for the gathers, in the design-matrix
+  //  region the marginal path does not use)
+  if ((rc = sp_launch_theta(S, K, t_dev, stars_dev, theta, st, info, status, tab_dev, covpts,
+                            lazy_nfull > 0 ? at<double>(ws, L.A) : nullptr)))
+    return rc;
   const double *rawp = nullptr;
   const double *condmean = nullptr;
   if (conditional) {
@@ -339,7 +346,7 @@ int lnlike_assemble(sp_handle *h, const Layout &L, void *ws, int K, int M, const
     double *part = at<double>(ws, L.part);
     if ((rc = sp_launch_assemble(S, K, M, L.Kp, 1, theta, t_dev, stars_dev, cp, tab_dev, meanvar_dev,
                                  h->d_xp, temporal, rawp, 1, qv, coef, diag_dev, 1, flux_dev, sys,
-                                 L.Kp, (long)L.Kp * L.Kp, st, part)))
+                                 L.Kp, (long)L.Kp * L.Kp, st, part, lazy_nfull)))
       return rc;
     return sp_launch_defer_finish(S, K, M, L.Kp, stars_dev, meanvar_dev, condmean, norm_order, zmax,
                                   part, diag_dev, sys, coef, status, rowsum, st);
@@ -429,6 +436,7 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
   h->chol_mode = 0;
   h->rec_base = SP_REC_BASE_DEFAULT;
   h->defer_norm = 1;
+  h->lazy_cov = 1;
   const int N = h->N;
   h->l_of.resize(N);
   h->m_of.resize(N);
@@ -475,6 +483,8 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
     h->groups = e3 ? atoi(e3) : 1;
     const char *e10 = getenv("SP_DEFER_NORM");
     h->defer_norm = e10 ? atoi(e10) : 1;
+    const char *e11 = getenv("SP_LAZY_COV");
+    h->lazy_cov = e11 ? atoi(e11) : 1;
     const char *e9 = getenv("SP_REC_BASE");
     h->rec_base = e9 ? atoi(e9) : SP_REC_BASE_DEFAULT;
     if (h->rec_base < 1) h->rec_base = 1;
@@ -672,6 +682,13 @@ int sp_profile_kind(sp_handle *h, int kind, long *launches, double *total_ms, do
 
 int sp_profile_end(sp_handle *h, long *launches, double *total_ms, double *flops) {
   return sp_profile_kind(h, SP_PROF_SYRK, launches, total_ms, flops);
+}
+
+int sp_set_lazy_cov(sp_handle *h, int on) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h) return SP_ERR_INVALID;
+  h->lazy_cov = on ? 1 : 0;
+  return SP_OK;
 }
 
 int sp_set_defer_norm(sp_handle *h, int on) {
@@ -1003,7 +1020,18 @@ int sp_lnlike_ensemble(sp_handle *h, int S, int K, int M, const double *t_dev,
     hipStream_t sg = g == 0 ? st : h->gstream[g - 1];
     if (g > 0) SP_HIP(hipStreamWaitEvent(sg, h->gfork, 0));
     CG[g] = sp_chol_group{at<double>(ws, LG[g].sys), at<int32_t>(ws, LG[g].info),
-                          at<double>(ws, LG[g].invL), s1 - s0, sg};
+                          at<double>(ws, LG[g].invL), s1 - s0, sg, LazyCov{}};
+  }
+  // Tiles formed at first touch (LazyCov, sp_cov.h): the marginal path under the deferred
+  // normalisation, factored by the one-launch-per-panel super-panel driver -- the configuration
+  // of handles that work several evaluations at a time.
+  int lazy_nfull = 0;
+  if (h->lazy_cov && !conditional && normalized && h->defer_norm && G == 1 && h->chol_mode == 0 &&
+      h->onelaunch && h->fuse_diag > 1 && h->eager && K / SP_NB >= 2 &&
+      (size_t)K * L.N >= 4 * (size_t)(covpts + 4)) {
+    lazy_nfull = K / SP_NB;
+    CG[0].lazy = LazyCov{at<double>(ws, L.theta), t_dev, stars_dev, at<double>(ws, L.A), K, covpts,
+                         temporal, lazy_nfull, 0, 0};
   }
   for (int g = 0; g < G; ++g) {
     const int s0 = first[g];
@@ -1011,7 +1039,7 @@ int sp_lnlike_ensemble(sp_handle *h, int S, int K, int M, const double *t_dev,
                              flux_dev + (size_t)s0 * M * K,
                              diag_dev ? diag_dev + (size_t)s0 * K : nullptr, stars_dev + s0,
                              conditional, covpts, tab_dev, meanvar_dev, rta1_dev, temporal,
-                             normalized, norm_order, zmax, CG[g].st);
+                             normalized, norm_order, zmax, CG[g].st, lazy_nfull);
     if (rc) return rc;
   }
   {

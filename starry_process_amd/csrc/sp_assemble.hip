@@ -16,13 +16,9 @@
 // Compiled with -ffp-contract=off: the int64 interpolation index
 // floor(x / dx) must agree bit for bit with the reference (flux.py:262-265).
 #include "sp_internal.h"
+#include "sp_cov.h"
 
 namespace {
-
-// valid cadences of a star: sp_star.nobs when 0 < nobs < K (ragged ensembles), else K
-__device__ __forceinline__ int star_nobs(const sp_star &st, int K) {
-  return (st.nobs > 0 && st.nobs < K) ? st.nobs : K;
-}
 
 struct Coef {   // per-star normalisation coefficients, 8 doubles
   double c1;    // alpha / mu^2          (1 when not normalised)
@@ -35,64 +31,21 @@ struct Coef {   // per-star normalisation coefficients, 8 doubles
   double pad;
 };
 
-__device__ __forceinline__ double temporal_factor(int kind, double ti, double tj,
-                                                  double tau) {
-  if (kind == SP_TEMPORAL_NONE) return 1.0;
-  const double dt = fabs(ti - tj);
-  if (kind == SP_TEMPORAL_MATERN32) {
-    const double x = 1.7320508075688772 * dt / tau;  // np.sqrt(3) * dt / tau
-    return (1.0 + x) * exp(-x);
-  }
-  return exp(-(dt * dt) / (2.0 * tau));
-}
-
-// spline lookup (flux.py:262-272)
-//
-// The segment index is integer work and must equal floor(fl(x / dx)) bit for
-// bit.  An IEEE fp64 division costs ~12 dependent instructions, so the index is
-// first taken from the product q = x * (1/dx) (within 2 ulp of the quotient)
-// and the exact division is only evaluated when q lies within 1e-9 of an
-// integer, the only case in which the two floors can differ.
-typedef double dd2 __attribute__((ext_vector_type(2)));
-
-struct SplineGen {
-  const double *tab;   // LDS: {a0, a1} per segment (16 B each), then {a2, a3} per segment at
-                       // tab + 2 np.  Two arrays of 16-byte entries rather than one of 32:
-                       // neighbouring lanes look up neighbouring segments, and 16-byte entries put
-                       // 16 consecutive segments on 16 different bank groups (32-byte ones: 8),
-                       // which halves the bank conflicts of these gathers (they were 61 % of the
-                       // LDS-busy cycles of the row sums, and the LDS was busy 65 % of the time)
-  int np2;             // 2 np
-  double dx, inv_dx;
-  int covpts;
-  __device__ __forceinline__ double operator()(double thi, double thj) const {
-    const double x = fabs(thi - thj);
-    const double q = x * inv_dx;
-    // 0 <= x <= 2 pi, so the int64 index of the reference fits 32 bits (one v_cvt_i32_f64)
-    int idx = (int)q;
-    // x0 = (x - xp[idx + 1]) / dx with xp[k] = (k - 1) dx (flux.py:312-314): q - idx, equal to
-    // 3e-14 absolute on [0, 1) and one LDS read shorter.  It also tells how close q is to an
-    // integer: within 1e-9 of one the exact quotient decides the index.
-    double x0 = q - (double)idx;
-    if (fabs(x0 - 0.5) > 0.5 - 1.0e-9) {
-      idx = (int)floor(x / dx);
-      x0 = q - (double)idx;
-    }
-    idx = idx < 0 ? 0 : (idx > covpts ? covpts : idx);
-    // two 16-byte LDS reads fetch the four coefficients of the segment
-    const dd2 c01 = *reinterpret_cast<const dd2 *>(tab + 2 * idx);
-    const dd2 c23 = *reinterpret_cast<const dd2 *>(tab + np2 + 2 * idx);
-    // a0 + a1 x0 + a2 x0^2 + a3 x0^3 in Horner form (the value, unlike the index, only has
-    // to agree to rounding: fused multiply-adds)
-    return __builtin_fma(x0, __builtin_fma(x0, __builtin_fma(x0, c23.y, c23.x), c01.y), c01.x);
-  }
-};
-
 __global__ __launch_bounds__(256) void theta_kernel(
     int K, const double *__restrict__ t, const sp_star *__restrict__ stars,
-    double *__restrict__ theta, int32_t *__restrict__ info, uint32_t *__restrict__ status) {
+    double *__restrict__ theta, int32_t *__restrict__ info, uint32_t *__restrict__ status,
+    const double *__restrict__ tab, int np, double *__restrict__ ptab) {
   const int s = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ptab && blockIdx.x == 0) {
+    // the star's table in the layout SplineGen reads (load_tables below), for the kernels that
+    // form covariance tiles at first touch (LazyCov, sp_cov.h)
+    const double *src = tab + (size_t)stars[s].table * 5 * np;
+    for (int e = threadIdx.x; e < 4 * np; e += 256) {
+      const int half = e >= 2 * np, f = half ? e - 2 * np : e;
+      ptab[(size_t)s * 4 * np + e] = src[(1 + 2 * half + (f & 1)) * np + (f >> 1)];
+    }
+  }
   if (i == 0) {  // first kernel of a likelihood call: also clears the per-star flags
     if (info) info[s] = 0;
     if (status) status[s] = 0u;
@@ -250,7 +203,8 @@ __global__ __launch_bounds__(256) void assemble_kernel(
     const double *__restrict__ xp, int temporal, const double *__restrict__ raw,
     int normalized, const double *__restrict__ qv, const Coef *__restrict__ coef,
     const double *__restrict__ diag, int add_noise, const double *__restrict__ flux,
-    double *__restrict__ out, long ldo, long strideo, int ntr, double *__restrict__ part) {
+    double *__restrict__ out, long ldo, long strideo, int ntr, double *__restrict__ part,
+    int lazy_nfull) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int s = blockIdx.y, np = covpts + 4;
   const sp_star st = stars[s];
@@ -352,6 +306,8 @@ __global__ __launch_bounds__(256) void assemble_kernel(
       if ((threadIdx.x & 15) == 0 && i < K) part[((size_t)s * ntr + tj) * K + i] = rsum;
       if (i >= lim) continue;
     }
+    // (tiles the factorisation forms itself at first touch: sums taken above, nothing written)
+    if (DEFER && ti > tj && ti < lazy_nfull) continue;
     double *dst = ob + (size_t)i * ldo + j0 + cj;
     if (j0 + cj + 3 < lim && (((size_t)dst) & 15) == 0) {
       *reinterpret_cast<dd2 *>(dst) = dd2{v[0], v[1]};
@@ -468,9 +424,10 @@ static void allow_big_lds(F f) {
 }
 
 int sp_launch_theta(int S, int K, const double *t, const sp_star *stars,
-                    double *theta, hipStream_t st, int32_t *info, uint32_t *status) {
+                    double *theta, hipStream_t st, int32_t *info, uint32_t *status,
+                    const double *tab, int covpts, double *ptab) {
   hipLaunchKernelGGL(theta_kernel, dim3((K + 255) / 256, S), dim3(256), 0, st, K,
-                     t, stars, theta, info, status);
+                     t, stars, theta, info, status, tab, covpts + 4, ptab);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }
@@ -527,7 +484,8 @@ int sp_launch_assemble(int S, int K, int M, int Kp, int system,
                        const double *xp, int temporal, const double *raw,
                        int normalized, const double *qv, const void *coef,
                        const double *diag, int add_noise, const double *flux,
-                       double *out, long ldo, long strideo, hipStream_t st, double *part) {
+                       double *out, long ldo, long strideo, hipStream_t st, double *part,
+                       int lazy_nfull) {
   const int np = covpts + 4;
   const size_t lds = sizeof(double) * ((raw ? 0 : 4 * (size_t)np) + 6 * 64 + (part ? 16 * 64 : 0));
   if (lds > attr_lds_limit) return SP_ERR_INVALID;
@@ -540,7 +498,7 @@ int sp_launch_assemble(int S, int K, int M, int Kp, int system,
     hipLaunchKernelGGL((assemble_kernel<FM, SY, ##__VA_ARGS__>), grid, dim3(256), lds, st, K, \
                        M, Kp, theta, t, stars, covpts, tab, meanvar, xp,                   \
                        temporal, raw, normalized, qv, (const Coef *)coef, diag,            \
-                       add_noise, flux, out, ldo, strideo, ntr, part);                     \
+                       add_noise, flux, out, ldo, strideo, ntr, part, lazy_nfull);         \
   } while (0)
   if (part && !system) return SP_ERR_INVALID;
   if (part && raw)

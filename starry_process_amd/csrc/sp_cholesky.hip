@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, double *sink,
 static int bulk_update(sp_handle *h, double *sys, long ld, long stride, int S, int c0,
                        int cfrom, int rend, int kd, hipStream_t st, long lts, int fuse_nact = 0,
                        double *invL = nullptr, int32_t *info = nullptr, int skip00 = 0,
-                       int skip_tile00 = 0) {
+                       int skip_tile00 = 0, const LazyCov *lazy = nullptr) {
   // fuse_nact > 0: tile (0, 0) is the diagonal block of the next panel and its
   // workgroup factors it on the spot (hidden behind the other tiles)
   const int n = rend - cfrom;
@@ -538,7 +538,7 @@ static int bulk_update(sp_handle *h, double *sys, long ld, long stride, int S, i
              ? sp_launch_gemm_nt_diag(X, ld, stride, X, ld, stride, T, ld, stride, n, n, kd,
                                       -1.0, 1, S, fuse_nact, invL, lts, info, st, skip00)
              : sp_launch_gemm_nt(X, ld, stride, X, ld, stride, T, ld, stride, n, n, kd, -1.0,
-                                 1, 1, S, st, skip_tile00);
+                                 1, 1, S, st, skip_tile00, lazy);
 }
 
 // rows r1..rend-1 of panel column c0: X = P L_d^-T in place (LT = diag_block's output)
@@ -816,6 +816,13 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
           const double *lt_in = G.invL + (size_t)(j & 1) * 2 * SP_LT_IMG;
           double *lt_out = G.invL + (size_t)((j + 1) & 1) * 2 * SP_LT_IMG;
           const double rows = Kp - r1;
+          // first super-panel of a system whose assembly left the tiles below the diagonal to
+          // their first touch (sp_cov.h): this launch's rows start at row tile j + 1 of block
+          // column j (partial blocks: the tiles beyond them hold residual rows -- from memory)
+          LazyCov lzv = G.lazy;
+          lzv.tr0 = j + 1;
+          lzv.tc0 = j;
+          const LazyCov *lzp = (G.lazy.theta && s0 == 0) ? &lzv : nullptr;
           // left-looking product + substitution + eager rank-64 updates + the next diagonal block
           const double fl = (double)G.S * (2.0 * rows * 64 * (q * 64.0) + rows * 64 * 64 +
                                            neager * 64.0 * 64 * 64 + 64.0 * 64 * 64 / 3);
@@ -836,11 +843,11 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
             if (rc != SP_OK) return rc;
             rc = sp_launch_panel(G.sys + (size_t)c1 * ld + cS, ld, G.sys + (size_t)c0 * ld + cS, ld,
                                  G.sys + (size_t)c1 * ld + c0, ld, stride, Kp - c1, q * SP_NB, G.S,
-                                 lt_in, lt_out, lts, 0, 0, G.info, G.st);
+                                 lt_in, lt_out, lts, 0, 0, G.info, G.st, lzp);
           } else {
             rc = sp_launch_panel(G.sys + (size_t)r1 * ld + cS, ld, G.sys + (size_t)c0 * ld + cS, ld,
                                  G.sys + (size_t)r1 * ld + c0, ld, stride, Kp - r1, q * SP_NB, G.S,
-                                 lt_in, lt_out, lts, neager, next_nact, G.info, G.st);
+                                 lt_in, lt_out, lts, neager, next_nact, G.info, G.st, lzp);
           }
           if (rc != SP_OK) return rc;
         }
@@ -850,8 +857,10 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
       if (cE < K) {
         for (int g = 0; g < ngroups; ++g) {
           const sp_chol_group &G = grp[g];
+          LazyCov lzv = G.lazy;
+          lzv.tr0 = lzv.tc0 = cE / SP_NB;
           int rc = bulk_update(h, G.sys, ld, stride, G.S, cS, cE, Kp, w * SP_NB, G.st, lts, 0,
-                               nullptr, nullptr, 0, 1);
+                               nullptr, nullptr, 0, 1, (G.lazy.theta && s0 == 0) ? &lzv : nullptr);
           if (rc != SP_OK) return rc;
         }
       }

@@ -1,0 +1,116 @@
+// Covariance entries of the marginal path, shared by the assembly (sp_assemble.hip) and by the
+// kernels of the factorisation that form tiles at their first touch instead of reading them
+// (LazyCov below; sp_gemm.hip): phase-lag spline lookup (flux.py:262-272), temporal kernels
+// (temporal.py:8-16), valid-cadence masks.
+#ifndef SP_COV_H
+#define SP_COV_H
+
+#include "sp_internal.h"
+
+// valid cadences of a star: sp_star.nobs when 0 < nobs < K (ragged ensembles), else K
+__device__ __forceinline__ int star_nobs(const sp_star &st, int K) {
+  return (st.nobs > 0 && st.nobs < K) ? st.nobs : K;
+}
+
+__device__ __forceinline__ double temporal_factor(int kind, double ti, double tj,
+                                                  double tau) {
+#pragma clang fp contract(off)
+  if (kind == SP_TEMPORAL_NONE) return 1.0;
+  const double dt = fabs(ti - tj);
+  if (kind == SP_TEMPORAL_MATERN32) {
+    const double x = 1.7320508075688772 * dt / tau;  // np.sqrt(3) * dt / tau
+    return (1.0 + x) * exp(-x);
+  }
+  return exp(-(dt * dt) / (2.0 * tau));
+}
+
+// spline lookup (flux.py:262-272)
+//
+// The segment index is integer work and must equal floor(fl(x / dx)) bit for
+// bit.  An IEEE fp64 division costs ~12 dependent instructions, so the index is
+// first taken from the product q = x * (1/dx) (within 2 ulp of the quotient)
+// and the exact division is only evaluated when q lies within 1e-9 of an
+// integer, the only case in which the two floors can differ.
+typedef double dd2 __attribute__((ext_vector_type(2)));
+
+struct SplineGen {
+  const double *tab;   // LDS: {a0, a1} per segment (16 B each), then {a2, a3} per segment at
+                       // tab + 2 np.  Two arrays of 16-byte entries rather than one of 32:
+                       // neighbouring lanes look up neighbouring segments, and 16-byte entries put
+                       // 16 consecutive segments on 16 different bank groups (32-byte ones: 8),
+                       // which halves the bank conflicts of these gathers (they were 61 % of the
+                       // LDS-busy cycles of the row sums, and the LDS was busy 65 % of the time)
+  int np2;             // 2 np
+  double dx, inv_dx;
+  int covpts;
+  __device__ __forceinline__ double operator()(double thi, double thj) const {
+    // (no contraction whatever the translation unit's default: the index must be the reference's,
+    //  and a tile formed at first touch must carry the bits the assembly would have written)
+#pragma clang fp contract(off)
+    const double x = fabs(thi - thj);
+    const double q = x * inv_dx;
+    // 0 <= x <= 2 pi, so the int64 index of the reference fits 32 bits (one v_cvt_i32_f64)
+    int idx = (int)q;
+    // x0 = (x - xp[idx + 1]) / dx with xp[k] = (k - 1) dx (flux.py:312-314): q - idx, equal to
+    // 3e-14 absolute on [0, 1) and one LDS read shorter.  It also tells how close q is to an
+    // integer: within 1e-9 of one the exact quotient decides the index.
+    double x0 = q - (double)idx;
+    if (fabs(x0 - 0.5) > 0.5 - 1.0e-9) {
+      idx = (int)floor(x / dx);
+      x0 = q - (double)idx;
+    }
+    idx = idx < 0 ? 0 : (idx > covpts ? covpts : idx);
+    // two 16-byte LDS reads fetch the four coefficients of the segment
+    const dd2 c01 = *reinterpret_cast<const dd2 *>(tab + 2 * idx);
+    const dd2 c23 = *reinterpret_cast<const dd2 *>(tab + np2 + 2 * idx);
+    // a0 + a1 x0 + a2 x0^2 + a3 x0^3 in Horner form (the value, unlike the index, only has
+    // to agree to rounding: fused multiply-adds)
+    return __builtin_fma(x0, __builtin_fma(x0, __builtin_fma(x0, c23.y, c23.x), c01.y), c01.x);
+  }
+};
+
+
+// ---- tiles formed at first touch ---------------------------------------------------------------
+// In the deferred-normalisation marginal path a tile of the system strictly below the diagonal whose
+// rows are all covariance rows is a pure function of (phase_i, phase_j[, t_i, t_j]) until the
+// factorisation first touches it.  With `LazyCov` the assembly does not write those tiles (it
+// still takes their row / column sums) and the kernel that touches a tile first -- the panel
+// kernel for the block columns of the first super-panel, the first trailing update for the rest --
+// evaluates its entries instead of loading them: the same spline code, the coefficients gathered
+// from a packed copy of the star's table in memory (L1 / L2), hence the same bits.  One write and
+// one read of 3/4 of the matrix less per factorisation.
+
+// the 16 entries of a lane of the 4 x (16 x 64) wavefront split: rows ri[r], columns cj[n]
+// (absolute indices in the star's system), accumulator layout out[n][r]
+template <typename V4>
+__device__ __forceinline__ void lazy_cov_tile(const LazyCov &z, int star, const int (&ri)[4],
+                                              const int (&cj)[4], V4 (&out)[4]) {
+  const sp_star st = z.stars[star];
+  const int nobs = star_nobs(st, z.K), np = z.covpts + 4;
+  const double *th = z.theta + (size_t)star * z.K, *tt = z.t + (size_t)star * z.K;
+  const bool tk = z.temporal != SP_TEMPORAL_NONE;
+  double thi[4], thj[4], ti[4], tj[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool oi = ri[k] < nobs, oj = cj[k] < nobs;
+    thi[k] = oi ? th[ri[k]] : 0.0;
+    thj[k] = oj ? th[cj[k]] : 0.0;
+    ti[k] = (oi && tk) ? tt[ri[k]] : 0.0;
+    tj[k] = (oj && tk) ? tt[cj[k]] : 0.0;
+  }
+  SplineGen g{z.ptab + (size_t)star * 4 * np, 2 * np, 6.283185307179586 / z.covpts,
+              1.0 / (6.283185307179586 / z.covpts), z.covpts};
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double v = 0.0;
+      if (ri[r] < nobs && cj[n] < nobs) {
+#pragma clang fp contract(off)
+        v = g(thi[r], thj[n]) * temporal_factor(z.temporal, ti[r], tj[n], st.tau);
+      }
+      out[n][r] = v;
+    }
+}
+
+#endif

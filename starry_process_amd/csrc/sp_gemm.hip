@@ -21,6 +21,7 @@
 
 #include "sp_internal.h"
 #include "sp_tile.h"
+#include "sp_cov.h"
 #include "sp_mm.h"
 #include "sp_wt.h"
 
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256, (FUSE == 2 && SP_PANEL_WGS > 0) ? SP_PANEL_WGS
     const double *__restrict__ B, long ldb, long strideB, double *C,
     long ldc, long strideC, int Mrows, int Nrows, int Kd, double alpha,
     int beta, int lower_only, int batch, int ntm, int ntn, int ntiles, int nact,
-    double *invL_all, int32_t *info, int skip00, const double *lt_in, long lts) {
+    double *invL_all, int32_t *info, int skip00, const double *lt_in, long lts, LazyCov lz) {
   // Padded LDS row of BK + 1 doubles.  hipcc fuses the per-k-step fragment reads
   // into ds_read2_b64, which is banked mod 32 dwords in 16-lane groups: an ODD
   // row length puts the 16 rows of a group on 16 distinct bank pairs.  (An even
@@ -183,13 +184,26 @@ __global__ __launch_bounds__(256, (FUSE == 2 && SP_PANEL_WGS > 0) ? SP_PANEL_WGS
   }
   const bool full = FAST || (row0 + GT <= Mrows && col0 + GT <= Nrows);
   if (beta && ABL != 4) {
+    // (one launch per panel, first super-panel: a tile below the diagonal made of covariance rows
+    //  has not been written by the assembly -- its entries are evaluated here, sp_cov.h)
+    const bool lazy = FUSE == 2 && lz.theta && lz.tr0 + ti > lz.tc0 + tj && lz.tr0 + ti < lz.nfull;
+    if (lazy) {
+      int ri[4], cj[4];
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int gi = row0 + 16 * wave + fk + 4 * r, gj = col0 + 16 * n + fr;
-        if (full || (gi < Mrows && gj < Nrows)) cin[n][r] = Cb[(size_t)gi * ldc + gj];
+      for (int k = 0; k < 4; ++k) {
+        ri[k] = GT * (lz.tr0 + ti) + 16 * wave + fk + 4 * k;
+        cj[k] = GT * (lz.tc0 + tj) + 16 * k + fr;
       }
+      lazy_cov_tile(lz, mtx, ri, cj, cin);
+    } else {
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gi = row0 + 16 * wave + fk + 4 * r, gj = col0 + 16 * n + fr;
+          if (full || (gi < Mrows && gj < Nrows)) cin[n][r] = Cb[(size_t)gi * ldc + gj];
+        }
+    }
     if (!DEFER_C) {
 #pragma unroll
       for (int n = 0; n < 4; ++n) acc[n] = cin[n];
@@ -557,7 +571,7 @@ template <class Core, bool SGN>
 __global__ __launch_bounds__(256) void mm_nt_kernel(
     const double *__restrict__ A, long lda, long strideA, const double *__restrict__ B, long ldb,
     long strideB, double *__restrict__ C, long ldc, long strideC, int Kd, double alpha, int beta,
-    int lower_only, int batch, int ntn, int ntiles, int skip00) {
+    int lower_only, int batch, int ntn, int ntiles, int skip00, LazyCov lz) {
   constexpr int TM = Core::TM_, TN = Core::TN_;
   __shared__ __attribute__((aligned(16))) double lds[Core::LDS_DOUBLES];
   int mtx, tile;
@@ -580,12 +594,28 @@ __global__ __launch_bounds__(256) void mm_nt_kernel(
   mm.init(Ab, lda, Bb, ldb);
   mm_d4 acc[Core::MA][Core::NA], cin[SGN ? 1 : Core::MA][SGN ? 1 : Core::NA];
   mm.prologue(lds, 0, Kd);   // the first slices are on their way while the C tile is fetched
+  // (first trailing update of a factorisation whose assembly left the tiles below the diagonal
+  //  to their first touch: a tile of covariance rows is evaluated, not loaded -- sp_cov.h)
+  constexpr bool CAN_LAZY = Core::MA == 1 && Core::NA == 4 && TM == 64 && TN == 64;
+  const bool lazy = CAN_LAZY && beta && lz.theta && lz.tr0 + ti > lz.tc0 + tj && lz.tr0 + ti < lz.nfull;
+  mm_d4 cz[4];
+  if (lazy) {
+    int ri[4], cj[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ri[k] = 64 * (lz.tr0 + ti) + mm.acc_row(0, k);
+      cj[k] = 64 * (lz.tc0 + tj) + mm.acc_col(k < Core::NA ? k : 0);
+    }
+    lazy_cov_tile(lz, mtx, ri, cj, cz);
+  }
 #pragma unroll
   for (int m = 0; m < Core::MA; ++m)
 #pragma unroll
     for (int n = 0; n < Core::NA; ++n) {
       mm_d4 c = mm_d4{0.0, 0.0, 0.0, 0.0};
-      if (beta) {
+      if (lazy) {
+        c = cz[n & 3];
+      } else if (beta) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) c[r] = Cb[(size_t)mm.acc_row(m, r) * ldc + mm.acc_col(n)];
       }
@@ -719,7 +749,8 @@ static int wt_launch(const double *A, long lda, long strideA, const double *B, l
 template <class Core>
 int mm_launch(const double *A, long lda, long strideA, const double *B, long ldb, long strideB,
               double *C, long ldc, long strideC, int Mrows, int Nrows, int Kd, double alpha, int beta,
-              int lower_only, int batch, hipStream_t st, int skip00) {
+              int lower_only, int batch, hipStream_t st, int skip00, const LazyCov *lazy = nullptr) {
+  const LazyCov lz = lazy ? *lazy : LazyCov{};
   const int ntm = Mrows / Core::TM_, ntn = Nrows / Core::TN_;
   const int ntiles = lower_only ? ntm * (ntm + 1) / 2 : ntm * ntn;
   const long nblk = sp_xcd_grid(batch, ntiles);
@@ -727,11 +758,11 @@ int mm_launch(const double *A, long lda, long strideA, const double *B, long ldb
   if (alpha == 1.0 || alpha == -1.0)
     hipLaunchKernelGGL((mm_nt_kernel<Core, true>), dim3((unsigned)nblk), dim3(256), 0, st,
                        A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Kd, alpha, beta, lower_only,
-                       batch, ntn, ntiles, skip00);
+                       batch, ntn, ntiles, skip00, lz);
   else
     hipLaunchKernelGGL((mm_nt_kernel<Core, false>), dim3((unsigned)nblk), dim3(256), 0, st,
                        A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Kd, alpha, beta, lower_only,
-                       batch, ntn, ntiles, skip00);
+                       batch, ntn, ntiles, skip00, lz);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }
@@ -745,7 +776,8 @@ void sp_set_mm_variant(int v) { g_mm_variant = v; }
 static int launch_gemm(const double *A, long lda, long strideA, const double *B, long ldb,
                        long strideB, double *C, long ldc, long strideC, int Mrows, int Nrows,
                        int Kd, double alpha, int beta, int lower_only, int batch, int fuse,
-                       int nact, double *invL, long lts, int32_t *info, hipStream_t st, int skip00 = 0) {
+                       int nact, double *invL, long lts, int32_t *info, hipStream_t st, int skip00 = 0,
+                       const LazyCov *lazy = nullptr) {
   if (Mrows <= 0 || Nrows <= 0 || batch <= 0) return SP_OK;
   if (Kd < 0) return SP_ERR_INVALID;
   const int ntm = (Mrows + GT - 1) / GT, ntn = (Nrows + GT - 1) / GT;
@@ -764,11 +796,11 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
 #define SP_GO_FAST(FD)                                                                       \
   hipLaunchKernelGGL((gemm_nt_kernel<32, false, FD, 0, true>), dim3((unsigned)nblk), dim3(256), 0, \
                      st, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd,  \
-                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00, nullptr, lts)
+                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00, nullptr, lts, LazyCov{})
 #define SP_GO(BK, DC, FD)                                                              \
   hipLaunchKernelGGL((gemm_nt_kernel<BK, DC, FD>), dim3((unsigned)nblk), dim3(256), 0, st, \
                      A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd, \
-                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00, nullptr, lts)
+                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00, nullptr, lts, LazyCov{})
   static int abl = -1;
   if (abl < 0) {
     const char *e = getenv("SP_GEMM_ABL");
@@ -777,12 +809,18 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
 #define SP_GO_ABL(N)                                                                          \
   hipLaunchKernelGGL((gemm_nt_kernel<32, false, 0, N>), dim3((unsigned)nblk), dim3(256), 0, st, \
                      A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd,       \
-                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00, nullptr, lts)
+                     alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00, nullptr, lts, LazyCov{})
   if (g_mm_variant < 0) {
     const char *e = getenv("SP_MM");
     g_mm_variant = e ? atoi(e) : 11;
   }
   const int mmv = g_mm_variant;
+  if (lazy && lazy->theta) {
+    // tiles formed at first touch: only the 64 x 64 pipelined kernel knows how
+    if (!(fast && !fuse && (Kd % 16) == 0)) return SP_ERR_INVALID;
+    return mm_launch<MM2<64, 64, 8, 6, 4>>(A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows,
+                                           Kd, alpha, beta, lower_only, batch, st, skip00, lazy);
+  }
   if (fast && !fuse && abl == 0 && mmv > 0) {
     // pipelined kernels (sp_mm.h); tile shape by SP_MM (tools/microbench.py compares them)
 #define SP_MM_GO(TM, TN, BK, NS, WR)                                                              \
@@ -828,7 +866,7 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
   } else if (fast && variant == 2 && (Kd % 64) == 0) {
     hipLaunchKernelGGL((gemm_nt_kernel<64, false, 0, 0, true>), dim3((unsigned)nblk), dim3(256), 0,
                        st, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd,
-                       alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00, nullptr, lts);
+                       alpha, beta, lower_only, batch, ntm, ntn, ntiles, nact, invL, info, skip00, nullptr, lts, LazyCov{});
   } else {
     switch (variant) {
       case 1: SP_GO(32, true, 0); break;
@@ -868,8 +906,10 @@ int sp_debug_panel_trace(long long *out) {
 
 int sp_launch_panel(const double *A, long lda, const double *B, long ldb, double *C, long ldc,
                     long stride, int Mrows, int Kd, int batch, const double *lt_in, double *lt_out,
-                    long lts, int neager, int next_nact, int32_t *info, hipStream_t st) {
+                    long lts, int neager, int next_nact, int32_t *info, hipStream_t st,
+                    const LazyCov *lazy) {
   if (Mrows <= 0 || batch <= 0) return SP_OK;
+  const LazyCov lz = lazy ? *lazy : LazyCov{};
   const int ntm = (Mrows + GT - 1) / GT, ntn = 1, ntiles = ntm;
   const long nblk = sp_xcd_grid(batch, ntiles);
   if (nblk > 0x7fffffffL) return SP_ERR_INVALID;
@@ -879,11 +919,11 @@ int sp_launch_panel(const double *A, long lda, const double *B, long ldb, double
   if (fast)
     hipLaunchKernelGGL((gemm_nt_kernel<32, false, 2, 0, true>), dim3((unsigned)nblk), dim3(256), 0,
                        st, A, lda, stride, B, ldb, stride, C, ldc, stride, Mrows, GT, Kd, -1.0, 1, 0,
-                       batch, ntm, ntn, ntiles, next_nact, lt_out, info, neager, lt_in, lts);
+                       batch, ntm, ntn, ntiles, next_nact, lt_out, info, neager, lt_in, lts, lz);
   else
     hipLaunchKernelGGL((gemm_nt_kernel<32, false, 2, 0, false>), dim3((unsigned)nblk), dim3(256), 0,
                        st, A, lda, stride, B, ldb, stride, C, ldc, stride, Mrows, GT, Kd, -1.0, 1, 0,
-                       batch, ntm, ntn, ntiles, next_nact, lt_out, info, neager, lt_in, lts);
+                       batch, ntm, ntn, ntiles, next_nact, lt_out, info, neager, lt_in, lts, lz);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }
@@ -891,9 +931,9 @@ int sp_launch_panel(const double *A, long lda, const double *B, long ldb, double
 int sp_launch_gemm_nt(const double *A, long lda, long strideA, const double *B, long ldb,
                       long strideB, double *C, long ldc, long strideC, int Mrows, int Nrows,
                       int Kd, double alpha, int beta, int lower_only, int batch,
-                      hipStream_t st, int skip_tile00) {
+                      hipStream_t st, int skip_tile00, const LazyCov *lazy) {
   return launch_gemm(A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd,
-                     alpha, beta, lower_only, batch, 0, 0, nullptr, 0, nullptr, st, skip_tile00);
+                     alpha, beta, lower_only, batch, 0, 0, nullptr, 0, nullptr, st, skip_tile00, lazy);
 }
 
 // Update (beta = 1) whose tile (0, 0) is the next diagonal block: that tile's

@@ -69,6 +69,7 @@ struct sp_handle {
   int chol_mode;                // 0: super-panel driver, 2: recursive driver (strip solves), 3: dataflow chain (SP_CHOL)
   int rec_base;                 // recursive driver: panels per base block
   int defer_norm;               // likelihood path: deferred normalisation (SP_DEFER_NORM, default 1)
+  int lazy_cov;                 // ... with covariance tiles formed at first touch where the driver can (SP_LAZY_COV, default 1)
   // dataflow panel chain (chol_mode 3, sp_chain.hip): flags, tickets and the abort word
   int *chain_mem;
   size_t chain_ints;
@@ -166,6 +167,17 @@ static inline int sp_nwig_of(int l) {
 }
 static inline int sp_roundup(int x, int m) { return ((x + m - 1) / m) * m; }
 
+// covariance tiles formed at first touch (sp_cov.h); theta == null: every tile comes from memory
+struct LazyCov {
+  const double *theta;     // [S][K] phases
+  const double *t;         // [S][K] cadence times (temporal kernels)
+  const sp_star *stars;
+  const double *ptab;      // [S][4 np]: the star's table as SplineGen reads it ({a0, a1} pairs, then {a2, a3})
+  int K, covpts, temporal;
+  int nfull;               // row tiles 0 .. nfull - 1 hold covariance rows only
+  int tr0, tc0;            // system tile coordinates of the launch's tile (0, 0)
+};
+
 // one group of stars factored on its own stream
 struct sp_chol_group {
   double *sys;
@@ -173,6 +185,7 @@ struct sp_chol_group {
   double *invL;      // S x sp_lt_stride(Kp) doubles
   int S;
   hipStream_t st;
+  LazyCov lazy;
 };
 
 // host-side constant builders (sp_host.cpp)
@@ -201,7 +214,8 @@ int sp_launch_polar_moments(sp_handle *h, const double *mu_src, const double *co
 //   Mrows, Nrows multiples of 64; Kd multiple of 4.
 int sp_launch_panel(const double *A, long lda, const double *B, long ldb, double *C, long ldc,
                     long stride, int Mrows, int Kd, int batch, const double *lt_in, double *lt_out,
-                    long lts, int neager, int next_nact, int32_t *info, hipStream_t st);
+                    long lts, int neager, int next_nact, int32_t *info, hipStream_t st,
+                    const LazyCov *lazy = nullptr);
 int sp_launch_tri_solve(const double *L, int K, long ldl, long strideL, double *B, long strideB,
                         long rs, long cs, int nrhs, int batch, int mode, hipStream_t st);
 int sp_launch_transpose(const double *in, long ldi, long stridei, double *out, int K, int batch,
@@ -212,7 +226,8 @@ int sp_launch_chol_rev_finish(const double *S, const double *L, long ldl, long s
 int sp_launch_gemm_nt(const double *A, long lda, long strideA, const double *B,
                       long ldb, long strideB, double *C, long ldc, long strideC,
                       int Mrows, int Nrows, int Kd, double alpha, int beta,
-                      int lower_only, int batch, hipStream_t st, int skip_tile00 = 0);
+                      int lower_only, int batch, hipStream_t st, int skip_tile00 = 0,
+                      const LazyCov *lazy = nullptr);
 
 void sp_set_mm_variant(int v);
 void sp_set_strip_flags(int f);  // ablations of the strip solve (sp_strip.hip)   // tile shape of the pipelined product (sp_gemm.hip)

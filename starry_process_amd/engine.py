@@ -363,6 +363,11 @@ class Engine(object):
         """0: super-panel driver (default), 2: recursive driver with strip solves, 3: dataflow panel chain."""
         check(self._L.sp_set_chol_mode(self._h, int(mode)))
 
+    def set_lazy_cov(self, on):
+        """Covariance tiles formed at first touch by the factorisation (default on; effective in the
+        one-launch-per-panel mode under the deferred normalisation)."""
+        check(self._L.sp_set_lazy_cov(self._h, int(bool(on))))
+
     def set_defer_norm(self, on):
         """True (default): normalised likelihoods assemble the raw covariance once and apply the
         normalisation's rank-2 part to the result; False: separate row-sum pass (sp_set_defer_norm).

@@ -148,6 +148,51 @@ def test_dataflow_chain_batch_sizes(engines, S):
     assert np.max(np.abs(a / ref - 1)) < TOL_DRIVERS
 
 
+@pytest.mark.parametrize("K,M,kw", [
+    (200, 1, {}), (127, 1, {}), (128, 1, {}), (129, 1, {}), (513, 1, {}), (960, 70, {}), (1000, 1, {}),
+    (1345, 1, {}), (1100, 5, {}), (1000, 1, dict(tau=2.5)), (1000, 1, dict(u=(0.4, 0.2))),
+])
+def test_tiles_formed_at_first_touch_are_the_assembled_ones(K, M, kw):
+    """sp_set_lazy_cov: in the one-launch-per-panel mode the assembly leaves the tiles below the
+    diagonal to the kernel that touches them first (same spline code, coefficients gathered from a
+    packed copy of the star's table): the log-likelihoods are IDENTICAL to those of the
+    materialised assembly -- sizes with partial blocks, residual rows in tiles of their own, a
+    temporal kernel, limb darkening."""
+    res = []
+    for lazy in (1, 0):
+        e = make_engine(15, 0, 1)
+        e.set_lazy_cov(lazy)
+        v, st = lnl(e, K, range(2, 8), M=M, **kw)
+        assert not st.any() and np.all(np.isfinite(v))
+        res.append(v)
+    assert np.array_equal(res[0], res[1])
+
+
+def test_first_touch_ragged_and_failures():
+    """Ragged light curves (entries beyond a star's cadences are zero, formed or assembled) and a
+    matrix that is not positive definite, with tiles formed at first touch."""
+    from starry_process_amd.engine import make_stars
+
+    res = []
+    for lazy in (1, 0):
+        e = make_engine(15, 0, 1)
+        e.set_lazy_cov(lazy)
+        K, S = 640, 6
+        sts = [synthetic_star(30 + s, K) for s in range(S)]
+        t = np.array([st["t"] for st in sts])
+        flux = np.array([st["flux"] for st in sts])[:, None, :]
+        dv = np.full(S, 1e-6)
+        dv[4] = -1.0
+        stars = make_stars(S, period=[st["p"] for st in sts], data_var=dv, nobs=[640, 639, 500, 130, 65, 3])
+        tab, mv = e.kernel_table(e.f64(e.rTA1L([0.0, 0.0])), 300)
+        out, status = e.lnlike_ensemble(e.f64(t), e.f64(flux), e.stars_to_device(stars), covpts=300, tab=tab,
+                                        meanvar=mv, normalized=True)
+        res.append((out.cpu().numpy(), status.cpu().numpy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert res[0][0][4] == -np.inf and (res[0][1][4] & 1)
+    assert np.all(np.isfinite(np.delete(res[0][0], 4)))
+
+
 def test_failure_semantics_every_driver(engines):
     """A covariance that is not positive definite gives -inf and the NOT_PD bit for THAT star only
     (math.py:82-91, sp.py:1186-1188), whichever driver factors it."""
