@@ -1028,7 +1028,7 @@ int sp_lnlike_ensemble(sp_handle *h, int S, int K, int M, const double *t_dev,
   int lazy_nfull = 0;
   if (h->lazy_cov && !conditional && normalized && h->defer_norm && G == 1 && h->chol_mode == 0 &&
       h->onelaunch && h->fuse_diag > 1 && h->eager && K / SP_NB >= 2 &&
-      (size_t)K * L.N >= 4 * (size_t)(covpts + 4)) {
+      (size_t)K * L.N >= 4 * (size_t)(covpts + 4) && 4 * (covpts + 4) <= SP_TILE_LDS_MIN) {
     lazy_nfull = K / SP_NB;
     CG[0].lazy = LazyCov{at<double>(ws, L.theta), t_dev, stars_dev, at<double>(ws, L.A), K, covpts,
                          temporal, lazy_nfull, 0, 0};

@@ -82,9 +82,13 @@ struct SplineGen {
 
 // the 16 entries of a lane of the 4 x (16 x 64) wavefront split: rows ri[r], columns cj[n]
 // (absolute indices in the star's system), accumulator layout out[n][r]
+// `stage`: LDS scratch of at least 4 (covpts + 4) doubles that the whole workgroup may use now: the
+// star's packed table is copied there first (one memory round trip, in parallel with the phases';
+// gathering the coefficients from memory instead made the entries wait for two round trips in a
+// row: +3 us per tile).  All 256 threads call this together; two barriers inside.
 template <typename V4>
 __device__ __forceinline__ void lazy_cov_tile(const LazyCov &z, int star, const int (&ri)[4],
-                                              const int (&cj)[4], V4 (&out)[4]) {
+                                              const int (&cj)[4], V4 (&out)[4], double *stage) {
   const sp_star st = z.stars[star];
   const int nobs = star_nobs(st, z.K), np = z.covpts + 4;
   const double *th = z.theta + (size_t)star * z.K, *tt = z.t + (size_t)star * z.K;
@@ -98,7 +102,13 @@ __device__ __forceinline__ void lazy_cov_tile(const LazyCov &z, int star, const 
     ti[k] = (oi && tk) ? tt[ri[k]] : 0.0;
     tj[k] = (oj && tk) ? tt[cj[k]] : 0.0;
   }
-  SplineGen g{z.ptab + (size_t)star * 4 * np, 2 * np, 6.283185307179586 / z.covpts,
+  {
+    const double *src = z.ptab + (size_t)star * 4 * np;
+    for (int e = 2 * threadIdx.x; e < 4 * np; e += 512)
+      *reinterpret_cast<dd2 *>(stage + e) = *reinterpret_cast<const dd2 *>(src + e);
+  }
+  __syncthreads();
+  SplineGen g{stage, 2 * np, 6.283185307179586 / z.covpts,
               1.0 / (6.283185307179586 / z.covpts), z.covpts};
 #pragma unroll
   for (int n = 0; n < 4; ++n)
@@ -111,6 +121,7 @@ __device__ __forceinline__ void lazy_cov_tile(const LazyCov &z, int star, const 
       }
       out[n][r] = v;
     }
+  __syncthreads();   // the scratch goes back to its owner
 }
 
 #endif

@@ -183,27 +183,17 @@ __global__ __launch_bounds__(256, (FUSE == 2 && SP_PANEL_WGS > 0) ? SP_PANEL_WGS
     cin[n] = d4{0.0, 0.0, 0.0, 0.0};
   }
   const bool full = FAST || (row0 + GT <= Mrows && col0 + GT <= Nrows);
-  if (beta && ABL != 4) {
-    // (one launch per panel, first super-panel: a tile below the diagonal made of covariance rows
-    //  has not been written by the assembly -- its entries are evaluated here, sp_cov.h)
-    const bool lazy = FUSE == 2 && lz.theta && lz.tr0 + ti > lz.tc0 + tj && lz.tr0 + ti < lz.nfull;
-    if (lazy) {
-      int ri[4], cj[4];
+  // (one launch per panel, first super-panel: a tile below the diagonal made of covariance rows
+  //  has not been written by the assembly -- its entries are evaluated below, sp_cov.h)
+  const bool lazy = FUSE == 2 && beta && lz.theta && lz.tr0 + ti > lz.tc0 + tj && lz.tr0 + ti < lz.nfull;
+  if (beta && ABL != 4 && !lazy) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        ri[k] = GT * (lz.tr0 + ti) + 16 * wave + fk + 4 * k;
-        cj[k] = GT * (lz.tc0 + tj) + 16 * k + fr;
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = row0 + 16 * wave + fk + 4 * r, gj = col0 + 16 * n + fr;
+        if (full || (gi < Mrows && gj < Nrows)) cin[n][r] = Cb[(size_t)gi * ldc + gj];
       }
-      lazy_cov_tile(lz, mtx, ri, cj, cin);
-    } else {
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int gi = row0 + 16 * wave + fk + 4 * r, gj = col0 + 16 * n + fr;
-          if (full || (gi < Mrows && gj < Nrows)) cin[n][r] = Cb[(size_t)gi * ldc + gj];
-        }
-    }
     if (!DEFER_C) {
 #pragma unroll
       for (int n = 0; n < 4; ++n) acc[n] = cin[n];
@@ -234,6 +224,21 @@ __global__ __launch_bounds__(256, (FUSE == 2 && SP_PANEL_WGS > 0) ? SP_PANEL_WGS
   } else {
 #pragma unroll
     for (int i = 0; i < (int)(sizeof(ra.v) / sizeof(ra.v[0])); ++i) ra.v[i] = rb.v[i] = d2{0.0, 0.0};
+  }
+  if (lazy) {
+    // the first operand slices are on their way to registers; the LDS is free until they are
+    // stored: the star's table passes through it and the tile is evaluated meanwhile
+    int ri[4], cj[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ri[k] = GT * (lz.tr0 + ti) + 16 * wave + fk + 4 * k;
+      cj[k] = GT * (lz.tc0 + tj) + 16 * k + fr;
+    }
+    lazy_cov_tile(lz, mtx, ri, cj, cin, smem);
+    if (!DEFER_C) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[n] = cin[n];
+    }
   }
   if (ABL == 2 || ABL == 3) {
     stage_store<BK>(ra, alpha, sA);
@@ -593,12 +598,13 @@ __global__ __launch_bounds__(256) void mm_nt_kernel(
   Core mm;
   mm.init(Ab, lda, Bb, ldb);
   mm_d4 acc[Core::MA][Core::NA], cin[SGN ? 1 : Core::MA][SGN ? 1 : Core::NA];
-  mm.prologue(lds, 0, Kd);   // the first slices are on their way while the C tile is fetched
   // (first trailing update of a factorisation whose assembly left the tiles below the diagonal
-  //  to their first touch: a tile of covariance rows is evaluated, not loaded -- sp_cov.h)
+  //  to their first touch: a tile of covariance rows is evaluated, not loaded -- sp_cov.h; the
+  //  star's table passes through the LDS stages before the product claims them)
   constexpr bool CAN_LAZY = Core::MA == 1 && Core::NA == 4 && TM == 64 && TN == 64;
   const bool lazy = CAN_LAZY && beta && lz.theta && lz.tr0 + ti > lz.tc0 + tj && lz.tr0 + ti < lz.nfull;
   mm_d4 cz[4];
+  if (!lazy) mm.prologue(lds, 0, Kd);   // the first slices are on their way while the C tile is fetched
   if (lazy) {
     int ri[4], cj[4];
 #pragma unroll
@@ -606,7 +612,8 @@ __global__ __launch_bounds__(256) void mm_nt_kernel(
       ri[k] = 64 * (lz.tr0 + ti) + mm.acc_row(0, k);
       cj[k] = 64 * (lz.tc0 + tj) + mm.acc_col(k < Core::NA ? k : 0);
     }
-    lazy_cov_tile(lz, mtx, ri, cj, cz);
+    lazy_cov_tile(lz, mtx, ri, cj, cz, lds);
+    mm.prologue(lds, 0, Kd);
   }
 #pragma unroll
   for (int m = 0; m < Core::MA; ++m)

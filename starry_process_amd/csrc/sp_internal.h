@@ -167,7 +167,10 @@ static inline int sp_nwig_of(int l) {
 }
 static inline int sp_roundup(int x, int m) { return ((x + m - 1) / m) * m; }
 
-// covariance tiles formed at first touch (sp_cov.h); theta == null: every tile comes from memory
+// covariance tiles formed at first touch (sp_cov.h); theta == null: every tile comes from memory.
+// (the star's table is staged in the LDS of the kernel that forms a tile: 4 (covpts + 4) doubles must
+//  fit the smallest of those scratch areas, the one-launch panel kernel's 4544 doubles)
+#define SP_TILE_LDS_MIN 4544
 struct LazyCov {
   const double *theta;     // [S][K] phases
   const double *t;         // [S][K] cadence times (temporal kernels)
