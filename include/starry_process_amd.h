@@ -390,7 +390,7 @@ int sp_set_defer_norm(sp_handle *h, int on);
 /* Covariance tiles formed at first touch (default on; environment SP_LAZY_COV).  Under the deferred
  * normalisation a tile of the system below the diagonal is a pure function of the cadences'
  * phases (flux.py:256-276) until the factorisation first touches it: with this switch on, and a
- * handle in the one-launch-per-panel mode (sp_set_panel_mode), the assembly takes those tiles'
+ * handle in the one-launch-per-panel mode (sp_set_panel_mode) and no temporal kernel, the assembly takes those tiles'
  * row / column sums but does not write them, and the kernel that touches a tile first evaluates
  * it instead of loading it -- the same code, the same bits, a write and a read of 3/4 of the
  * matrix less.  Diagonal tiles and the rows holding residuals are always written.            */

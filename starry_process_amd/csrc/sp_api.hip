@@ -1026,7 +1026,10 @@ int sp_lnlike_ensemble(sp_handle *h, int S, int K, int M, const double *t_dev,
   // normalisation, factored by the one-launch-per-panel super-panel driver -- the configuration
   // of handles that work several evaluations at a time.
   int lazy_nfull = 0;
-  if (h->lazy_cov && !conditional && normalized && h->defer_norm && G == 1 && h->chol_mode == 0 &&
+  // (not with a temporal kernel: its exp per entry, evaluated twice, costs more than the traffic
+  //  it saves -- cfg5 shape: -2.5 %)
+  if (h->lazy_cov && !conditional && temporal == SP_TEMPORAL_NONE && normalized && h->defer_norm && G == 1 &&
+      h->chol_mode == 0 &&
       h->onelaunch && h->fuse_diag > 1 && h->eager && K / SP_NB >= 2 &&
       (size_t)K * L.N >= 4 * (size_t)(covpts + 4) && 4 * (covpts + 4) <= SP_TILE_LDS_MIN) {
     lazy_nfull = K / SP_NB;
