@@ -307,7 +307,8 @@ __global__ __launch_bounds__(256) void assemble_kernel(
       if (i >= lim) continue;
     }
     // (tiles the factorisation forms itself at first touch: sums taken above, nothing written)
-    if (DEFER && ti > tj && ti < lazy_nfull) continue;
+    // (not the first block column: its panel launch has no product to form the tile behind)
+    if (DEFER && ti > tj && tj > 0 && ti < lazy_nfull) continue;
     double *dst = ob + (size_t)i * ldo + j0 + cj;
     if (j0 + cj + 3 < lim && (((size_t)dst) & 15) == 0) {
       *reinterpret_cast<dd2 *>(dst) = dd2{v[0], v[1]};

@@ -185,7 +185,8 @@ __global__ __launch_bounds__(256, (FUSE == 2 && SP_PANEL_WGS > 0) ? SP_PANEL_WGS
   const bool full = FAST || (row0 + GT <= Mrows && col0 + GT <= Nrows);
   // (one launch per panel, first super-panel: a tile below the diagonal made of covariance rows
   //  has not been written by the assembly -- its entries are evaluated below, sp_cov.h)
-  const bool lazy = FUSE == 2 && beta && lz.theta && lz.tr0 + ti > lz.tc0 + tj && lz.tr0 + ti < lz.nfull;
+  const bool lazy = FUSE == 2 && beta && lz.theta && lz.tr0 + ti > lz.tc0 + tj && lz.tc0 + tj > 0 &&
+                    lz.tr0 + ti < lz.nfull;
   if (beta && ABL != 4 && !lazy) {
 #pragma unroll
     for (int n = 0; n < 4; ++n)
@@ -234,7 +235,9 @@ __global__ __launch_bounds__(256, (FUSE == 2 && SP_PANEL_WGS > 0) ? SP_PANEL_WGS
       ri[k] = GT * (lz.tr0 + ti) + 16 * wave + fk + 4 * k;
       cj[k] = GT * (lz.tc0 + tj) + 16 * k + fr;
     }
+    PT_STAMP(8);
     lazy_cov_tile(lz, mtx, ri, cj, cin, smem);
+    PT_STAMP(9);
     if (!DEFER_C) {
 #pragma unroll
       for (int n = 0; n < 4; ++n) acc[n] = cin[n];
@@ -602,7 +605,8 @@ __global__ __launch_bounds__(256) void mm_nt_kernel(
   //  to their first touch: a tile of covariance rows is evaluated, not loaded -- sp_cov.h; the
   //  star's table passes through the LDS stages before the product claims them)
   constexpr bool CAN_LAZY = Core::MA == 1 && Core::NA == 4 && TM == 64 && TN == 64;
-  const bool lazy = CAN_LAZY && beta && lz.theta && lz.tr0 + ti > lz.tc0 + tj && lz.tr0 + ti < lz.nfull;
+  const bool lazy = CAN_LAZY && beta && lz.theta && lz.tr0 + ti > lz.tc0 + tj && lz.tc0 + tj > 0 &&
+                    lz.tr0 + ti < lz.nfull;
   mm_d4 cz[4];
   if (!lazy) mm.prologue(lds, 0, Kd);   // the first slices are on their way while the C tile is fetched
   if (lazy) {

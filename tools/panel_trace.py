@@ -34,6 +34,8 @@ for l in range(64):
     line += " | product +%5.1f image +%4.1f solve +%4.1f eager +%4.1f | diag %4.1f | tail %4.1f | total %5.1f" % (
         us(p[1]) - us(p[0]), us(p[2]) - us(p[1]), us(p[3]) - us(p[2]), us(p[4]) - us(p[3]),
         us(p[6]) - us(p[5]), us(p[7]) - us(p[6]), us(p[7]) - us(p[0]))
+    if p[8] and p[9]:
+        line += " | forming the tile: %4.1f (at +%4.1f)" % (us(p[9]) - us(p[8]), us(p[8]) - us(p[0]))
     o = t[l, 1]
     if o[0]:
         line += " || strip 3: start %+5.1f product +%5.1f image +%4.1f solve +%4.1f" % (
