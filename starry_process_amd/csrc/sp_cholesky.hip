@@ -63,7 +63,9 @@ __global__ __launch_bounds__(256) void diag_kernel(double *__restrict__ sys, lon
   __syncthreads();
   if (TIMED) { ts[1] = wall_clock64(); tc[1] = clock64(); }
   const int notpd = diag_block(sD, sRd, invL_all + (size_t)blockIdx.x * lts,
-                               TIMED ? dbg + 8 + 40 * blockIdx.x + 0 : nullptr);
+                               TIMED ? dbg + 8 + 40 * blockIdx.x + 0 : nullptr, threadIdx.x,
+                               (INV && SP_PANEL_MFMA_SOLVE == 1) ? invL_all + (size_t)blockIdx.x * lts + SP_LT_IMG
+                                                                 : nullptr);
   if (notpd && info) info[blockIdx.x] = 1;
   if (TIMED) { ts[2] = wall_clock64(); tc[2] = clock64(); }
   {
@@ -83,9 +85,6 @@ __global__ __launch_bounds__(256) void diag_kernel(double *__restrict__ sys, lon
     // L_d^-T behind the image: the one-launch-per-panel kernel solves with it (sp_gemm.hip)
 #if SP_PANEL_MFMA_SOLVE == 2
     diag_solve_operand(sD, sRd, invL_all + (size_t)blockIdx.x * lts + SP_LT_IMG);
-#else
-    __syncthreads();
-    diag_inverse(lds, sD, sRd, invL_all + (size_t)blockIdx.x * lts + SP_LT_IMG);
 #endif
   }
   if (TIMED) {

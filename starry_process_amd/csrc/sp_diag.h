@@ -207,14 +207,93 @@ __device__ __forceinline__ void below_quad(double *sD, const double *sRd, const 
   }
 }
 
+// ---- inverse of the block, formed in the shadow of the factorisation (inv_out of diag_block) -----
+// Linv = L^-1 is built block row by block row (16 x 16 blocks) while the NEXT leaf is being factored
+// by its wavefront and the others would wait:  Linv_cc = M_c = L_cc^-1 (substitution on the identity,
+// lane = row, x_k handed round by DPP row broadcasts),  Linv_cj = -M_c sum_{k=j}^{c-1} L_ck Linv_kj
+// (matrix cores; the partial sum comes out of the MFMA in exactly the layout of the next B operand,
+// so nothing goes through LDS in between).  Storage: the UPPER triangle of sD, which the
+// factorisation never touches: sD[r][c] = Linv[c][r] for r < c; the diagonal of Linv is sRd.
+template <int K>
+struct LeafInvStep {
+  // columns 4 t + g of the inverse for the lanes of 16-lane group g: res[t] = M[i][4 t + g], the A
+  // fragment (step t) of an MFMA whose A operand is M
+  static __device__ __forceinline__ void run(double (&s)[4], double (&res)[4], const double (&Lrow)[16],
+                                             double rd, int i) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const double m = s[t] * rd;                 // row K of the column: final in lane K
+      res[t] = (i == K) ? m : res[t];
+      s[t] = fma(-Lrow[K], row_bcast<K>(m), s[t]);
+    }
+    LeafInvStep<K + 1>::run(s, res, Lrow, rd, i);
+  }
+};
+template <>
+struct LeafInvStep<16> {
+  static __device__ __forceinline__ void run(double (&)[4], double (&)[4], const double (&)[16], double, int) {}
+};
+
+// block row c of Linv by ONE wavefront: `writer` stores M_c (strictly lower part, transposed into
+// sD's upper triangle), `j` >= 0 forms the block Linv_cj
+__device__ __forceinline__ void inverse_block_row(double *sD, const double *sRd, int c, bool writer,
+                                                  int j, int lane) {
+  if (!writer && j < 0) return;
+  const int i = lane & 15, g = lane >> 4, o = 16 * c;
+  double Lrow[16];
+#pragma unroll
+  for (int k = 0; k < 16; k += 2) {
+    const d2v v = *reinterpret_cast<const d2v *>(sD + (o + i) * BLD + o + k);
+    Lrow[k] = v.x;
+    Lrow[k + 1] = v.y;
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) Lrow[k] = k > i ? 0.0 : Lrow[k];   // (above the leaf's diagonal: not L)
+  const double rd = sRd[o + i];
+  double s[4], res[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    s[t] = (i == 4 * t + g) ? 1.0 : 0.0;
+    res[t] = 0.0;
+  }
+  LeafInvStep<0>::run(s, res, Lrow, rd, i);
+  if (writer) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int col = 4 * t + g;
+      if (i > col) sD[(o + col) * BLD + o + i] = res[t];
+    }
+  }
+  if (j < 0) return;
+  d4 S = d4{0.0, 0.0, 0.0, 0.0};
+  for (int k = j; k < c; ++k) {
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const double a = frag_rowmajor(sD, BLD, o, 16 * k, st, lane);          // L_ck[i][4 st + g]
+      const int m = 4 * st + g;
+      double b = sD[(16 * j + i) * BLD + 16 * k + m];                        // Linv_kj[m][n = i]
+      if (k == j) b = m > i ? b : (m == i ? sRd[16 * j + i] : 0.0);          // the diagonal block: M_j
+      S = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, S, 0, 0, 0);
+    }
+  }
+  d4 R = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int st = 0; st < 4; ++st) R = __builtin_amdgcn_mfma_f64_16x16x4f64(-res[st], S[st], R, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) sD[(16 * j + i) * BLD + o + g + 4 * r] = R[r];   // Linv_cj[g + 4 r][n = i]
+}
+
 // All 256 threads of the workgroup call this with the block already in sD
 // (lower triangle valid, upper part mirrored or zero; see callers for the
 // identity padding of a partial block) and a barrier behind the stores.
 // Returns 1 in every thread of wavefronts that saw a non-positive pivot
 // (callers OR it through global memory).
 // (tid_in: a caller inside a long loop passes a laundered copy of threadIdx.x, sp_chain.hip)
+// inv_out (optional): L^-T of the block, row k column n = Linv[n][k] (64 x 64 row-major, zero
+// left of the diagonal), formed in the shadow of the factorisation as described above.
 __device__ __forceinline__ int diag_block(double *sD, double *sRd, double *__restrict__ lt,
-                                          long long *dbg = nullptr, int tid_in = threadIdx.x) {
+                                          long long *dbg = nullptr, int tid_in = threadIdx.x,
+                                          double *__restrict__ inv_out = nullptr) {
   const int tid = tid_in, lane = tid & 63, wave = tid >> 6;
   int notpd = 0;
 #pragma unroll 1
@@ -259,9 +338,20 @@ __device__ __forceinline__ int diag_block(double *sD, double *sRd, double *__res
             if (t % 3 == hw) upd_tile(ib, w);
             ++t;
           }
+        // ... and block row kb of the inverse, while the next leaf is being factored
+        if (inv_out) inverse_block_row(sD, sRd, kb, hw == 0, (hw < kb) ? hw : -1, lane);
       }
     }
     if (dbg && wave == (kb < 3 ? kb + 1 : 3) && lane == 0) dbg[8 * kb + 6] = clock64();
+  }
+  if (inv_out) {
+    // the last block row (nothing left to hide it behind), then the whole of L^-T
+    inverse_block_row(sD, sRd, 3, wave == 3, wave < 3 ? wave : -1, lane);
+    __syncthreads();
+    for (int e = tid; e < 4096; e += 256) {
+      const int k = e >> 6, c = e & 63;
+      inv_out[e] = c > k ? sD[k * BLD + c] : (c == k ? sRd[k] : 0.0);
+    }
   }
   // operands of the panel solve: L^T with the reciprocal diagonal
   for (int e = tid; e < 4096; e += 256) {

@@ -476,7 +476,8 @@ __global__ __launch_bounds__(256, (FUSE == 2 && SP_PANEL_WGS > 0) ? SP_PANEL_WGS
       }
     __syncthreads();
     PT_STAMP(5);
-    const int notpd = diag_block(sD, sRd, invL_all + (size_t)mtx * lts);
+    const int notpd = diag_block(sD, sRd, invL_all + (size_t)mtx * lts, nullptr, threadIdx.x,
+                                 SP_PANEL_MFMA_SOLVE == 1 ? invL_all + (size_t)mtx * lts + SP_LT_IMG : nullptr);
     PT_STAMP(6);
     if (notpd && info) info[mtx] = 1;
     {
@@ -494,9 +495,7 @@ __global__ __launch_bounds__(256, (FUSE == 2 && SP_PANEL_WGS > 0) ? SP_PANEL_WGS
     // ... and the operand of the next launch's solves (L's blocks, the leaves inverted), behind the image
     diag_solve_operand(sD, sRd, invL_all + (size_t)mtx * lts + SP_LT_IMG);
 #elif SP_PANEL_MFMA_SOLVE
-    // ... and its L_d^-T for the next launch's solves, behind the image
-    __syncthreads();
-    diag_inverse(smem, sD, sRd, invL_all + (size_t)mtx * lts + SP_LT_IMG);
+    // (its L_d^-T for the next launch's solves was formed inside diag_block)
 #else
     if (nact < GT) {
       // partial last block: the rows of this tile below the active ones (residual rows,

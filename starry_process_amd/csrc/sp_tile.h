@@ -131,59 +131,12 @@ __device__ __forceinline__ void quad_solve_store(double (&x)[16], const double *
   }
 }
 
-// L_d^-T of the block diag_block has just factored: sD holds L (rows of BLD doubles), sRd the
-// reciprocal diagonal.  The rows of the identity are solved like any other tile, X = I L_d^-T, so
-// inv_out (64 x 64, row-major) gets row k, column n = (L_d^-1)[n][k] -- the operand with which a
-// panel solve becomes a product on the matrix cores (sp_gemm.hip one-launch-per-panel kernel,
-// sp_strip.hip).  All 256 threads; `work` (>= 4160 doubles) may alias sD, which is overwritten.
-__device__ __forceinline__ void diag_inverse(double *work, const double *sD, const double *sRd,
-                                             double *__restrict__ inv_out, int tid = threadIdx.x) {
-  LtRegs R;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int e = 2 * (tid + 256 * i), k = e >> 6, c = e & 63;
-    d2v v;
-    v.x = c > k ? sD[c * BLD + k] * sRd[c] : (c == k ? sRd[k] : 0.0);
-    v.y = c + 1 > k ? sD[(c + 1) * BLD + k] * sRd[c + 1] : (c + 1 == k ? sRd[k] : 0.0);
-    R.v[i] = v;
-  }
-  __syncthreads();
-  lt_store(R, work, work + 4096, tid);
-  __syncthreads();
-  const int q = tid & 3, row = tid >> 2;
-  double x[16];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    x[2 * i] = (8 * i + 2 * q == row) ? 1.0 : 0.0;
-    x[2 * i + 1] = (8 * i + 2 * q + 1 == row) ? 1.0 : 0.0;
-  }
-  quad_solve_store(x, work, work + 4096, inv_out + (size_t)row * 64 + 2 * q, true, tid);
-}
-
 // ---- operand of the panel solve as a BLOCK substitution on the matrix cores (SP_PANEL_MFMA_SOLVE 2) ----
 // W (64 x 64, row-major): the 16 x 16 blocks of L_d below the diagonal as they are, and in place
 // of each diagonal block L_cc its inverse M_c.  A solve X = T L_d^-T is then, block column by
 // block column,  X_c = (T_c - sum_{k<c} X_k L_ck^T) M_c^T : 40 MFMAs per wavefront, no inverse of
 // the whole block to form -- only the four 16 x 16 leaves are inverted, each by one wavefront
 // (lane = row, four columns per 16-lane group, x_k handed round by DPP row broadcasts).
-template <int K>
-struct LeafInvStep {
-  static __device__ __forceinline__ void run(double (&s)[4], double (&res)[4], const double (&Lrow)[16],
-                                             double rd, int i) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const double m = s[t] * rd;                 // row K of column t: final in lane K
-      res[t] = (i == K) ? m : res[t];
-      s[t] = fma(-Lrow[K], row_bcast<K>(m), s[t]);
-    }
-    LeafInvStep<K + 1>::run(s, res, Lrow, rd, i);
-  }
-};
-template <>
-struct LeafInvStep<16> {
-  static __device__ __forceinline__ void run(double (&)[4], double (&)[4], const double (&)[16], double, int) {}
-};
-
 // after diag_block: sD holds L (rows of BLD doubles, zero above the diagonal), sRd 1 / L_cc.
 // All 256 threads; reads LDS only, writes W.
 __device__ __forceinline__ void diag_solve_operand(const double *sD, const double *sRd,
@@ -204,13 +157,13 @@ __device__ __forceinline__ void diag_solve_operand(const double *sD, const doubl
   double s[4], res[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    s[t] = (i == 4 * g + t) ? 1.0 : 0.0;
+    s[t] = (i == 4 * t + g) ? 1.0 : 0.0;
     res[t] = 0.0;
   }
   LeafInvStep<0>::run(s, res, Lrow, rd, i);
-  double *dst = W + (size_t)(o + i) * 64 + o + 4 * g;
-  *reinterpret_cast<d2v *>(dst) = d2v{res[0], res[1]};
-  *reinterpret_cast<d2v *>(dst + 2) = d2v{res[2], res[3]};
+  double *dst = W + (size_t)(o + i) * 64 + o + g;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) dst[4 * t] = res[t];
 }
 
 #endif
