@@ -298,7 +298,8 @@ def main():
                     help="untimed pre-warm after the --warmup steps: whole steps keep running until this "
                          "much wall time has passed and every slot has run 3 times (clocks and fabric "
                          "at their loaded state); the timed region is exactly --steps steps either way")
-    ap.add_argument("--cpu-stars", type=int, default=256)
+    ap.add_argument("--cpu-stars", type=int, default=1024,
+                    help="stars of the CPU-baseline sample (about 25 core-seconds of the C pipeline)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the cfg5-shape and conditional-branch measurements (after the headline)")
