@@ -5,6 +5,11 @@ bench.py -- log_likelihood evaluations per second on MI355X.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks
+itself (launch_ranks: N fresh child processes of this script, one per GPU, rendezvous on
+127.0.0.1; the parent never touches a GPU and relays rank 0's line and the first non-zero exit
+code).  Under a launcher WORLD_SIZE must equal --gpus, anything else is an error (exit code 2).
+
 Workload (BASELINE.json configs[2], the one-GPU share of configs[3]):
   ydeg = 15, K = 1000 cadences, 64 independent stars per GPU, marginalised over
   inclination, normalised, covpts = 300, fp64.  Weak scaling: rank r owns stars
@@ -287,6 +292,122 @@ def bench_shape(torch, dist, ydeg, Kc, S, tspan, tau, u, conditional, F, steps, 
     return res
 
 
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """Start the n ranks of `bench.py --gpus n` as child processes (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set, 127.0.0.1 rendezvous).  The caller has made no GPU call and makes none; rank 0
+    inherits stdout (its JSON line is the job's), every rank inherits stderr.  Returns the exit code:
+    0 only if every rank returned 0 -- the first failure ends the others."""
+    import subprocess
+
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print("bench.py: rank %d exited with %d; stopping the other ranks" % (r, code), file=sys.stderr)
+                for o in live:
+                    procs[o].terminate()
+        if live:
+            time.sleep(0.05)
+    return rc
+
+
+def _stub_lnlike(s, step_id):
+    return -0.5 * (s + 1) ** 1.5 + np.cos(s) + 1e-3 * step_id
+
+
+class StubSlot(object):
+    """SP_BENCH_BACKEND=gloo: a slot whose "device step" is a deterministic function of (star, step) on
+    the CPU -- the per-star values of this rank's shard, then the all-gather Slot.step issues.  Lets the
+    whole multi-rank flow of this script (launch, rendezvous, shards, collectives, timing bracket, the
+    JSON line) run without a GPU (tests/test_bench_dist_gloo.py).  Never a measurement."""
+
+    def __init__(self, dist, torch, rank, world, S, slot_id):
+        self.dist, self.torch, self.rank, self.world, self.S = dist, torch, rank, world, S
+        self.slot_id = slot_id
+        self.calls = 0
+        self.out = torch.zeros(S, dtype=torch.float64)
+        self.gathered = torch.zeros(world * S, dtype=torch.float64)
+        self.history = []
+
+    def run(self):
+        first = self.rank * self.S
+        # (the step id is a function of the call count only: the same on every rank)
+        step_id = self.calls * 16 + self.slot_id
+        self.out[:] = self.torch.tensor([_stub_lnlike(s, step_id) for s in range(first, first + self.S)])
+        if self.world > 1:
+            self.dist.all_gather_into_tensor(self.gathered, self.out)
+        else:
+            self.gathered[:] = self.out
+        self.history.append((step_id, self.gathered.clone()))
+        self.calls += 1
+
+
+def main_stub(args, rank, world):
+    """The control flow of main() on gloo with StubSlot evaluators (no GPU, no library)."""
+    import torch
+    import torch.distributed as dist
+
+    if os.environ.get("SP_BENCH_STUB_FAIL_RANK") == str(rank):   # (test hook: a rank that dies at start-up)
+        return 7
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    S, F = STARS_PER_GPU, max(1, args.in_flight)
+    slots = [StubSlot(dist, torch, rank, world, S, i) for i in range(F)]
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    h = Harness(slots, lambda: None, dist.barrier if world > 1 else None, max_over_ranks)
+    elapsed, _, prewarm_steps = timed_steps(h, args.steps, args.warmup, min(args.prewarm_ms, 5.0), None)
+    sid, g = slots[(args.steps - 1) % F].history[-1]
+    ref = np.array([_stub_lnlike(s, sid) for s in range(world * S)])
+    ok = bool(np.array_equal(g.numpy(), ref))
+    if rank == 0:
+        print(json.dumps({
+            "metric": "log_likelihood evals/sec (ydeg=15, K=1000)", "value": world * S * args.steps / elapsed,
+            "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "STUB evaluator on gloo (SP_BENCH_BACKEND=gloo): control flow only, not a "
+                                   "measurement", "stars_per_gpu": S, "parallelism": "stars sharded %d-way" % world,
+                       "steps_in_flight": F},
+            "backend": "gloo-stub", "parity_ok": ok, "gathered_values": int(g.numel()),
+            "prewarm": {"steps": prewarm_steps, "timed": False}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -305,15 +426,29 @@ def main():
                     help="skip the cfg5-shape and conditional-branch measurements (after the headline)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
+    if args.gpus < 1:
+        print("bench.py: --gpus must be at least 1", file=sys.stderr)
+        return 2
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: be the launcher (this process makes no GPU call, before or after)
+        return launch_ranks(args.gpus, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        print("bench.py: --gpus %d but WORLD_SIZE=%d (rank %d): the line would not describe the job that ran"
+              % (args.gpus, world, rank), file=sys.stderr)
+        return 2
+    if os.environ.get("SP_BENCH_BACKEND", "nccl") == "gloo":
+        return main_stub(args, rank, world)
+
+    import torch
+    import torch.distributed as dist
+
+    if torch.cuda.device_count() <= local_rank:
+        print("bench.py: rank %d wants GPU %d, %d visible" % (rank, local_rank, torch.cuda.device_count()),
+              file=sys.stderr)
+        return 3
     torch.cuda.set_device(local_rank)
     # SP_BENCH_FORCE_DIST=1: take the multi-GPU code path (RCCL communicator, all-gather,
     # barriers, max over ranks) with however many ranks there are, even one -- lets a
@@ -581,7 +716,8 @@ def main():
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()
+    return 0 if ok else 1
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -32,6 +32,9 @@ Files (L = ydeg):
   upstream.npz      upstream-of-path pieces: size / latitude / longitude first
                     moments, log_jac, gauss2beta / beta2gauss, mu / sigma
   lnlike.npz        log-likelihoods for the BASELINE.json configs
+  lnlike_full.npz   the reference's value for EVERY star of bench.py's workloads: the 64 stars of
+                    cfg3 (ydeg 15, K 1000) and the 32 stars of cfg5's share of a GPU (ydeg 20,
+                    K 3000, Matern-3/2, u = [0.4, 0.2]) -- about ten minutes of the executed reference
 """
 import os
 import sys
@@ -468,6 +471,29 @@ def gen_lnlike():
     save("lnlike.npz", **out)
 
 
+def gen_lnlike_full():
+    """Every star of the full-batch GPU tests: sp.py:1052-1188 executed per star."""
+    out = {}
+    t0 = time.time()
+    marg = dict(marginalize_over_inclination=True, normalized=True)
+
+    def run(tag, L, K, nstars, ctor, tspan, call_extra):
+        sp = SP(ydeg=L, **ctor, **HYPER["default"])
+        vals = []
+        for s in range(nstars):
+            st = synthetic_star(s, K, tspan)
+            kw = dict(p=st["p"])
+            kw.update(call_extra)
+            vals.append(float(sp.log_likelihood(st["t"], st["flux"], st["data_cov"], **kw).eval()))
+            if s % 8 == 7:
+                print("  %-18s star %2d  %.12f  (%.0fs)" % (tag, s, vals[-1], time.time() - t0), flush=True)
+        out[tag] = np.array(vals)
+
+    run("cfg3_L15_K1000", 15, 1000, 64, marg, 4.0, {})
+    run("cfg5_L20_K3000", 20, 3000, 32, dict(tau=3.0, **marg), 30.0, dict(u=[0.4, 0.2]))
+    save("lnlike_full.npz", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ops", "consts", "moments", "cov", "norm", "lnlike", "upstream", "calibrate", "predict", "rev", "linalg_rev", "sum"]
     for L in (5, 15, 20):
@@ -486,6 +512,8 @@ if __name__ == "__main__":
         gen_norm()
     if "lnlike" in which:
         gen_lnlike()
+    if "lnlike_full" in which:      # (not in the default list: ten minutes)
+        gen_lnlike_full()
     if "upstream" in which:
         gen_upstream()
     if "calibrate" in which:

@@ -6,6 +6,11 @@ ranks bracket of exactly K steps, three steps in flight each issuing its all-gat
 communicator (the order of the collectives must be the same on every rank: a mismatch deadlocks
 or mixes shards), the weak-scaling shard of every rank and the whole-job value.  Also: the ragged
 sharded path with a rank that owns no star (world 3, S 2).
+
+Round 3: `python bench.py --gpus 2` END TO END -- the script starts its two
+ranks itself (launch_ranks), they rendezvous on 127.0.0.1, shard, all-gather and rank 0 prints
+the job's line; with SP_BENCH_BACKEND=gloo the evaluator is bench.StubSlot.  A WORLD_SIZE that
+contradicts --gpus, or a rank that dies, must end the job with a non-zero exit code.
 """
 import os
 import socket
@@ -27,29 +32,10 @@ def _free_port():
 
 
 def _fake_lnlike(s, step_id):
-    return -0.5 * (s + 1) ** 1.5 + np.cos(s) + 1e-3 * step_id
+    sys.path.insert(0, ROOT)
+    import bench
 
-
-class StubSlot(object):
-    """A slot of the benchmark whose "device step" is a deterministic function of (star, step):
-    per-star values of this rank's shard, then the all-gather bench.py's Slot.step issues."""
-
-    def __init__(self, dist, torch, rank, world, S, slot_id):
-        self.dist, self.torch, self.rank, self.world, self.S = dist, torch, rank, world, S
-        self.slot_id = slot_id
-        self.calls = 0
-        self.out = torch.zeros(S, dtype=torch.float64)
-        self.gathered = torch.zeros(world * S, dtype=torch.float64)
-        self.history = []
-
-    def run(self):
-        first = self.rank * self.S
-        # (the step id is a function of the call count only: the same on every rank)
-        step_id = self.calls * 16 + self.slot_id
-        self.out[:] = self.torch.tensor([_fake_lnlike(s, step_id) for s in range(first, first + self.S)])
-        self.dist.all_gather_into_tensor(self.gathered, self.out)
-        self.history.append((step_id, self.gathered.clone()))
-        self.calls += 1
+    return bench._stub_lnlike(s, step_id)
 
 
 def _bench_worker(rank, world, port, S, steps, warmup, F, q):
@@ -62,7 +48,7 @@ def _bench_worker(rank, world, port, S, steps, warmup, F, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    slots = [StubSlot(dist, torch, rank, world, S, i) for i in range(F)]
+    slots = [bench.StubSlot(dist, torch, rank, world, S, i) for i in range(F)]
 
     def max_over_ranks(x):
         tt = torch.tensor([x], dtype=torch.float64)
@@ -154,3 +140,41 @@ def test_ragged_shards_with_an_empty_rank():
     ref = np.array([(5 + s) * (1.0 + s) for s in range(S)])
     for rank, full in res:
         assert np.array_equal(full, ref)
+
+
+def _run_bench(argv, env_extra, timeout=240):
+    import subprocess
+
+    env = dict(os.environ, SP_BENCH_BACKEND="gloo", SP_BENCH_STARS="64")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, timeout=timeout,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+
+
+def test_bench_py_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher: two ranks, ONE line, n_gpus 2, 128 gathered values."""
+    import json
+
+    r = _run_bench(["--gpus", "2", "--steps", "7", "--warmup", "2"], {})
+    assert r.returncode == 0, r.stderr
+    # (gloo itself prints a "[Gloo] Rank 0 is connected ..." notice on stdout; RCCL does not)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip() and not ln.startswith("[Gloo]")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 7 and rec["warmup"] == 2
+    assert rec["gathered_values"] == 128 and rec["parity_ok"] is True
+    assert rec["backend"] == "gloo-stub" and rec["scaling"] == "weak"
+    assert np.isfinite(rec["value"]) and rec["value"] > 0
+
+
+def test_bench_py_refuses_a_world_that_is_not_gpus():
+    r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1"], {"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr and "{" not in r.stdout
+
+
+def test_bench_py_reports_a_dead_rank():
+    """A rank that fails takes the job down with a non-zero code (no hang on the survivor's collective)."""
+    r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1"], {"SP_BENCH_STUB_FAIL_RANK": "1"}, timeout=120)
+    assert r.returncode != 0 and "rank 1 exited" in r.stderr
