@@ -223,9 +223,6 @@ int ensure_big(sp_handle *h, size_t bytes, void **out) {
     SP_HIP(hipDeviceSynchronize());
     if (h->big_ptr) SP_HIP(hipFree(h->big_ptr));
     h->big_ptr = nullptr;
-  h->chain_mem = nullptr;
-  h->chain_dbg = nullptr;
-  h->chain_ints = 0;
     h->big_bytes = 0;
     hipError_t e = hipMalloc(&h->big_ptr, bytes);
     if (e != hipSuccess) {
@@ -437,6 +434,8 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
   h->rec_base = SP_REC_BASE_DEFAULT;
   h->defer_norm = 1;
   h->lazy_cov = 1;
+  h->panel2 = 1;
+  h->ncu = 256;
   const int N = h->N;
   h->l_of.resize(N);
   h->m_of.resize(N);
@@ -490,6 +489,12 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
     if (h->rec_base < 1) h->rec_base = 1;
     const char *e8 = getenv("SP_CHOL");
     h->chol_mode = e8 ? atoi(e8) : 0;
+    const char *e12 = getenv("SP_PANEL2");
+    h->panel2 = e12 ? atoi(e12) : 1;
+    {
+      hipDeviceProp_t prop;
+      h->ncu = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
+    }
     const char *e2 = getenv("SP_SUPER");
     h->superpanel = e2 ? atoi(e2) : 0;   // 0: chosen from K (sp_launch_cholesky_groups)
     if (h->superpanel < 0) h->superpanel = 0;

@@ -23,6 +23,7 @@
 #include "sp_internal.h"
 
 #include "sp_tile.h"
+#include "sp_paneldiag.h"
 
 #define DLD 65  // padded row length of a diagonal block in cho_solve_kernel
 
@@ -762,6 +763,85 @@ static int cholesky_dataflow(sp_handle *h, const sp_chol_group &G, int K, int Kp
   return SP_OK;
 }
 
+// ---- round-3 driver (h->panel2): ONE launch per panel (sp_panel.hip) ---------------------------------
+// Super-panels of w pivot blocks as above.  Launch j = T items (left-looking product over the q
+// panels of the super-panel before it, solve on the matrix cores, eager update of the coming
+// diagonal tiles).  Who factors pivot block j (a 12-17 us latency chain):
+//   j = 0                      a launch of its own (64 workgroups);
+//   q = 0, later super-panels  the tile-(0, 0) workgroup of the trailing update (sp_launch_syrk_diag);
+//   q > 0                      the workgroup that solved row tile j in launch j - 1, at its end (SP_PANEL_TAILD).
+// Look-ahead (SP_PANEL_LA, default on): the first tile of launch j + 1 -- tile (j + 2, j + 1), whose solve
+// and eager update stand between this launch and pivot block j + 2 -- is brought up to date with the
+// column blocks s0 .. j - 1 by an item of THIS launch; launch j + 1 then only adds the rank-64 update
+// with column block j: the first item's product leaves the critical path, and the diagonal block
+// behind it runs under the products of the launch's other items.
+static int cholesky_panel2(sp_handle *h, int ngroups, const sp_chol_group *grp, int K, int Kp, int w) {
+  const long ld = Kp, stride = (long)Kp * Kp, lts = sp_lt_stride(Kp);
+  const int nsteps = (K + SP_NB - 1) / SP_NB, ntile = Kp / SP_NB;
+  static int la_on = -1;
+  if (la_on < 0) {
+    const char *e2 = getenv("SP_PANEL_LA");
+    la_on = e2 ? atoi(e2) : 1;
+  }
+  auto nact_of = [&](int j) { return K - j * SP_NB < SP_NB ? K - j * SP_NB : SP_NB; };
+  for (int s0 = 0; s0 < nsteps; s0 += w) {
+    {
+      SpProfScope sp_scope(ngroups == 1 ? h : nullptr, grp[0].st, SP_PROF_PANELS, 0.0, 0);
+      for (int q = 0; q < w && s0 + q < nsteps; ++q) {
+        const int j = s0 + q;
+        int last = s0 + w;
+        if (last > nsteps - 1) last = nsteps - 1;
+        const int neager = last > j ? last - j : 0;
+        const double rows = (double)(ntile - j - 1) * SP_NB;
+        for (int g = 0; g < ngroups; ++g) {
+          const sp_chol_group &G = grp[g];
+          const LazyCov *lzp = (G.lazy.theta && s0 == 0) ? &G.lazy : nullptr;
+          // algorithmic work as the per-panel drivers have always counted it: left-looking product,
+          // triangular solve, eager rank-64 updates, the diagonal block
+          const double fl = (double)G.S * (2.0 * rows * 64 * (q * 64.0) + rows * 64 * 64 +
+                                           neager * 64.0 * 64 * 64 + 64.0 * 64 * 64 / 3);
+          const bool d_alone = j == 0;                         // block 0: nobody before it
+          // block j + 1 in the tail of this launch (same super-panel: the next one's first block
+          // belongs to the trailing update)
+          const bool tail = rows > 0 && j + 1 < nsteps && q + 1 < w;
+          const bool la = la_on && q >= 1 && j + 2 < ntile && j + 1 < nsteps && q + 1 < w && rows > 0;
+          const bool first_la = la_on && q >= 2 && rows > 0;   // (launch j - 1 qualified: q - 1 >= 1, j + 1 < ntile)
+          const int nl = d_alone && rows > 0 ? 2 : 1;
+          SpProfScope prof(h, G.st, SP_PROF_CHAIN, fl, nl);
+          SpProfScope prof1(h, G.st, SP_PROF_PANEL_LAUNCH, fl, nl);
+          sp_scope.add(fl, nl);
+          int rc = SP_OK;
+          if (d_alone)
+            rc = sp_launch_panel2(G.sys, ld, stride, G.S, ntile, j, s0, nact_of(j), 0, last, SP_PANEL_D, h->ncu,
+                                  G.invL, lts, G.info, G.st, nullptr);
+          const int what = rows > 0 ? (SP_PANEL_T | (tail ? SP_PANEL_TAILD : 0) | (la ? SP_PANEL_LA : 0) |
+                                       (first_la ? SP_PANEL_FIRSTLA : 0))
+                                    : 0;
+          if (rc == SP_OK && what)
+            rc = sp_launch_panel2(G.sys, ld, stride, G.S, ntile, j, s0, nact_of(j), tail ? nact_of(j + 1) : 0,
+                                  last, what, h->ncu, G.invL, lts, G.info, G.st, lzp);
+          if (rc != SP_OK) return rc;
+        }
+      }
+    }   // (sp_scope ends here: the trailing update has its own pair)
+    const int jE = s0 + w, cE = jE * SP_NB;
+    if (cE < K) {
+      const int n = Kp - cE, kd = w * SP_NB, cS = s0 * SP_NB;
+      for (int g = 0; g < ngroups; ++g) {
+        const sp_chol_group &G = grp[g];
+        LazyCov lzv = G.lazy;
+        lzv.tr0 = lzv.tc0 = jE;
+        DiagFuse df{G.sys, ld, stride, jE, nact_of(jE), G.invL, lts, G.info};
+        SpProfScope prof(h, G.st, SP_PROF_SYRK, (double)G.S * (double)n * (n + 1) * kd);
+        int rc = sp_launch_syrk_diag(G.sys + (size_t)cE * ld + cS, ld, stride, G.sys + (size_t)cE * ld + cE,
+                                     n, kd, G.S, G.st, (G.lazy.theta && s0 == 0) ? &lzv : nullptr, &df);
+        if (rc != SP_OK) return rc;
+      }
+    }
+  }
+  return SP_OK;
+}
+
 // In-place factorisation of S padded systems (Kp x Kp, ld = Kp): the leading
 // K x K part is factored, rows K..Kp-1 only receive the triangular solve.
 //
@@ -785,6 +865,8 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
   // 12 / 16 -> 1.17 / 1.10 / 1.085 / 1.08 / 1.12 / 1.14 ms per step; K = 3000 (47 panels): 8 best as well
   const int w = (h && h->superpanel > 0) ? h->superpanel : (nsteps >= 16 ? 8 : 4);
   if (h && h->chol_mode == 3 && ngroups == 1) return cholesky_dataflow(h, grp[0], K, Kp, w);
+  if (h && h->onelaunch && h->panel2 && h->fuse_diag > 1 && h->eager)
+    return cholesky_panel2(h, ngroups, grp, K, Kp, w);
   if (h && h->onelaunch && h->fuse_diag > 1 && h->eager) {
     // ONE launch per panel (sp_launch_panel): update + solve + eager diagonal updates + the
     // next diagonal block; the L_d^T images ping-pong between the two slots of a star

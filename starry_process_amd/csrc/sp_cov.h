@@ -124,4 +124,42 @@ __device__ __forceinline__ void lazy_cov_tile(const LazyCov &z, int star, const 
   __syncthreads();   // the scratch goes back to its owner
 }
 
+// the same for a lane that holds ONE row and four groups of four consecutive columns (the panel
+// kernel's transposed accumulator layout, sp_panel.hip): out[m][r] = entry (row ri, column
+// c0 + 16 m + r).  No temporal kernel here: tiles are only left to their first touch without one
+// (sp_lnlike_ensemble; the exp per entry, evaluated twice, costs more than the traffic saves), and
+// sixteen inlined copies of exp() would be dead code in the panel kernel.
+template <typename V4>
+__device__ __forceinline__ void lazy_cov_row(const LazyCov &z, int star, int ri, int c0, V4 (&out)[4],
+                                             double *stage, int tid) {
+  const sp_star st = z.stars[star];
+  const int nobs = star_nobs(st, z.K), np = z.covpts + 4;
+  const double *th = z.theta + (size_t)star * z.K;
+  const bool oi = ri < nobs;
+  const double thi = oi ? th[ri] : 0.0;
+  {
+    const double *src = z.ptab + (size_t)star * 4 * np;
+    for (int e = 2 * tid; e < 4 * np; e += 512)
+      *reinterpret_cast<dd2 *>(stage + e) = *reinterpret_cast<const dd2 *>(src + e);
+  }
+  __syncthreads();
+  SplineGen g{stage, 2 * np, 6.283185307179586 / z.covpts,
+              1.0 / (6.283185307179586 / z.covpts), z.covpts};
+  // (unrolled -- a run-time index into the caller's accumulators would send them to scratch memory)
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    double thj[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = c0 + 16 * m + r;
+      thj[r] = c < nobs ? th[c] : 0.0;
+    }
+    V4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (oi && c0 + 16 * m + r < nobs) ? g(thi, thj[r]) : 0.0;
+    out[m] = o;
+  }
+  __syncthreads();   // the scratch goes back to its owner
+}
+
 #endif

@@ -291,10 +291,13 @@ __device__ __forceinline__ void inverse_block_row(double *sD, const double *sRd,
 // (tid_in: a caller inside a long loop passes a laundered copy of threadIdx.x, sp_chain.hip)
 // inv_out (optional): L^-T of the block, row k column n = Linv[n][k] (64 x 64 row-major, zero
 // left of the diagonal), formed in the shadow of the factorisation as described above.
+// form_inv: build L^-1 in the upper triangle of sD / sRd even without inv_out (sp_paneldiag.h writes
+// it out in the fragment order of the panel kernel's solve).  lt may be null (no substitution image).
 __device__ __forceinline__ int diag_block(double *sD, double *sRd, double *__restrict__ lt,
                                           long long *dbg = nullptr, int tid_in = threadIdx.x,
-                                          double *__restrict__ inv_out = nullptr) {
+                                          double *__restrict__ inv_out = nullptr, bool form_inv = false) {
   const int tid = tid_in, lane = tid & 63, wave = tid >> 6;
+  const bool inv = form_inv || inv_out != nullptr;
   int notpd = 0;
 #pragma unroll 1
   for (int kb = 0; kb < 4; ++kb) {
@@ -339,25 +342,27 @@ __device__ __forceinline__ int diag_block(double *sD, double *sRd, double *__res
             ++t;
           }
         // ... and block row kb of the inverse, while the next leaf is being factored
-        if (inv_out) inverse_block_row(sD, sRd, kb, hw == 0, (hw < kb) ? hw : -1, lane);
+        if (inv) inverse_block_row(sD, sRd, kb, hw == 0, (hw < kb) ? hw : -1, lane);
       }
     }
     if (dbg && wave == (kb < 3 ? kb + 1 : 3) && lane == 0) dbg[8 * kb + 6] = clock64();
   }
-  if (inv_out) {
+  if (inv) {
     // the last block row (nothing left to hide it behind), then the whole of L^-T
     inverse_block_row(sD, sRd, 3, wave == 3, wave < 3 ? wave : -1, lane);
     __syncthreads();
-    for (int e = tid; e < 4096; e += 256) {
-      const int k = e >> 6, c = e & 63;
-      inv_out[e] = c > k ? sD[k * BLD + c] : (c == k ? sRd[k] : 0.0);
-    }
+    if (inv_out)
+      for (int e = tid; e < 4096; e += 256) {
+        const int k = e >> 6, c = e & 63;
+        inv_out[e] = c > k ? sD[k * BLD + c] : (c == k ? sRd[k] : 0.0);
+      }
   }
   // operands of the panel solve: L^T with the reciprocal diagonal
-  for (int e = tid; e < 4096; e += 256) {
-    const int k = e >> 6, c = e & 63;
-    lt[e] = c > k ? sD[c * BLD + k] * sRd[c] : (c == k ? sRd[k] : 0.0);
-  }
+  if (lt)
+    for (int e = tid; e < 4096; e += 256) {
+      const int k = e >> 6, c = e & 63;
+      lt[e] = c > k ? sD[c * BLD + k] * sRd[c] : (c == k ? sRd[k] : 0.0);
+    }
   return notpd;
 }
 

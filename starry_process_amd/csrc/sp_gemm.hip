@@ -24,10 +24,12 @@
 #include "sp_cov.h"
 #include "sp_mm.h"
 #include "sp_wt.h"
+#include "sp_stage.h"
+#include "sp_paneldiag.h"
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-#define GT 64   // tile edge
+#define GT SP_GT   // tile edge
 // one-launch-per-panel kernel: workgroups per CU asked of the compiler (0: whatever it needs), and
 // whether the image of the solve is fetched ahead of the product (32 more registers)
 #ifndef SP_PANEL_WGS
@@ -52,63 +54,6 @@ __device__ int g_panel_trace_n;
 #endif
 
 namespace {
-
-// Global -> registers -> LDS staging of a 64-row x BK panel slice, split in two
-// so that the loads of slice k+1 are in flight while slice k feeds the MFMAs.
-//   BK/2 lanes x 16 B per row, 256/(BK/2) rows per pass, 64/that passes.
-template <int BK>
-struct PanelRegs {
-  d2 v[GT / (256 / (BK / 2))];
-};
-
-template <int BK>
-__device__ __forceinline__ void stage_load(const double *P, long ld, int row0, int nrows,
-                                           int k0, int Kd, bool vec_ok, PanelRegs<BK> &R) {
-  constexpr int LPR = BK / 2, RPP = 256 / LPR;
-  const int t = threadIdx.x;
-  const int cpair = (t % LPR) * 2;
-#pragma unroll
-  for (int pass = 0; pass < GT / RPP; ++pass) {
-    const int gr = row0 + (t / LPR) + RPP * pass;
-    d2 v = {0.0, 0.0};
-    if (gr < nrows) {
-      const double *src = P + (size_t)gr * ld + k0 + cpair;
-      if (vec_ok && k0 + cpair + 1 < Kd) {
-        v = *reinterpret_cast<const d2 *>(src);
-      } else {
-        if (k0 + cpair < Kd) v.x = src[0];
-        if (k0 + cpair + 1 < Kd) v.y = src[1];
-      }
-    }
-    R.v[pass] = v;
-  }
-}
-
-// the same without bounds checks: full 64-row tiles, BK | Kd, 16-byte aligned rows
-template <int BK>
-__device__ __forceinline__ void stage_load_fast(const double *P, long ld, int row0, int k0,
-                                                PanelRegs<BK> &R) {
-  constexpr int LPR = BK / 2, RPP = 256 / LPR;
-  const int t = threadIdx.x;
-  const double *src = P + (size_t)(row0 + t / LPR) * ld + k0 + (t % LPR) * 2;
-#pragma unroll
-  for (int pass = 0; pass < GT / RPP; ++pass)
-    R.v[pass] = *reinterpret_cast<const d2 *>(src + (size_t)(RPP * pass) * ld);
-}
-
-template <int BK>
-__device__ __forceinline__ void stage_store(const PanelRegs<BK> &R, double scale,
-                                            double *__restrict__ s) {
-  constexpr int LDW = BK + 1, LPR = BK / 2, RPP = 256 / LPR;
-  const int t = threadIdx.x;
-  const int cpair = (t % LPR) * 2;
-#pragma unroll
-  for (int pass = 0; pass < GT / RPP; ++pass) {
-    const int r = (t / LPR) + RPP * pass;
-    s[r * LDW + cpair] = R.v[pass].x * scale;
-    s[r * LDW + cpair + 1] = R.v[pass].y * scale;
-  }
-}
 
 // (A and C may alias: the triangular solve X = P L^-T runs in place, each
 //  workgroup reads its whole A row-tile before it stores the same C tile.)
@@ -578,8 +523,9 @@ template <class Core, bool SGN>
 __global__ __launch_bounds__(256) void mm_nt_kernel(
     const double *__restrict__ A, long lda, long strideA, const double *__restrict__ B, long ldb,
     long strideB, double *__restrict__ C, long ldc, long strideC, int Kd, double alpha, int beta,
-    int lower_only, int batch, int ntn, int ntiles, int skip00, LazyCov lz) {
+    int lower_only, int batch, int ntn, int ntiles, int skip00, LazyCov lz, DiagFuse df) {
   constexpr int TM = Core::TM_, TN = Core::TN_;
+  static_assert(Core::LDS_DOUBLES >= SP_DIAG_LDS_DOUBLES, "the tile-(0,0) workgroup factors a pivot block in this LDS");
   __shared__ __attribute__((aligned(16))) double lds[Core::LDS_DOUBLES];
   int mtx, tile;
   if (!sp_xcd_decode(blockIdx.x, batch, ntiles, mtx, tile)) return;
@@ -593,7 +539,17 @@ __global__ __launch_bounds__(256) void mm_nt_kernel(
     ti = tile / ntn;
     tj = tile % ntn;
   }
-  if (skip00 && lower_only && ti == 0 && tj == 0) return;
+  if (skip00 && lower_only && ti == 0 && tj == 0) {
+    // tile (0, 0) -- the next pivot block -- carries every update already (the panel kernels keep it
+    // up to date); its workgroup factors it beside the products of this launch (sp_paneldiag.h)
+    if (df.sys) {
+      __builtin_amdgcn_s_setprio(3);
+      panel_diag_item(df.sys + (size_t)mtx * df.stride, df.ld, df.j, df.nact,
+                      df.img + (size_t)mtx * df.lts + (size_t)(df.j & 1) * 2 * SP_LT_IMG,
+                      df.info ? df.info + mtx : nullptr, lds, threadIdx.x);
+    }
+    return;
+  }
   const double *Ab = A + (size_t)mtx * strideA + (size_t)ti * TM * lda;
   const double *Bb = B + (size_t)mtx * strideB + (size_t)tj * TN * ldb;
   double *Cb = C + (size_t)mtx * strideC + (size_t)ti * TM * ldc + (size_t)tj * TN;
@@ -759,8 +715,10 @@ static int wt_launch(const double *A, long lda, long strideA, const double *B, l
 template <class Core>
 int mm_launch(const double *A, long lda, long strideA, const double *B, long ldb, long strideB,
               double *C, long ldc, long strideC, int Mrows, int Nrows, int Kd, double alpha, int beta,
-              int lower_only, int batch, hipStream_t st, int skip00, const LazyCov *lazy = nullptr) {
+              int lower_only, int batch, hipStream_t st, int skip00, const LazyCov *lazy = nullptr,
+              const DiagFuse *dfp = nullptr) {
   const LazyCov lz = lazy ? *lazy : LazyCov{};
+  const DiagFuse df = dfp ? *dfp : DiagFuse{nullptr, 0, 0, 0, 0, nullptr, 0, nullptr};
   const int ntm = Mrows / Core::TM_, ntn = Nrows / Core::TN_;
   const int ntiles = lower_only ? ntm * (ntm + 1) / 2 : ntm * ntn;
   const long nblk = sp_xcd_grid(batch, ntiles);
@@ -768,11 +726,11 @@ int mm_launch(const double *A, long lda, long strideA, const double *B, long ldb
   if (alpha == 1.0 || alpha == -1.0)
     hipLaunchKernelGGL((mm_nt_kernel<Core, true>), dim3((unsigned)nblk), dim3(256), 0, st,
                        A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Kd, alpha, beta, lower_only,
-                       batch, ntn, ntiles, skip00, lz);
+                       batch, ntn, ntiles, skip00, lz, df);
   else
     hipLaunchKernelGGL((mm_nt_kernel<Core, false>), dim3((unsigned)nblk), dim3(256), 0, st,
                        A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Kd, alpha, beta, lower_only,
-                       batch, ntn, ntiles, skip00, lz);
+                       batch, ntn, ntiles, skip00, lz, df);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }
@@ -936,6 +894,18 @@ int sp_launch_panel(const double *A, long lda, const double *B, long ldb, double
                        batch, ntm, ntn, ntiles, next_nact, lt_out, info, neager, lt_in, lts, lz);
   SP_LAUNCH_CHECK();
   return SP_OK;
+}
+
+// C -= X X^T on the lower 64 x 64 tiles of an n x n block, tile (0, 0) skipped -- its workgroup
+// factors the pivot block `df` describes instead (round-3 driver, sp_cholesky.hip)
+int sp_launch_syrk_diag(const double *X, long ld, long stride, double *T, int n, int kd, int batch,
+                        hipStream_t st, const LazyCov *lazy, const DiagFuse *df) {
+  if (n <= 0 || batch <= 0) return SP_OK;
+  if ((n % GT) || (kd % 16) || kd <= 0 || (ld & 1) || (stride & 1) ||
+      ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(T)) & 15))
+    return SP_ERR_INVALID;
+  return mm_launch<MM2<64, 64, 8, 6, 4>>(X, ld, stride, X, ld, stride, T, ld, stride, n, n, kd, -1.0, 1, 1,
+                                         batch, st, 1, (lazy && lazy->theta) ? lazy : nullptr, df);
 }
 
 int sp_launch_gemm_nt(const double *A, long lda, long strideA, const double *B, long ldb,

@@ -63,6 +63,8 @@ struct sp_handle {
   int fuse_diag;                // fuse the diagonal-block factorisation into the block-column update
   int eager;                    // panel solves keep the coming diagonal blocks up to date (SP_EAGER)
   int onelaunch;                // update + solve + eager + next diagonal block in ONE launch per panel (SP_ONELAUNCH)
+  int panel2;                   // ... with the round-3 panel kernel (sp_panel.hip; SP_PANEL2, default 1)
+  int ncu;                      // compute units of the device
   std::vector<hipStream_t> gstream;
   std::vector<hipEvent_t> gdone;
   hipEvent_t gfork;
@@ -93,31 +95,44 @@ enum {
   SP_PROF_NKINDS = 6
 };
 
-// brackets the launches issued during its lifetime with a pair of events on `st`
+// brackets the launches issued during its lifetime with a pair of events on `st`.  Scopes nest (the
+// panel driver holds a PANELS scope around per-launch CHAIN / PANEL_LAUNCH scopes): a scope RESERVES
+// its pair of events when it is constructed and keeps the index, so an inner scope never touches
+// the outer one's slot.
 struct SpProfScope {
   sp_handle *h;
   hipStream_t st;
   bool on;
+  size_t idx;     // first event of this scope's pair
   SpProfScope(sp_handle *h_, hipStream_t st_, int kind, double flops, int launches = 1)
-      : h(h_), st(st_), on(false) {
+      : h(h_), st(st_), on(false), idx(0) {
     if (!h || !h->prof_on || !((h->prof_mask >> kind) & 1u) || h->prof_used + 2 > h->prof_ev.size()) return;
-    if (hipEventRecord(h->prof_ev[h->prof_used], st) != hipSuccess) return;
-    h->prof_kind[h->prof_used / 2] = kind;
-    h->prof_fl[h->prof_used / 2] = flops;
-    h->prof_n[h->prof_used / 2] = launches;
+    idx = h->prof_used;
+    h->prof_used += 2;
+    h->prof_kind[idx / 2] = kind;
+    h->prof_fl[idx / 2] = flops;
+    h->prof_n[idx / 2] = launches;
+    // (a pair whose start could not be recorded stays reserved with zero launches: read as empty)
+    if (hipEventRecord(h->prof_ev[idx], st) != hipSuccess) {
+      h->prof_n[idx / 2] = 0;
+      h->prof_fl[idx / 2] = 0.0;
+      h->prof_kind[idx / 2] = -1;
+      return;
+    }
     on = true;
   }
   // (a scope around several launches: add each one's algorithmic flops as it is issued)
   void add(double flops, int launches = 1) {
     if (!on) return;
-    h->prof_fl[h->prof_used / 2] += flops;
-    h->prof_n[h->prof_used / 2] += launches;
+    h->prof_fl[idx / 2] += flops;
+    h->prof_n[idx / 2] += launches;
   }
   ~SpProfScope() {
     if (!on) return;
-    (void)hipEventRecord(h->prof_ev[h->prof_used + 1], st);
-    h->prof_used += 2;
+    if (hipEventRecord(h->prof_ev[idx + 1], st) != hipSuccess) h->prof_kind[idx / 2] = -1;
   }
+  SpProfScope(const SpProfScope &) = delete;
+  SpProfScope &operator=(const SpProfScope &) = delete;
 };
 
 // one-launch-per-panel kernel (sp_gemm.hip): the panel solve by substitution on the vector ALU, four
@@ -231,6 +246,17 @@ int sp_launch_gemm_nt(const double *A, long lda, long strideA, const double *B,
                       int Mrows, int Nrows, int Kd, double alpha, int beta,
                       int lower_only, int batch, hipStream_t st, int skip_tile00 = 0,
                       const LazyCov *lazy = nullptr);
+
+// round-3 panel kernel (sp_panel.hip)
+struct DiagFuse;
+enum { SP_PANEL_D = 1, SP_PANEL_T = 2, SP_PANEL_TAILD = 4, SP_PANEL_LA = 8, SP_PANEL_FIRSTLA = 16 };
+int sp_launch_panel2(double *sys, long ld, long stride, int S, int ntile, int j, int s0, int nact,
+                     int next_nact, int last, int what, int ncu, double *img, long lts, int32_t *info,
+                     hipStream_t st, const LazyCov *lazy);
+// symmetric trailing update C -= X X^T (lower 64 x 64 tiles, tile (0, 0) skipped) whose tile-(0, 0)
+// workgroup factors the pivot block described by `df` (sp_paneldiag.h)
+int sp_launch_syrk_diag(const double *X, long ld, long stride, double *T, int n, int kd, int batch,
+                        hipStream_t st, const LazyCov *lazy, const DiagFuse *df);
 
 void sp_set_mm_variant(int v);
 void sp_set_strip_flags(int f);  // ablations of the strip solve (sp_strip.hip)   // tile shape of the pipelined product (sp_gemm.hip)

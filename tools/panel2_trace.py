@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""Timeline of the round-3 panel kernel (sp_panel.hip; K = 1000, 64 stars, one step at a time) from
+in-kernel wall-clock stamps of star 0's work items.  Needs the variant library:
+    bash tools/ab_build.sh trace -DSP_PANEL_TRACE && SP_LIB_VARIANT=trace python tools/panel2_trace.py"""
+import ctypes, os, sys
+import numpy as np
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import torch
+from starry_process_amd._lib import check
+from chain_check import engine, setup, run
+
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+e = engine(0, 1)
+a = setup(e, S, K)
+run(e, a, reps=5)
+f = e._L.sp_debug_panel2_trace
+f.restype = ctypes.c_int
+f.argtypes = [ctypes.c_void_p]
+check(f(None))
+run(e, a, reps=1)
+buf = np.zeros(64 * 3 * 16, dtype=np.int64)
+check(f(buf.ctypes.data_as(ctypes.c_void_p)))
+t = buf.reshape(64, 3, 16).astype(np.float64)
+t0 = t[t > 0].min()
+us = lambda v: (v - t0) / 100.0
+d = lambda p, a, b: (us(p[b]) - us(p[a])) if p[a] and p[b] else float("nan")
+print("star 0, us.  D item: start | load->diag_block | diag_block | image + L out | tail (partial rows, publish)")
+print("T items (first = next pivot row tile, last = bottom row tile): start | C tile / lazy | product | wait | solve | store | eager")
+for j in range(64):
+    if not t[j].any():
+        continue
+    D, F, L = t[j]
+    line = "j %2d" % j
+    if D[0]:
+        line += " | D%s @%7.1f: load %4.1f diag %5.1f img %4.1f tail %4.1f = %5.1f" % (
+            "(j+1, tail)" if F[0] and D[0] > F[0] + 1 else "", us(D[0]), d(D, 0, 8), d(D, 8, 9), d(D, 9, 10), d(D, 10, 2), d(D, 0, 2))
+    for name, p in (("first", F), ("last", L)):
+        if p[0]:
+            line += " | %s @%7.1f: C %4.1f prod %5.1f wait %5.1f solve %4.1f store %4.1f eager %4.1f end @%7.1f" % (
+                name, us(p[0]), d(p, 0, 1), d(p, 1, 2), d(p, 2, 3), d(p, 3, 4), d(p, 4, 5), d(p, 5, 6),
+                us(p[6] if p[6] else p[5]))
+    print(line)
