@@ -205,14 +205,33 @@ def prof_summary(engines, kinds):
     return out
 
 
+PANEL_KERNEL = ("panel_kernel (csrc/sp_panel.hip; one launch per 64-column panel: left-looking block-column product + "
+                "triangular solve + eager rank-64 diagonal updates on v_mfma_f64_16x16x4_f64, next diagonal block)")
 KERNEL_OF_KIND = {
-    "panels": "gemm_nt_kernel<32,false,2,...> (one launch per panel: left-looking block-column product + "
-              "substitution solve + eager rank-64 diagonal updates + next diagonal block)",
-    "chain": "panel chain (diag_kernel, gemm_nt_kernel<32,false,1,...> block-column update + diagonal block, "
-             "trsm_quad_kernel)",
-    "syrk": "mm_nt_kernel<MM2<64,64,8,6,4>> / gemm_nt_kernel (symmetric trailing update, v_mfma_f64_16x16x4_f64)",
-    "strip": "strip_kernel (strip solve X = A21 L11^-T)",
+    "panels": PANEL_KERNEL,
+    "chain": PANEL_KERNEL,
+    "syrk": "mm_nt_kernel<MM2<64,64,8,6,4>> (csrc/sp_gemm.hip; symmetric rank-512 trailing update, "
+            "v_mfma_f64_16x16x4_f64)",
 }
+
+
+def rocprof_average_us(kernel_prefix):
+    """Average duration of a kernel in the committed rocprofv3 kernel-trace summary of THIS round's
+    one-step-at-a-time run (profiles/r03_one_kernel_stats.csv), or None: printed beside the event
+    average so that the two can be compared; it is a file of the repository, not of this run."""
+    import csv
+
+    path = os.path.join(ROOT, "profiles", "r03_one_kernel_stats.csv")
+    if not os.path.exists(path):
+        return None, None
+    try:
+        for r in csv.DictReader(open(path)):
+            name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+            if name.startswith(kernel_prefix):
+                return float(r["AverageNs"]) / 1e3, "profiles/r03_one_kernel_stats.csv"
+    except Exception:
+        pass
+    return None, None
 
 
 def roofline_entry(kind, rec, extra=None):
@@ -501,9 +520,9 @@ def main():
 
     harness = Harness(slots, torch.cuda.synchronize, dist.barrier if use_dist else None, max_over_ranks)
     # kinds bracketed with HIP events INSIDE the timed region (on the launch streams): the symmetric
-    # trailing updates (one pair each), the panel kernels of each super-panel (one pair per
-    # super-panel) and the strip solves; the per-launch breakdown of the chain is taken outside it
-    timed_kinds = ("syrk", "panels", "strip")
+    # trailing updates (one pair each) and the panel kernels of each super-panel (one pair per
+    # super-panel); the per-launch figures are taken outside it
+    timed_kinds = ("syrk", "panels")
     nev = (args.steps // F + 2) * 8
 
     def arm():
@@ -554,7 +573,7 @@ def main():
         dt1 = time.perf_counter() - t1
         one = {"evals_per_s": S * nrep / dt1, "ms_per_step": 1e3 * dt1 / nrep}
         # (a separate short pass with every launch bracketed: the events cost ~10 % of a step)
-        kinds1 = ("syrk", "chain", "strip")
+        kinds1 = ("syrk", "chain")
         e.profile_begin(10 * 64, kinds1)
         for _ in range(10):
             c0.step()
@@ -630,13 +649,18 @@ def main():
         # the dominant kernel of the timed region: the bracketed kind with the largest summed duration
         cand = {k: v for k, v in timed_prof.items() if v["launches"] > 0}
         dom = max(cand, key=lambda k: cand[k]["ms"]) if cand else "syrk"
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r02_step_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("dominant_kernel_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic = traffic_source = None
+        for name in ("r03_step_traffic.json", "r02_step_traffic.json"):
+            pmc = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get("dominant_kernel_bytes_per_launch")
+                    traffic_source = "profiles/" + name + " (separate FETCH_SIZE / WRITE_SIZE passes of an earlier run, " \
+                                                          "one step at a time; NOT measured by this run)"
+                    break
+                except Exception:
+                    traffic = None
+        shared = roofline_entry(dom, cand.get(dom, dict(launches=0, ms=0.0, flops=0.0)))
         alone = None
         if one_prof is not None:
             key = "chain" if dom == "panels" else dom
@@ -650,28 +674,39 @@ def main():
                  "hbm_frac": by / (ms_per_step * 1e-3) / 1e12 / HBM_PEAK_TBS,
                  "note": "per GPU: S (K^3/3 + 2 M K^2 + 20 K^2) flop and 24 S K^2 bytes (SURVEY 8d) over "
                          "the timed ms_per_step (steps_in_flight steps share the GPU)"}
-        roof = roofline_entry(dom, cand.get(dom, dict(launches=0, ms=0.0, flops=0.0)), {
-            "traffic": traffic,
-            # with F > 1 the launches of F steps share the GPU: a launch's duration then includes
-            # the time its workgroups wait for CUs held by the other steps' kernels, so `frac` is
-            # that launch's share of the machine; the same kernel with the GPU to itself
-            # (one step at a time, every launch bracketed, measured in this run) is `alone`
+        # `frac` is the dominant kernel's fraction of the fp64 peak with the GPU to itself: one step at
+        # a time, every launch of the kernel under its own pair of HIP events on the launch stream,
+        # measured in this run (reproducible from the committed rocprofv3 kernel trace of the same
+        # command: flops / summed duration / 78.6e12).  With F steps in flight a launch shares the
+        # GPU with the other steps' kernels and its bracket includes the time its workgroups wait
+        # for CUs: that figure is `frac_shared`, a share of the machine, not an efficiency.
+        main = alone if alone else shared
+        rp_us, rp_src = rocprof_average_us("panel_kernel" if dom in ("panels", "chain") else "mm_nt_kernel")
+        roof = dict(main)
+        roof.update({
+            "measured": ("one step at a time, every launch under its own pair of HIP events on its stream"
+                         if alone else "in flight (no one-at-a-time leg in this run): a share of the machine"),
+            "algorithmic_flops_note": "per panel launch: S (2 rows 64 (64 q) + rows 64 64 + neager 64^3 + 64^3 / 3) -- "
+                                      "left-looking product, triangular solve, eager rank-64 updates, the diagonal "
+                                      "block (1.45e10 per 64-star K = 1000 step); the flops the look-ahead items "
+                                      "move from one launch to the one before are counted where the sum has them",
+            "rocprof_avg_launch_us": rp_us, "rocprof_source": rp_src,
+            "traffic": traffic, "traffic_source": traffic_source,
             "steps_in_flight": F,
+            "frac_shared": shared["frac"],
+            "shared": {"achieved": shared["achieved"], "launches": shared["launches"],
+                       "avg_launch_ms": shared["avg_launch_ms"],
+                       "note": "the same kernel in the timed region (one pair of events per super-panel)"},
             "event_ms_by_kind": {k: v["ms"] for k, v in timed_prof.items()},
-            "avg_launch_ms_note": "events on the launch stream: with several steps in flight a launch's bracket "
-                                  "includes the time its workgroups wait for CUs held by the other steps' kernels "
-                                  "(rocprofv3's kernel trace times a kernel from its first wavefront: "
-                                  "profiles/*_inflight_kernel_stats.csv shows ~25 % less); `per_launch` = every "
-                                  "launch under its own pair in an untimed repeat (the timed region uses one pair "
-                                  "per super-panel): same figure, so the grouping is not what differs; one step "
-                                  "at a time (`alone`) events and kernel trace agree",
-            "per_launch": (None if not launch_prof or not launch_prof["launches"] else {
+            "per_launch_shared": (None if not launch_prof or not launch_prof["launches"] else {
                 "launches": launch_prof["launches"],
                 "avg_launch_ms": launch_prof["ms"] / launch_prof["launches"],
                 "achieved": launch_prof["flops"] / (launch_prof["ms"] * 1e-3) / 1e12,
                 "frac": launch_prof["flops"] / (launch_prof["ms"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}),
-            "alone": alone,
-            "secondary": {k: roofline_entry(k, v) for k, v in cand.items() if k != dom},
+            "secondary": {k: {"shared": roofline_entry(k, v),
+                              "alone": (roofline_entry(k, one_prof[k]) if one_prof and one_prof.get(k, {}).get("launches", 0)
+                                        else None)}
+                          for k, v in cand.items() if k != dom},
             "whole_step": whole,
         })
         line = {

@@ -247,16 +247,6 @@ int sp_cholesky_rev(sp_handle *h, const double *L_dev, int K, long ldl,
                     long strideL, const double *Lbar_dev, int batch,
                     double *Cbar_dev, void *stream);
 
-/* How the blocked factorisation spends its launches (both give the same factor to rounding):
- *   0 (default)  two launches per 64-column panel -- the shortest critical path: for ONE
- *                evaluation at a time;
- *   1            one launch per panel (update + solve + next diagonal block together): a
- *                longer critical path but 18 % fewer bytes through HBM -- for several
- *                independent evaluations in flight on separate handles / streams, where the
- *                GPU is saturated and traffic is what counts.
- * The environment variable SP_ONELAUNCH sets the initial value.                          */
-int sp_set_panel_mode(sp_handle *h, int one_launch);
-
 /* ---- a16-a19 + fused driver: log-likelihood of an ensemble ---------------- */
 /* Size in bytes of the device workspace sp_lnlike_ensemble needs.            */
 long sp_lnlike_workspace_bytes(sp_handle *h, int S, int K, int M);
@@ -350,29 +340,16 @@ int sp_latitude_integrals(int ydeg, double alpha, double beta, double *q_host,
 int sp_profile_begin(sp_handle *h, int max_launches);
 int sp_profile_end(sp_handle *h, long *launches, double *total_ms, double *flops);
 /* The same for one KIND of launch of the factorisation (every launch is bracketed while
- * profiling is on): 0 symmetric trailing updates (what sp_profile_end reports), 1 strip solves
- * X = A L^-T, 2 the panel chain (diagonal blocks, block-column updates, panel solves),
- * 3 covariance assembly (row sums + assembly), 4 the one-launch-per-panel kernels of a whole
- * super-panel under ONE pair of events, 5 each of those kernels under its own pair.  Stops the
- * profile like sp_profile_end; may be called for several kinds in a row.                   */
+ * profiling is on): 0 symmetric trailing updates (what sp_profile_end reports), 2 every panel
+ * launch under its own pair of events (5: the same, kept apart so that both may be armed),
+ * 4 the panel launches of a whole super-panel under ONE pair (cheap enough for a timed region).
+ * Kinds 1 and 3 are not produced any more.  Scopes nest.  Stops the profile like sp_profile_end;
+ * may be called for several kinds in a row.                                                  */
 int sp_profile_kind(sp_handle *h, int kind, long *launches, double *total_ms, double *flops);
 /* sp_profile_begin for a chosen set of kinds (bit k of kind_mask = kind k; sp_profile_begin
- * = kind 0 only).  An event pair costs a few microseconds of stream time: bracket the panel
- * chain (32 launches per K = 1000 factorisation) only outside timed regions.             */
+ * = kind 0 only).  An event pair costs a few microseconds of stream time: bracket every panel
+ * launch (17 per K = 1000 factorisation) only outside timed regions.                      */
 int sp_profile_begin_kinds(sp_handle *h, int max_launches, unsigned kind_mask);
-
-/* Driver of the blocked factorisation (math.py:75-91), per handle:
- *   0 (default): super-panels of 8 panels, left-looking inside, one trailing update per
- *      super-panel (sp_set_panel_mode selects its one- or two-launch form);
- *   2: recursive -- diagonal blocks of SP_REC_BASE (8) panels factored panel by panel,
- *      everything between them one strip solve (X = A21 L11^-T, a long-lived workgroup per
- *      64-row strip) and one symmetric update per level.  Measured equal to mode 0 within 2 %
- *      at the north-star sizes, hence not the default;
- *   3: dataflow panel chain -- ONE launch per super-panel: every 64-row strip is a long-lived
- *      workgroup that walks the panels, ordered by flags in memory instead of kernel boundaries
- *      (every wait bounded).  Measured slower than mode 0 here: an experiment.
- * Results agree to rounding (different summation order).  Environment: SP_CHOL.             */
-int sp_set_chol_mode(sp_handle *h, int mode);
 
 /* Normalised likelihoods (sp.py:705-727: C = c1 Sigma + z ((alpha + beta) p p^T - alpha q q^T),
  * q = row sums / (K m)), per handle:
@@ -389,9 +366,8 @@ int sp_set_defer_norm(sp_handle *h, int on);
 
 /* Covariance tiles formed at first touch (default on; environment SP_LAZY_COV).  Under the deferred
  * normalisation a tile of the system below the diagonal is a pure function of the cadences'
- * phases (flux.py:256-276) until the factorisation first touches it: with this switch on, and a
- * handle in the one-launch-per-panel mode (sp_set_panel_mode) and no temporal kernel, the assembly takes those tiles'
- * row / column sums but does not write them, and the kernel that touches a tile first evaluates
+ * phases (flux.py:256-276) until the factorisation first touches it: with this switch on and no
+ * temporal kernel, the assembly takes those tiles' row / column sums but does not write them, and the kernel that touches a tile first evaluates
  * it instead of loading it -- the same code, the same bits, a write and a read of 3/4 of the
  * matrix less.  Diagonal tiles and the rows holding residuals are always written.            */
 int sp_set_lazy_cov(sp_handle *h, int on);
@@ -408,26 +384,14 @@ int sp_set_lazy_cov(sp_handle *h, int on);
 int sp_allgather_lnlike(sp_handle *h, void *nccl_comm, const double *local_dev, int count,
                         double *all_dev, void *stream);
 
-/* launch ONE phase (0 diagonal block, 1 panel solve, 2 trailing update, 3 timestamps
- * inside the diagonal-block kernel, 4 rank-256 update of the first super-panel, 5
- * sustained fp64 MFMA rate) of panel
- * step j on the systems left in `workspace_dev` by sp_lnlike_ensemble; used by
- * tools/microbench.py to time the kernels in isolation.                        */
-int sp_debug_cholesky_phase(sp_handle *h, int S, int K, int M, void *workspace_dev,
-                            int phase, int j, void *stream);
-
-/* Tile shape of the pipelined fp64 product (csrc/sp_mm.h) for every later launch of this
- * process: 0 = register-staged 64 x 64 kernel, 1 = 64 x 64 tiles, 16-deep slices, 4 LDS stages
- * (default), 2-8 = the other shapes tools/mm_bench.py compares.  Results do not depend on it
- * beyond the summation order.  Environment: SP_MM.                                        */
-int sp_debug_set_mm_variant(int variant);
-/* (debug) in-kernel wall-clock timestamps of the dataflow panel chain (sp_set_chol_mode 3): `buf` = device
- * buffer of (super-panels) x (Kp / 64) x 128 int64, or NULL to switch off.  tools/chain_trace.py */
-int sp_debug_chain_trace(sp_handle *h, void *buf);
-/* (debug) wall-clock stamps of the one-launch-per-panel kernel; only in a library built with
- * -DSP_PANEL_TRACE (tools/ab_build.sh), SP_ERR_INVALID otherwise.  out == NULL resets; else 64 x 4 x 16
- * int64 (launch, workgroup {pivot strip, strip 3}, stamp).  tools/panel_trace.py */
-int sp_debug_panel_trace(long long *out);
+/* (debug) the look-ahead items of the panel launches (csrc/sp_cholesky.hip) on (default; environment
+ * SP_PANEL_LA) or off: the factor is the same to rounding, the critical path of a panel is not.  */
+int sp_debug_set_look_ahead(sp_handle *h, int on);
+/* (debug) wall-clock stamps of the panel kernel (csrc/sp_panel.hip); only in a library built with
+ * -DSP_PANEL_TRACE (tools/ab_build.sh), SP_ERR_INVALID otherwise.  out == NULL resets; else
+ * 64 x 3 x 16 int64 (pivot block, work item of star 0 {diagonal block, first tile, last tile},
+ * stamp).  tools/panel2_trace.py                                                             */
+int sp_debug_panel2_trace(long long *out);
 
 #ifdef __cplusplus
 }

@@ -87,12 +87,9 @@ PROTOTYPES = {
     "sp_set_ylm_moments": (_I, [_V, _V, _V]),
     "sp_set_ylm_moments_dev": (_I, [_V, _V, _V, _V]),
     "sp_get_polar_moments": (_I, [_V, _V, _V]),
-    "sp_debug_cholesky_phase": (_I, [_V, _I, _I, _I, _V, _I, _I, _V]),
-    "sp_debug_set_mm_variant": (_I, [_I]),
-    "sp_debug_chain_trace": (_I, [_V, _V]),
-    "sp_debug_panel_trace": (_I, [_V]),
+    "sp_debug_panel2_trace": (_I, [_V]),
+    "sp_debug_set_look_ahead": (_I, [_V, _I]),
     "sp_profile_kind": (_I, [_V, _I, ctypes.POINTER(ctypes.c_long), c_double_p, c_double_p]),
-    "sp_set_chol_mode": (_I, [_V, _I]),
     "sp_set_lazy_cov": (_I, [_V, _I]),
     "sp_set_defer_norm": (_I, [_V, _I]),
     "sp_profile_begin_kinds": (_I, [_V, _I, ctypes.c_uint]),
@@ -109,7 +106,6 @@ PROTOTYPES = {
     "sp_tri_solve": (_I, [_V, _V, _I, _L, _L, _V, _I, _I, _I, _V]),
     "sp_solve_rev": (_I, [_V, _V, _I, _L, _L, _V, _V, _I, _I, _I, _V, _V, _V]),
     "sp_cholesky_rev": (_I, [_V, _V, _I, _L, _L, _V, _I, _V, _V]),
-    "sp_set_panel_mode": (_I, [_V, _I]),
     "sp_lnlike_workspace_bytes": (_L, [_V, _I, _I, _I]),
     "sp_lnlike_ensemble": (
         _I, [_V, _I, _I, _I, _V, _V, _V, _V, _I, _I, _V, _V, _V, _I, _I, _I, _D,

@@ -45,8 +45,6 @@ int sp_launch_cholesky_systems(sp_handle *h, double *sys, int S, int K, int Kp,
                                int32_t *info, double *invL, hipStream_t st);
 int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *grp, int K,
                               int Kp);
-int sp_debug_phase(sp_handle *h, double *sys, int S, int K, int Kp, int32_t *info,
-                   double *invL, int phase, int j, hipStream_t st);
 int sp_launch_lnlike_reduce(const double *sys, int S, int K, int M, int Kp,
                             const int32_t *info, double *lnlike, uint32_t *status,
                             hipStream_t st, uint32_t *status_out = nullptr,
@@ -425,17 +423,14 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
   h->cs_next = 0;
   h->superpanel = 0;
   h->groups = 1;
-  h->fuse_diag = 2;
   h->gfork = nullptr;
   h->prof_on = false;
   h->prof_mask = 1u;
   h->prof_used = 0;
-  h->chol_mode = 0;
-  h->rec_base = SP_REC_BASE_DEFAULT;
   h->defer_norm = 1;
   h->lazy_cov = 1;
-  h->panel2 = 1;
   h->ncu = 256;
+  h->look_ahead = 1;
   const int N = h->N;
   h->l_of.resize(N);
   h->m_of.resize(N);
@@ -472,29 +467,18 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
   SP_HIP(hipMemcpy(h->d_blk, h->blk.data(), sizeof(int32_t) * (ydeg + 2), hipMemcpyHostToDevice));
 
   {
-    const char *e4 = getenv("SP_FUSE_DIAG");
-    h->fuse_diag = e4 ? atoi(e4) : 2;  // 0 off, 1 block-column updates, 2 + bulk updates
-    const char *e5 = getenv("SP_EAGER");
-    h->eager = e5 ? atoi(e5) : 1;
-    const char *e7 = getenv("SP_ONELAUNCH");
-    h->onelaunch = e7 ? atoi(e7) : 0;
     const char *e3 = getenv("SP_GROUPS");
     h->groups = e3 ? atoi(e3) : 1;
     const char *e10 = getenv("SP_DEFER_NORM");
     h->defer_norm = e10 ? atoi(e10) : 1;
     const char *e11 = getenv("SP_LAZY_COV");
     h->lazy_cov = e11 ? atoi(e11) : 1;
-    const char *e9 = getenv("SP_REC_BASE");
-    h->rec_base = e9 ? atoi(e9) : SP_REC_BASE_DEFAULT;
-    if (h->rec_base < 1) h->rec_base = 1;
-    const char *e8 = getenv("SP_CHOL");
-    h->chol_mode = e8 ? atoi(e8) : 0;
-    const char *e12 = getenv("SP_PANEL2");
-    h->panel2 = e12 ? atoi(e12) : 1;
     {
       hipDeviceProp_t prop;
       h->ncu = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
     }
+    const char *e12 = getenv("SP_PANEL_LA");
+    h->look_ahead = e12 ? atoi(e12) : 1;
     const char *e2 = getenv("SP_SUPER");
     h->superpanel = e2 ? atoi(e2) : 0;   // 0: chosen from K (sp_launch_cholesky_groups)
     if (h->superpanel < 0) h->superpanel = 0;
@@ -527,7 +511,6 @@ void sp_destroy(sp_handle *h) {
   for (hipStream_t s2 : h->gstream) (void)hipStreamDestroy(s2);
   if (h->gfork) (void)hipEventDestroy(h->gfork);
   if (h->big_ptr) (void)hipFree(h->big_ptr);
-  if (h->chain_mem) (void)hipFree(h->chain_mem);
   for (auto &c : h->cs_ring) {
     if (c.host) (void)hipHostFree(c.host);
     if (c.dev) (void)hipFree(c.dev);
@@ -703,18 +686,10 @@ int sp_set_defer_norm(sp_handle *h, int on) {
   return SP_OK;
 }
 
-int sp_set_chol_mode(sp_handle *h, int mode) {
-  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
-  if (!h || (mode != 0 && mode != 2 && mode != 3)) return SP_ERR_INVALID;
-  h->chol_mode = mode;
-  return SP_OK;
-}
-
-// (debug, tools/chain_trace.py) device buffer of nlaunch x ntile x 128 int64 that the dataflow
-// chain fills with wall-clock timestamps of star 0's strips; null switches it off
-int sp_debug_chain_trace(sp_handle *h, void *buf) {
+// (debug) look-ahead items of the panel launches on / off (sp_cholesky.hip); results agree to rounding
+int sp_debug_set_look_ahead(sp_handle *h, int on) {
   if (!h) return SP_ERR_INVALID;
-  h->chain_dbg = (long long *)buf;
+  h->look_ahead = on ? 1 : 0;
   return SP_OK;
 }
 
@@ -961,13 +936,6 @@ int sp_cholesky_rev(sp_handle *h, const double *L_dev, int K, long ldl, long str
   return sp_launch_chol_rev_finish(P, L_dev, ldl, strideL, Cbar_dev, K, batch, st);
 }
 
-int sp_set_panel_mode(sp_handle *h, int one_launch) {
-  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
-  if (!h || (one_launch != 0 && one_launch != 1)) return SP_ERR_INVALID;
-  h->onelaunch = one_launch;
-  return SP_OK;
-}
-
 long sp_lnlike_workspace_bytes(sp_handle *h, int S, int K, int M) {
   if (!h || S < 0 || K < 1 || M < 1) return SP_ERR_INVALID;
   return (long)make_layout(h, S, K, M, true).total;
@@ -1028,14 +996,12 @@ int sp_lnlike_ensemble(sp_handle *h, int S, int K, int M, const double *t_dev,
                           at<double>(ws, LG[g].invL), s1 - s0, sg, LazyCov{}};
   }
   // Tiles formed at first touch (LazyCov, sp_cov.h): the marginal path under the deferred
-  // normalisation, factored by the one-launch-per-panel super-panel driver -- the configuration
-  // of handles that work several evaluations at a time.
+  // normalisation.
   int lazy_nfull = 0;
   // (not with a temporal kernel: its exp per entry, evaluated twice, costs more than the traffic
   //  it saves -- cfg5 shape: -2.5 %)
   if (h->lazy_cov && !conditional && temporal == SP_TEMPORAL_NONE && normalized && h->defer_norm && G == 1 &&
-      h->chol_mode == 0 &&
-      h->onelaunch && h->fuse_diag > 1 && h->eager && K / SP_NB >= 2 &&
+      K / SP_NB >= 2 &&
       (size_t)K * L.N >= 4 * (size_t)(covpts + 4) && 4 * (covpts + 4) <= SP_TILE_LDS_MIN) {
     lazy_nfull = K / SP_NB;
     CG[0].lazy = LazyCov{at<double>(ws, L.theta), t_dev, stars_dev, at<double>(ws, L.A), K, covpts,
@@ -1128,29 +1094,6 @@ int sp_allgather_lnlike(sp_handle *h, void *nccl_comm, const double *local_dev, 
   return fn(local_dev, all_dev, (size_t)count, nccl_float64, nccl_comm, (hipStream_t)stream) == 0
              ? SP_OK
              : SP_ERR_COMM;
-}
-
-// micro-benchmark hook (not part of the reference-facing API): one phase of one
-// panel step on the workspace systems of a previous sp_lnlike_ensemble call
-int sp_debug_cholesky_phase(sp_handle *h, int S, int K, int M, void *workspace_dev,
-                            int phase, int j, void *stream) {
-  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
-  if (!h || !workspace_dev || S < 1 || K < 1 || M < 1 || j < 0 || j * SP_NB >= K)
-    return SP_ERR_INVALID;
-  Layout L = make_layout(h, S, K, M, true);
-  return sp_debug_phase(h, at<double>(workspace_dev, L.sys), S, K, L.Kp,
-                        at<int32_t>(workspace_dev, L.info), at<double>(workspace_dev, L.invL),
-                        phase, j, (hipStream_t)stream);
-}
-
-int sp_debug_set_mm_variant(int variant) {
-  if (variant >= 100) {   // 100 + f: ablation flags of the strip solve (tools/strip_bench.py)
-    sp_set_strip_flags(variant - 100);
-    return SP_OK;
-  }
-  if (variant < 0 || variant > 16) return SP_ERR_INVALID;
-  sp_set_mm_variant(variant);
-  return SP_OK;
 }
 
 int sp_cholesky_lnlike_batched(sp_handle *h, int S, int K, int M,

@@ -1,30 +1,22 @@
-// Device routine shared by sp_cholesky.hip (stand-alone diagonal-block kernel)
-// and sp_gemm.hip (fused into the tile-(0,0) workgroup of a block-column update).
-//
-// diag_block(): Cholesky factor L of a 64 x 64 SPD block held in LDS, by one
-// 256-thread workgroup, and the operands of the panel solve that follows
-// (trsm_quad_kernel, sp_cholesky.hip): L^T and the reciprocal diagonal.
+// diag_block(): Cholesky factor L of a 64 x 64 SPD block held in LDS, by one 256-thread workgroup,
+// and its inverse L^-1, formed in the shadow of the factorisation (callers: panel_diag_core,
+// sp_paneldiag.h, which writes both out).
 //
 // The block is cut in four block columns of 16; wavefront w owns block column w.
-//   factor_panel(w): first the 16 x 16 diagonal leaf with lane = row (the four
-//     16-lane DPP rows carry the same copy): column c is scaled by 1 / sqrt(pivot)
-//     in every lane at once and the rank-1 step a_j -= l * l_j takes l_j from lane
-//     j by a DPP row broadcast (v_mov_b64_dpp row_newbcast) -- no LDS traffic, no
-//     scalar registers, no barrier inside the leaf.  Then the rows below the leaf,
-//     one per lane, by substitution against the leaf.  fp64 VALU and fp64 MFMA
-//     have the same peak on gfx950, so nothing is lost by leaving the matrix
-//     cores here; the leaf is a latency chain of ~130 cycles per column.
+//   factor_panel(w): the 16 x 16 diagonal leaf with lane = row (the four 16-lane DPP rows carry
+//     the same copy): column c is scaled by 1 / sqrt(pivot) in every lane at once and the rank-1
+//     step a_j -= l * l_j takes l_j from lane j by a DPP row broadcast (v_mov_b64_dpp
+//     row_newbcast) -- no LDS traffic, no scalar registers, no barrier inside the leaf.  fp64 VALU
+//     and fp64 MFMA have the same peak on gfx950, so nothing is lost by leaving the matrix cores
+//     here; the leaf is a latency chain of ~200 cycles per column.
 //   rows below the leaf: by all wavefronts, four lanes per row (below_quad).
-//   update: the tiles right of a published panel are updated on the MFMA from LDS; the
-//     owner of the next panel takes the one tile its leaf needs and starts factoring
-//     while the three other wavefronts share the rest.
-//   Two workgroup barriers per panel.
-// Critical path ~ 4 x (16 columns x ~130 cycles + ~1 us of update / LDS turn).
+//   update: the tiles right of a published panel are updated on the MFMA from LDS; the owner of
+//     the next panel takes the one tile its leaf needs and starts factoring while the three other
+//     wavefronts share the rest -- and form the finished block row of the inverse.
+//   Two workgroup barriers per panel.  12 us alone on a CU.
 //
-// LDS: sD[64 * BLD] (block in, L out in the lower part) + sRd[64] (1 / L_cc)
-// + 16 x 16 scaled leaf for the substitution.
-// `lt` (global, 64 x 64 row-major) receives  lt[k][c] = L[c][k] / L[c][c] for
-// c > k, 1 / L[k][k] for c == k, 0 for c < k.
+// LDS: sD[64 * BLD] (block in; L out in the lower part, L^-T in the upper) + sRd[64] (1 / L_cc,
+// which is also the diagonal of the inverse) + 16 x 16 scaled leaf for the substitution.
 #ifndef SP_DIAG_H
 #define SP_DIAG_H
 
@@ -283,21 +275,15 @@ __device__ __forceinline__ void inverse_block_row(double *sD, const double *sRd,
   for (int r = 0; r < 4; ++r) sD[(16 * j + i) * BLD + o + g + 4 * r] = R[r];   // Linv_cj[g + 4 r][n = i]
 }
 
-// All 256 threads of the workgroup call this with the block already in sD
-// (lower triangle valid, upper part mirrored or zero; see callers for the
-// identity padding of a partial block) and a barrier behind the stores.
-// Returns 1 in every thread of wavefronts that saw a non-positive pivot
-// (callers OR it through global memory).
-// (tid_in: a caller inside a long loop passes a laundered copy of threadIdx.x, sp_chain.hip)
-// inv_out (optional): L^-T of the block, row k column n = Linv[n][k] (64 x 64 row-major, zero
-// left of the diagonal), formed in the shadow of the factorisation as described above.
-// form_inv: build L^-1 in the upper triangle of sD / sRd even without inv_out (sp_paneldiag.h writes
-// it out in the fragment order of the panel kernel's solve).  lt may be null (no substitution image).
-__device__ __forceinline__ int diag_block(double *sD, double *sRd, double *__restrict__ lt,
-                                          long long *dbg = nullptr, int tid_in = threadIdx.x,
-                                          double *__restrict__ inv_out = nullptr, bool form_inv = false) {
+// All 256 threads of the workgroup call this with the block already in sD (lower triangle valid,
+// zero above it; see panel_diag_load for the identity padding of a partial block) and a barrier
+// behind the stores.  On return (behind a barrier) sD holds L below the diagonal, L^-T above it
+// (sD[r][c] = Linv[c][r] for r < c) and sRd the reciprocal diagonal.  Returns 1 in every thread of
+// wavefronts that saw a non-positive pivot (callers OR it through global memory).
+__device__ __forceinline__ int diag_block(double *sD, double *sRd, int tid_in = threadIdx.x,
+                                          long long *dbg = nullptr) {
   const int tid = tid_in, lane = tid & 63, wave = tid >> 6;
-  const bool inv = form_inv || inv_out != nullptr;
+  const bool inv = true;
   int notpd = 0;
 #pragma unroll 1
   for (int kb = 0; kb < 4; ++kb) {
@@ -347,22 +333,9 @@ __device__ __forceinline__ int diag_block(double *sD, double *sRd, double *__res
     }
     if (dbg && wave == (kb < 3 ? kb + 1 : 3) && lane == 0) dbg[8 * kb + 6] = clock64();
   }
-  if (inv) {
-    // the last block row (nothing left to hide it behind), then the whole of L^-T
-    inverse_block_row(sD, sRd, 3, wave == 3, wave < 3 ? wave : -1, lane);
-    __syncthreads();
-    if (inv_out)
-      for (int e = tid; e < 4096; e += 256) {
-        const int k = e >> 6, c = e & 63;
-        inv_out[e] = c > k ? sD[k * BLD + c] : (c == k ? sRd[k] : 0.0);
-      }
-  }
-  // operands of the panel solve: L^T with the reciprocal diagonal
-  if (lt)
-    for (int e = tid; e < 4096; e += 256) {
-      const int k = e >> 6, c = e & 63;
-      lt[e] = c > k ? sD[c * BLD + k] * sRd[c] : (c == k ? sRd[k] : 0.0);
-    }
+  // the last block row of the inverse (nothing left to hide it behind)
+  inverse_block_row(sD, sRd, 3, wave == 3, wave < 3 ? wave : -1, lane);
+  __syncthreads();
   return notpd;
 }
 

@@ -60,22 +60,13 @@ struct sp_handle {
   int cs_next;
   int superpanel;               // panels per super-panel (SP_SUPER; 0 = chosen from K)
   int groups;                   // concurrent star groups (SP_GROUPS, default 1)
-  int fuse_diag;                // fuse the diagonal-block factorisation into the block-column update
-  int eager;                    // panel solves keep the coming diagonal blocks up to date (SP_EAGER)
-  int onelaunch;                // update + solve + eager + next diagonal block in ONE launch per panel (SP_ONELAUNCH)
-  int panel2;                   // ... with the round-3 panel kernel (sp_panel.hip; SP_PANEL2, default 1)
   int ncu;                      // compute units of the device
+  int look_ahead;               // panel launches carry a look-ahead item (sp_cholesky.hip; SP_PANEL_LA, default 1)
   std::vector<hipStream_t> gstream;
   std::vector<hipEvent_t> gdone;
   hipEvent_t gfork;
-  int chol_mode;                // 0: super-panel driver, 2: recursive driver (strip solves), 3: dataflow chain (SP_CHOL)
-  int rec_base;                 // recursive driver: panels per base block
   int defer_norm;               // likelihood path: deferred normalisation (SP_DEFER_NORM, default 1)
-  int lazy_cov;                 // ... with covariance tiles formed at first touch where the driver can (SP_LAZY_COV, default 1)
-  // dataflow panel chain (chol_mode 3, sp_chain.hip): flags, tickets and the abort word
-  int *chain_mem;
-  size_t chain_ints;
-  long long *chain_dbg;         // (debug) caller's buffer for in-kernel timestamps, or null
+  int lazy_cov;                 // ... with covariance tiles formed at first touch (SP_LAZY_COV, default 1)
   // optional per-launch timing of the factorisation's launches by kind (bench roofline)
   bool prof_on;
   unsigned prof_mask;                // kinds that are bracketed (bit k = kind k)
@@ -86,13 +77,12 @@ struct sp_handle {
   size_t prof_used;                  // events handed out so far
 };
 
-// kinds of timed launches (sp_profile_kind)
-// SP_PROF_PANELS: the one-launch-per-panel kernels of a whole super-panel under ONE pair of events
-// (cheap enough for a timed region: 2 pairs per K = 1000 factorisation)
+// kinds of timed launches (sp_profile_kind; 1 and 3 were round 2's strip solves and assembly)
+// SP_PROF_PANELS: the panel kernels of a whole super-panel under ONE pair of events (cheap enough
+// for a timed region: 2 pairs per K = 1000 factorisation); SP_PROF_CHAIN and SP_PROF_PANEL_LAUNCH:
+// every panel launch under its own pair (comparable with rocprofv3's durations)
 enum {
-  SP_PROF_SYRK = 0, SP_PROF_STRIP = 1, SP_PROF_CHAIN = 2, SP_PROF_ASSEMBLE = 3, SP_PROF_PANELS = 4,
-  SP_PROF_PANEL_LAUNCH = 5,   // every one-launch-per-panel kernel under its own pair (comparable with rocprofv3's durations)
-  SP_PROF_NKINDS = 6
+  SP_PROF_SYRK = 0, SP_PROF_CHAIN = 2, SP_PROF_PANELS = 4, SP_PROF_PANEL_LAUNCH = 5, SP_PROF_NKINDS = 6
 };
 
 // brackets the launches issued during its lifetime with a pair of events on `st`.  Scopes nest (the
@@ -134,28 +124,6 @@ struct SpProfScope {
   SpProfScope(const SpProfScope &) = delete;
   SpProfScope &operator=(const SpProfScope &) = delete;
 };
-
-// one-launch-per-panel kernel (sp_gemm.hip): the panel solve by substitution on the vector ALU, four
-// lanes per row (0, default), or as a product against L_d^-T on the matrix cores (1: the workgroup
-// that factors a block also inverts it; measured: solve + image 9-13 us -> 4-6 us per workgroup,
-// +4.4 us on the tail of every launch, 0.98 -> 1.01 ms alone, +-1 % with three steps in flight;
-// 2: as a block substitution with the four 16 x 16 leaves inverted: 1.02 ms alone, -4 % in flight)
-#ifndef SP_PANEL_MFMA_SOLVE
-#define SP_PANEL_MFMA_SOLVE 0
-#endif
-
-// strip solve: at most this many 64-column blocks per launch (wider triangles are split)
-#define SP_STRIP_MAXB 8
-// diagonal blocks of at most this many panels are factored panel by panel (h->rec_base; SP_REC_BASE)
-#define SP_REC_BASE_DEFAULT 8
-// inv_first: L_d^-T of the first column block (those of the following blocks 8192 doubles apart)
-int sp_launch_strip(double *sys, long ld, long stride, int batch, int r0, int nrt, int c0, int nb,
-                    const double *inv_first, long lts, hipStream_t st);
-// dataflow panel chain of one super-panel (sp_chain.hip): pivot blocks s0 .. s0 + wq - 1
-size_t sp_chain_mem_ints(int S, int ntile, int nlaunch);
-int sp_launch_chain(double *sys, long ld, long stride, int S, int ntile, int s0, int wq, int nsteps,
-                    int nact_last, double *img, long lts, int *flags, int *tickets, int *abort_flag,
-                    int32_t *info, long long *dbg, hipStream_t st);
 
 const char *sp_set_hip_error(hipError_t e, const char *what);
 
@@ -226,14 +194,8 @@ int sp_launch_dotRx(sp_handle *h, const double *M, long strideM, long rs,
 int sp_launch_polar_moments(sp_handle *h, const double *mu_src, const double *cov_src,
                             hipStream_t st);
 
-// C[b] (+)= alpha * A[b] . B[b]^T  on 64x64 tiles with fp64 MFMA.
-//   A: Mrows x Kd (lda), B: Nrows x Kd (ldb), C: Mrows x Nrows (ldc)
-//   beta is 0 or 1;  lower_only: only tiles with tile_i >= tile_j are touched
-//   Mrows, Nrows multiples of 64; Kd multiple of 4.
-int sp_launch_panel(const double *A, long lda, const double *B, long ldb, double *C, long ldc,
-                    long stride, int Mrows, int Kd, int batch, const double *lt_in, double *lt_out,
-                    long lts, int neager, int next_nact, int32_t *info, hipStream_t st,
-                    const LazyCov *lazy = nullptr);
+// C[b] (+)= alpha * A[b] . B[b]^T  on the matrix cores (sp_gemm.hip): A: Mrows x Kd (lda), B: Nrows x Kd
+// (ldb), C: Mrows x Nrows (ldc); beta is 0 or 1; lower_only: only tiles with tile_i >= tile_j.
 int sp_launch_tri_solve(const double *L, int K, long ldl, long strideL, double *B, long strideB,
                         long rs, long cs, int nrhs, int batch, int mode, hipStream_t st);
 int sp_launch_transpose(const double *in, long ldi, long stridei, double *out, int K, int batch,
@@ -258,19 +220,7 @@ int sp_launch_panel2(double *sys, long ld, long stride, int S, int ntile, int j,
 int sp_launch_syrk_diag(const double *X, long ld, long stride, double *T, int n, int kd, int batch,
                         hipStream_t st, const LazyCov *lazy, const DiagFuse *df);
 
-void sp_set_mm_variant(int v);
-void sp_set_strip_flags(int f);  // ablations of the strip solve (sp_strip.hip)   // tile shape of the pipelined product (sp_gemm.hip)
-
-int sp_launch_gemm_nt_diag(const double *A, long lda, long strideA, const double *B, long ldb,
-                           long strideB, double *C, long ldc, long strideC, int Mrows,
-                           int Nrows, int Kd, double alpha, int lower_only, int batch,
-                           int nact, double *invL, long lts, int32_t *info, hipStream_t st,
-                           int skip00 = 0);
-
-// per-star scratch of the factorisation: one L_d^T image (64 x 64 doubles) per 64-column block
-// of the padded system, at least two (the ping-pong of the one-launch-per-panel mode).  Doubles.
-// (two images per block: L_d^T for the substitution solves and L_d^-T for the strip solves)
-// (at least two blocks: the one-launch-per-panel mode ping-pongs between two (image, inverse) pairs)
-static inline long sp_lt_stride(int Kp) { const long nb = Kp / SP_NB; return (nb < 2 ? 2 : nb) * 8192L; }
+// per-star scratch of the factorisation: two image slots (sp_tile.h: SP_LT_IMG doubles each).  Doubles.
+static inline long sp_lt_stride(int) { return 2 * 4096L; }
 
 #endif

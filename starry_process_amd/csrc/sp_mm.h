@@ -48,165 +48,10 @@ __device__ __forceinline__ void mm_wait_vmcnt() {
 }
 
 // TM, TN: tile edges (multiples of 16 WR / 16 WC); BK: slice depth (8, 16 or 32);
-// NS: LDS stages (>= 2); WR: wavefronts along the rows (1, 2 or 4)
-template <int TM, int TN, int BK, int NS, int WR>
-struct MM {
-  static constexpr int TM_ = TM, TN_ = TN;
-  static constexpr int WC = 4 / WR;
-  static constexpr int MA = TM / (16 * WR), NA = TN / (16 * WC);
-  static constexpr int G = BK / 2;        // 16-byte granules per row of a slice
-  static constexpr int RPI = 64 / G;      // rows covered by one DMA wave-instruction (1 KiB)
-  static constexpr int RPB = 32 / BK;     // rows per 256-byte LDS bank row
-  static constexpr int IA = TM / RPI, IB = TN / RPI;   // wave-instructions per slice
-  static constexpr int LA = IA / 4, LB = IB / 4;       // ... per wavefront
-  static constexpr int LPW = LA + LB;
-  static constexpr int STAGE_A = TM * BK, STAGE_B = TN * BK, STAGE = STAGE_A + STAGE_B;
-  static constexpr int LDS_DOUBLES = NS * STAGE;
-  static_assert(BK == 8 || BK == 16 || BK == 32, "slice depth");
-  static_assert(IA % 4 == 0 && IB % 4 == 0, "a slice must split evenly over four wavefronts");
-  static_assert(TM % (16 * WR) == 0 && TN % (16 * WC) == 0, "tile / wavefront arrangement");
-
-  // swizzle of the granule index: rows that share a bank row or are read together get
-  // different granule positions
-  __device__ static __forceinline__ int swz(int row) { return (row / RPB) & (G - 1); }
-
-  // per-lane state
-  const double *srcA[LA > 0 ? LA : 1];    // source of this lane's 16 bytes of each DMA, at k = 0
-  const double *srcB[LB > 0 ? LB : 1];
-  int rdA, rdB;                            // fragment read offsets (doubles) without the granule term
-  int fsw, hsel, esel;                     // lane's swizzle, granule half (lane >> 5), element (lane >> 4) & 1
-  int wave;
-
-  // A: rows row0A.. of a matrix with leading dimension lda (doubles); B likewise
-  __device__ __forceinline__ void init(const double *A, long lda, const double *B, long ldb) {
-    const int lane = threadIdx.x & 63;
-    wave = threadIdx.x >> 6;
-    const int r = lane / G, p = lane % G;
-#pragma unroll
-    for (int i = 0; i < LA; ++i) {
-      const int row = (wave + 4 * i) * RPI + r;
-      srcA[i] = A + (size_t)row * lda + 2 * (p ^ swz(row));
-    }
-#pragma unroll
-    for (int i = 0; i < LB; ++i) {
-      const int row = (wave + 4 * i) * RPI + r;
-      srcB[i] = B + (size_t)row * ldb + 2 * (p ^ swz(row));
-    }
-    const int wr = wave / WC, wc = wave % WC;
-    const int fr = lane & 15;
-    rdA = (wr * (TM / WR) + fr) * BK;
-    rdB = STAGE_A + (wc * (TN / WC) + fr) * BK;
-    fsw = swz(fr);          // (multiples of 16 rows do not change the swizzle)
-    hsel = lane >> 5;
-    esel = (lane >> 4) & 1;
-  }
-
-  // start the DMA of the slice at column k0 into stage `st` of `lds`
-  __device__ __forceinline__ void issue(double *lds, int st, int k0) const {
-    double *base = lds + st * STAGE;
-#pragma unroll
-    for (int i = 0; i < LA; ++i)
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void *)(srcA[i] + k0),
-          (__attribute__((address_space(3))) void *)(base + (wave + 4 * i) * 128), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < LB; ++i)
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void *)(srcB[i] + k0),
-          (__attribute__((address_space(3))) void *)(base + STAGE_A + (wave + 4 * i) * 128), 16, 0, 0);
-  }
-
-  // multiply the slice held by stage `st`
-  __device__ __forceinline__ void consume(const double *lds, int st, mm_d4 (&acc)[MA][NA]) const {
-    const double *base = lds + st * STAGE;
-#pragma unroll
-    for (int s = 0; s < BK / 4; ++s) {
-      const int goff = 2 * ((2 * s + hsel) ^ fsw) + esel;
-      double a[MA], b[NA];
-#pragma unroll
-      for (int m = 0; m < MA; ++m) a[m] = base[rdA + m * 16 * BK + goff];
-#pragma unroll
-      for (int n = 0; n < NA; ++n) b[n] = base[rdB + n * 16 * BK + goff];
-#pragma unroll
-      for (int m = 0; m < MA; ++m)
-#pragma unroll
-        for (int n = 0; n < NA; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
-    }
-  }
-
-  // acc += A[:, k_begin : k_end] . B[:, k_begin : k_end]^T; k_end - k_begin a multiple of BK.
-  // Every thread of the workgroup calls prologue() then loop() with the same arguments (other
-  // work -- fetching the C tile, say -- may sit between the two: the first NS - 1 slices are
-  // then already on their way).  loop() begins and ends with the workgroup in step: a barrier
-  // follows the last slice, so `lds` may be reused at once.
-  __device__ __forceinline__ void prologue(double *lds, int k_begin, int k_end) const {
-    const int nsl = (k_end - k_begin) / BK;
-#pragma unroll
-    for (int p = 0; p < NS - 1; ++p)
-      if (p < nsl) issue(lds, p, k_begin + p * BK);
-  }
-  __device__ __forceinline__ void loop(double *lds, int k_begin, int k_end, mm_d4 (&acc)[MA][NA]) const {
-    const int nsl = (k_end - k_begin) / BK;
-    if (nsl <= 0) return;
-    int st = 0, stn = NS - 1;
-    for (int s = 0; s < nsl; ++s) {
-      // slice s has landed once at most the NS - 2 younger slices are outstanding
-      if (s + NS - 2 < nsl)
-        mm_wait_vmcnt<(NS - 2) * LPW>();
-      else
-        mm_wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      if (s + NS - 1 < nsl) issue(lds, stn, k_begin + (s + NS - 1) * BK);
-      consume(lds, st, acc);
-      st = st + 1 == NS ? 0 : st + 1;
-      stn = stn + 1 == NS ? 0 : stn + 1;
-    }
-    __builtin_amdgcn_s_barrier();
-  }
-  // (ablation for the microbenchmarks: the same product with every slice fetched from the first
-  //  BK columns -- operands that stay in L2 -- results are garbage)
-  __device__ __forceinline__ void prologue_same(double *lds, int kd) const {
-    const int nsl = kd / BK;
-#pragma unroll
-    for (int p = 0; p < NS - 1; ++p)
-      if (p < nsl) issue(lds, p, 0);
-  }
-  __device__ __forceinline__ void loop_same(double *lds, int kd, mm_d4 (&acc)[MA][NA]) const {
-    const int nsl = kd / BK;
-    if (nsl <= 0) return;
-    int st = 0, stn = NS - 1;
-    for (int s = 0; s < nsl; ++s) {
-      if (s + NS - 2 < nsl)
-        mm_wait_vmcnt<(NS - 2) * LPW>();
-      else
-        mm_wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      if (s + NS - 1 < nsl) issue(lds, stn, 0);
-      consume(lds, st, acc);
-      st = st + 1 == NS ? 0 : st + 1;
-      stn = stn + 1 == NS ? 0 : stn + 1;
-    }
-    __builtin_amdgcn_s_barrier();
-  }
-  __device__ __forceinline__ void run(double *lds, int k_begin, int k_end, mm_d4 (&acc)[MA][NA]) const {
-    prologue(lds, k_begin, k_end);
-    loop(lds, k_begin, k_end, acc);
-  }
-
-  // accumulator element (m, n, r) is C[row, col] with:
-  __device__ __forceinline__ int acc_row(int m, int r) const {
-    const int lane = threadIdx.x & 63;
-    return (wave / WC) * (TM / WR) + 16 * m + (lane >> 4) + 4 * r;
-  }
-  __device__ __forceinline__ int acc_col(int n) const {
-    const int lane = threadIdx.x & 63;
-    return (wave % WC) * (TN / WC) + 16 * n + (lane & 15);
-  }
-};
-
-// ---- second form: 16-byte fragment reads, fragments double-buffered in registers ---------------
-// Same DMA pipeline and LDS image as MM.  Differences on the consuming side:
+// NS: LDS stages (>= 3); WR: wavefronts along the rows (1, 2 or 4).
+// (Round 2 measured a first form, MM, that read 8-byte fragments from the same LDS image just in time
+//  -- 0.58 / 0.70 of peak where this one reaches 0.62 / 0.81 -- and a wave-tile form without LDS, WT:
+//  both are in the git history, tools/mm_bench.py of round 2 compared them.)  On the consuming side:
 //   * the MFMA sums over its 4 k-entries whatever their order as long as A and B agree, so lane
 //     (r = lane & 15, q = lane >> 4) takes the k-PAIR {8 c + 2 q, 8 c + 2 q + 1} of each 8-column
 //     chunk c with ONE ds_read_b128 and feeds two MFMAs with it (.x then .y): half the LDS

@@ -97,7 +97,7 @@ struct PanelArgs {
   int last;            // row tiles i <= last keep their own diagonal tile up to date
   int mode;
   int pair;            // row tiles below the next pivot row tile are dealt in pairs (128-row items)
-  double *img;         // per star `lts` doubles: image slots at 0 and 2 SP_LT_IMG
+  double *img;         // per star `lts` doubles: two image slots (sp_tile.h)
   long lts;
   int32_t *info;
   LazyCov lz;
@@ -124,7 +124,7 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
   const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fk = lane >> 4;
   const long ld = a.ld;
   const int Kd = 64 * (kb1 - kb0);
-  const double *img = img_star + (size_t)(a.j & 1) * 2 * SP_LT_IMG;
+  const double *img = img_star + (size_t)(a.j & 1) * SP_LT_IMG;
 #ifdef SP_PANEL_TRACE
   const int role = i0 == a.j + 1 ? 1 : (i0 + NR == a.ntile ? 2 : -1);
 #endif
@@ -320,11 +320,11 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
       __builtin_amdgcn_s_setprio(3);
       P2_STAMP(0, 0);
 #ifdef SP_PANEL_TRACE
-      panel_diag_core(Dt, ld, nact, img_star + (size_t)((a.j + 1) & 1) * 2 * SP_LT_IMG,
+      panel_diag_core(Dt, ld, nact, img_star + (size_t)((a.j + 1) & 1) * SP_LT_IMG,
                       a.info ? a.info + mtx : nullptr, smem, tid, nullptr, nullptr,
                       (mtx == 0 && a.j < 64) ? &g_p2trace[(a.j * 3) * 16 + 8] : nullptr);
 #else
-      panel_diag_core(Dt, ld, nact, img_star + (size_t)((a.j + 1) & 1) * 2 * SP_LT_IMG,
+      panel_diag_core(Dt, ld, nact, img_star + (size_t)((a.j + 1) & 1) * SP_LT_IMG,
                       a.info ? a.info + mtx : nullptr, smem, tid);
 #endif
       __builtin_amdgcn_s_setprio(0);
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256, P_WGS) void panel_kernel(PanelArgs a) {
   double *img_star = a.img + (size_t)mtx * a.lts;
   if (strip < nd) {
     P2_STAMP(0, 0);
-    double *img = img_star + (size_t)(a.j & 1) * 2 * SP_LT_IMG;
+    double *img = img_star + (size_t)(a.j & 1) * SP_LT_IMG;
 #ifdef SP_PANEL_TRACE
     panel_diag_item(M, a.ld, a.j, a.nact, img, a.info ? a.info + mtx : nullptr, smem, tid, nullptr, nullptr,
                     (mtx == 0 && a.j < 64) ? &g_p2trace[(a.j * 3) * 16 + 8] : nullptr);

@@ -21,7 +21,7 @@
 #ifndef SP_PANELDIAG_H
 #define SP_PANELDIAG_H
 
-#include "sp_diag.h"
+#include "sp_tile.h"
 
 #define SP_IMG_DOUBLES 2560   // ten fragment-ordered 16 x 16 blocks
 
@@ -72,7 +72,7 @@ __device__ __forceinline__ void panel_diag_core(double *D, long ld, int nact, do
   double *sD = lds, *sRd = lds + 64 * BLD;
   __syncthreads();
   if (dbg && tid == 0) dbg[0] = wall_clock64();
-  const int notpd = diag_block(sD, sRd, nullptr, nullptr, tid, nullptr, true);
+  const int notpd = diag_block(sD, sRd, tid);
   if (dbg && tid == 0) dbg[1] = wall_clock64();
   if (notpd && info_star) *info_star = 1;
   // (diag_block ends on a barrier behind the last block row of the inverse: sD / sRd are final)

@@ -251,12 +251,12 @@ class Engine(object):
         self._moments_owner = None
         check(self._L.sp_set_ylm_moments_dev(self._h, self._p(mean_ylm), self._p(cov_ylm), self._stream()))
 
-    PROF_KINDS = {"syrk": 0, "strip": 1, "chain": 2, "assemble": 3, "panels": 4, "panel_launch": 5}
+    PROF_KINDS = {"syrk": 0, "chain": 2, "panels": 4, "panel_launch": 5}
 
     def profile_begin(self, max_launches, kinds=("syrk",)):
         """Bracket the factorisation's launches of the given kinds with HIP events on their stream
-        ("syrk" trailing updates, "strip" strip solves, "chain" every launch of the panel chain,
-        "panels" the one-launch-per-panel kernels of a super-panel under ONE pair of events)."""
+        ("syrk" trailing updates, "chain" / "panel_launch" every panel launch under its own pair,
+        "panels" the panel launches of a super-panel under ONE pair of events)."""
         mask = 0
         for k in kinds:
             mask |= 1 << self.PROF_KINDS[k]
@@ -359,13 +359,9 @@ class Engine(object):
         check(self._L.sp_cho_solve(self._h, self._p(Lb), K, K, K * K, self._p(bb), nrhs, B, self._stream()))
         return bb.reshape(shape)
 
-    def set_chol_mode(self, mode):
-        """0: super-panel driver (default), 2: recursive driver with strip solves, 3: dataflow panel chain."""
-        check(self._L.sp_set_chol_mode(self._h, int(mode)))
-
     def set_lazy_cov(self, on):
-        """Covariance tiles formed at first touch by the factorisation (default on; effective in the
-        one-launch-per-panel mode under the deferred normalisation)."""
+        """Covariance tiles formed at first touch by the factorisation (default on; effective under
+        the deferred normalisation, without a temporal kernel)."""
         check(self._L.sp_set_lazy_cov(self._h, int(bool(on))))
 
     def set_defer_norm(self, on):
@@ -374,11 +370,6 @@ class Engine(object):
         Invalidates the cached workspace size."""
         check(self._L.sp_set_defer_norm(self._h, int(bool(on))))
         self._ws = None
-
-    def set_panel_mode(self, one_launch):
-        """False: two launches per panel (shortest critical path, one evaluation at a time);
-        True: one launch per panel (least HBM traffic, several evaluations in flight)."""
-        check(self._L.sp_set_panel_mode(self._h, int(bool(one_launch))))
 
     def tri_solve(self, L, b, trans=False):
         """L^-1 b (trans False) or L^-T b (trans True); shapes as in cho_solve."""
@@ -510,11 +501,10 @@ def engine_slots(ydeg=15, udeg=2, device=None, depth=3):
     INDEPENDENT evaluations in flight (the walkers / live points a sampler evaluates per
     iteration): run evaluation i inside ``with torch.cuda.stream(stream_i)`` on ``engine_i``,
     each with its own workspace and outputs.  One evaluation alone leaves most of the GPU idle
-    during its latency-bound phases (diagonal blocks, panel solves); with three in flight those
-    overlap the neighbours' assembly and trailing updates: 1.02 -> 0.75 ms per 64-star step
-    (bench.py).  A handle is not re-entrant, hence one per slot (fresh handles in
-    the one-launch-per-panel mode; the process-wide engine of ``get_engine`` is left as it is,
-    and is what depth = 1 returns)."""
+    during its latency-bound phases (the chain of diagonal blocks); with three in flight those
+    overlap the neighbours' assembly and trailing updates: 0.95 -> 0.66 ms per 64-star step
+    (bench.py).  A handle is not re-entrant, hence one per slot (fresh handles; the
+    process-wide engine of ``get_engine`` is left as it is, and is what depth = 1 returns)."""
     torch = _torch()
     first = get_engine(ydeg, udeg, device)
     depth = max(1, int(depth))
@@ -523,10 +513,6 @@ def engine_slots(ydeg=15, udeg=2, device=None, depth=3):
     out = []
     for k in range(depth):
         e = Engine(first.ydeg, first.udeg, first.device_index)
-        if os.environ.get("SP_ONELAUNCH") is None:
-            # several evaluations in flight saturate the GPU: spend launches for traffic, not
-            # latency (include/starry_process_amd.h: sp_set_panel_mode)
-            e.set_panel_mode(True)
         out.append((e, torch.cuda.Stream(device=e.device)))
     return out
 

@@ -1,20 +1,18 @@
 """
-GPU parity of the fused log-likelihood path under EVERY factorisation driver and panel mode, at
-the BASELINE sizes ("close the pytest holes"):
+GPU parity of the fused log-likelihood path -- assembly, blocked factorisation (sp_panel.hip panel
+kernel, trailing updates), reduction -- at the BASELINE sizes and on awkward ones:
 
-  * super-panel driver in its two-launch and one-launch-per-panel forms (sp_set_panel_mode) at
-    K = 1000 with the full 64-star batch of cfg3 and at K = 3000 (cfg5), against the golden
-    values of the executed reference (tests/golden/lnlike.npz) and against each other;
-  * the dataflow panel chain (sp_set_chol_mode 3: one launch per super-panel, workgroups ordered
-    by flags in memory) on the same, with every one of its waits bounded;
-  * the recursive driver with its strip-solve kernel (sp_set_chol_mode 2) on the same, plus a
-    sweep of awkward sizes (partial last block, residual rows spilling into blocks of their own,
-    fewer panels than a base block) against the super-panel driver;
-  * the cfg5 share of one GPU (32 stars, ydeg 20, K 3000, Matern-3/2, u = [0.4, 0.2]);
-  * three K = 1000, 64-star steps in flight on three (handle, stream) pairs.
+  * cfg3's full 64-star batch (ydeg 15, K 1000) and cfg5's 32-star share of a GPU (ydeg 20, K 3000,
+    Matern-3/2, u = [0.4, 0.2]): EVERY star against the value the executed reference gave for it
+    (tests/golden/lnlike_full.npz, make_golden.py gen_lnlike_full), and a star's
+    value independent of the batch it is evaluated in, bit for bit;
+  * a sweep of sizes with partial last blocks, residual rows in the last pivot block's rows or in
+    blocks of their own, single blocks, batches of 1 ... 64 stars (items dealt to XCDs unevenly),
+    128-row pair items and the look-ahead on or off: against the CPU oracle's factorisation;
+  * covariance tiles formed at first touch against the materialised assembly (identical bits);
+  * the deferred normalisation against the direct form; failure semantics; three steps in flight.
 
-North-star bar: fp64 log_likelihood within 1e-8 relative of the reference; drivers among
-themselves: 1e-10 (they differ in summation order only).
+North-star bar: fp64 log_likelihood within 1e-8 relative of the reference.
 """
 import numpy as np
 import pytest
@@ -24,18 +22,14 @@ from starry_process_amd.synthetic import synthetic_star
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-8
-TOL_DRIVERS = 1e-10
 
 
-def make_engine(L, chol=0, panel=0):
-    from starry_process_amd._lib import check
+def make_engine(L):
     from starry_process_amd.engine import Engine
 
     e = Engine(L, 2, 0)
     mom = golden("moments_L%d" % L)
     e.set_moments(mom["default_mean_ylm"], mom["default_cov_ylm"])
-    check(e._L.sp_set_chol_mode(e._h, chol))
-    e.set_panel_mode(bool(panel))
     return e
 
 
@@ -43,16 +37,12 @@ def make_engine(L, chol=0, panel=0):
 def engines():
     cache = {}
 
-    def get(L, chol, panel):
-        key = (L, chol, panel)
-        if key not in cache:
-            cache[key] = make_engine(L, chol, panel)
-        return cache[key]
+    def get(L):
+        if L not in cache:
+            cache[L] = make_engine(L)
+        return cache[L]
 
     return get
-
-
-MODES = [(0, 0), (0, 1), (2, 0), (3, 0)]   # (chol_mode, panel_mode); 3: dataflow chain (sp_chain.hip)
 
 
 def lnl(e, K, idx, tspan=4.0, u=(0.0, 0.0), tau=None, M=1, data_var=None):
@@ -74,78 +64,96 @@ def lnl(e, K, idx, tspan=4.0, u=(0.0, 0.0), tau=None, M=1, data_var=None):
     return out.cpu().numpy(), status.cpu().numpy()
 
 
-def test_cfg3_full_batch_every_driver(engines):
-    """64 stars, ydeg 15, K 1000: golden stars within 1e-8 of the reference, a star's value
-    independent of the batch (bit for bit), drivers within 1e-11 of one another."""
-    g = golden("lnlike")
-    gs = [int(s) for s in g["cfg2_L15_K1000_stars"]]
-    res = {}
-    for chol, panel in MODES:
-        e = engines(15, chol, panel)
-        v, st = lnl(e, 1000, range(64))
-        assert not st.any() and np.all(np.isfinite(v))
-        assert np.max(np.abs(v[gs] / g["cfg2_L15_K1000"] - 1)) < TOL, (chol, panel)
-        # SURVEY Appendix B anchor (star 0's period, RandomState(0) noise) is a different light curve;
-        # the batch-independence property: the same stars alone / in a smaller batch
-        v8, _ = lnl(e, 1000, range(8))
-        assert np.array_equal(v8, v[:8]), (chol, panel)
-        v1, _ = lnl(e, 1000, [63])
-        assert v1[0] == v[63], (chol, panel)
-        res[(chol, panel)] = v
-    ref = res[MODES[0]]
-    for k, v in res.items():
-        assert np.max(np.abs(v / ref - 1)) < TOL_DRIVERS, k
+def oracle_lnl(K, idx, M=1):
+    """The CPU oracle (NumPy / SciPy restatement of sp.py:1052-1188) on the same stars."""
+    from oracle.sp_oracle import OracleProcess
+
+    mom = golden("moments_L15")
+    op = OracleProcess(mom["default_mean_ylm"], mom["default_cov_ylm"], ydeg=15)
+    vals = []
+    for s in idx:
+        st = synthetic_star(int(s), K)
+        if M == 1:
+            flux = st["flux"]
+        else:
+            flux = np.array([np.roll(st["flux"], 7 * m) * (1.0 + 0.01 * m) for m in range(M)])
+        vals.append(op.log_likelihood(st["t"], flux, 1e-6, p=st["p"]))
+    return np.array(vals)
 
 
-def test_cfg5_share_every_driver(engines):
+def test_cfg3_full_batch_every_star(engines):
+    """64 stars, ydeg 15, K 1000 -- bench.py's workload: every star within 1e-8 of the reference's own
+    value, and a star's value independent of the batch (bit for bit)."""
+    ref = golden("lnlike_full")["cfg3_L15_K1000"]
+    e = engines(15)
+    v, st = lnl(e, 1000, range(64))
+    assert not st.any() and np.all(np.isfinite(v))
+    assert np.max(np.abs(v / ref - 1)) < TOL
+    v8, _ = lnl(e, 1000, range(8))
+    assert np.array_equal(v8, v[:8])
+    v1, _ = lnl(e, 1000, [63])
+    assert v1[0] == v[63]
+    v5, _ = lnl(e, 1000, range(20, 25))       # (fewer than 8 stars: a matrix's tiles spread over the XCDs)
+    assert np.array_equal(v5, v[20:25])
+
+
+def test_cfg5_share_every_star(engines):
     """cfg5's share of one GPU: 32 stars, ydeg 20, K 3000, Matern-3/2 (tau 3), u = [0.4, 0.2]."""
-    g = golden("lnlike")
-    gs = [int(s) for s in g["cfg5_L20_K3000_stars"]]
-    res = {}
-    for chol, panel in MODES:
-        e = engines(20, chol, panel)
-        v, st = lnl(e, 3000, range(32), tspan=30.0, u=(0.4, 0.2), tau=3.0)
-        assert not st.any() and np.all(np.isfinite(v))
-        assert np.max(np.abs(v[gs] / g["cfg5_L20_K3000"] - 1)) < TOL, (chol, panel)
-        v3, _ = lnl(e, 3000, range(3), tspan=30.0, u=(0.4, 0.2), tau=3.0)
-        assert np.array_equal(v3, v[:3]), (chol, panel)
-        res[(chol, panel)] = v
-    ref = res[MODES[0]]
-    for k, v in res.items():
-        assert np.max(np.abs(v / ref - 1)) < TOL_DRIVERS, k
+    ref = golden("lnlike_full")["cfg5_L20_K3000"]
+    e = engines(20)
+    v, st = lnl(e, 3000, range(32), tspan=30.0, u=(0.4, 0.2), tau=3.0)
+    assert not st.any() and np.all(np.isfinite(v))
+    assert np.max(np.abs(v / ref - 1)) < TOL
+    v3, _ = lnl(e, 3000, range(3), tspan=30.0, u=(0.4, 0.2), tau=3.0)
+    assert np.array_equal(v3, v[:3])
 
 
-@pytest.mark.parametrize("K,M", [(40, 1), (63, 1), (64, 1), (65, 1), (200, 1), (257, 3), (448, 1), (511, 2),
-                                 (513, 1), (960, 70), (1000, 1), (1023, 1), (1024, 1), (1100, 5), (1345, 1)])
-def test_awkward_sizes_recursive_vs_superpanel(engines, K, M):
+@pytest.mark.parametrize("K,M", [(40, 1), (63, 1), (64, 1), (65, 1), (127, 1), (128, 1), (129, 1), (200, 1),
+                                 (257, 3), (448, 1), (511, 2), (513, 1), (960, 70), (1000, 1), (1023, 1),
+                                 (1024, 1), (1100, 5), (1345, 1)])
+def test_awkward_sizes_against_the_oracle(engines, K, M):
     """Partial last blocks, residual rows in the last pivot block's rows or in blocks of their own
-    (K + M beyond the last pivot block), fewer panels than a base block, uneven recursion."""
+    (K + M beyond the last pivot block), a single pivot block, one or several super-panels."""
     S = 5 if K > 600 else 9
-    ref, st0 = lnl(engines(15, 0, 0), K, range(3, 3 + S), M=M)
-    one, st1 = lnl(engines(15, 0, 1), K, range(3, 3 + S), M=M)
-    rec, st2 = lnl(engines(15, 2, 0), K, range(3, 3 + S), M=M)
-    flow, st3 = lnl(engines(15, 3, 0), K, range(3, 3 + S), M=M)
-    assert not st0.any() and not st1.any() and not st2.any() and not st3.any()
-    assert np.all(np.isfinite(ref))
-    # (with M > 1 shifted copies a star's value can be a small difference of terms of size
-    #  max |lnlike| over the batch: the drivers agree relative to that size)
+    idx = range(3, 3 + S)
+    v, st = lnl(engines(15), K, idx, M=M)
+    assert not st.any() and np.all(np.isfinite(v))
+    nref = 2 if K > 600 else 4              # (the oracle takes seconds per star at K = 1000)
+    ref = oracle_lnl(K, list(idx)[:nref], M=M)
+    # (with M > 1 shifted copies a star's value can be a small difference of large terms: relative to the
+    #  batch's size)
     scale = np.maximum(np.abs(ref), np.abs(ref).max())
-    assert np.max(np.abs(one - ref) / scale) < TOL_DRIVERS
-    assert np.max(np.abs(rec - ref) / scale) < TOL_DRIVERS
-    assert np.max(np.abs(flow - ref) / scale) < TOL_DRIVERS
+    assert np.max(np.abs(v[:nref] - ref) / scale) < TOL
 
 
-@pytest.mark.parametrize("S", [1, 3, 8, 13, 64])
-def test_dataflow_chain_batch_sizes(engines, S):
-    """The dataflow chain deals stars to per-XCD queues (S >= 8: star s to XCD s % 8, uneven when 8
-    does not divide S) or to one queue with device-scope releases (S < 8): same values as the
-    super-panel driver, bit-identical when repeated."""
-    ref, st0 = lnl(engines(15, 0, 0), 700, range(S))
-    a, st1 = lnl(engines(15, 3, 0), 700, range(S))
-    b, _ = lnl(engines(15, 3, 0), 700, range(S))
-    assert not st0.any() and not st1.any()
-    assert np.array_equal(a, b)
-    assert np.max(np.abs(a / ref - 1)) < TOL_DRIVERS
+@pytest.mark.parametrize("S", [1, 3, 8, 13, 64, 100])
+def test_batch_sizes_and_pair_items(engines, S):
+    """Items are dealt to the XCDs in contiguous runs (whole stars when 8 divides the batch); launches
+    whose 64-row items would not fit the CUs in one round use 128-row pair items (S = 64, 100 at
+    K = 700: the first panels).  A star's value does not depend on any of that."""
+    e = engines(15)
+    a, st = lnl(e, 700, range(S))
+    b, _ = lnl(e, 700, range(S))
+    assert not st.any() and np.array_equal(a, b)
+    one, _ = lnl(e, 700, [S - 1])
+    assert one[0] == a[S - 1]
+    ref = oracle_lnl(700, [0])
+    assert abs(a[0] / ref[0] - 1) < TOL
+
+
+def test_look_ahead_and_super_panel_width_do_not_change_the_answer(monkeypatch):
+    """SP_PANEL_LA = 0 (no look-ahead items) and other super-panel widths: the same factor to rounding."""
+    res = {}
+    for la, sup in (("1", "0"), ("0", "0"), ("1", "4"), ("1", "16"), ("1", "3")):
+        monkeypatch.setenv("SP_SUPER", sup)
+        e = make_engine(15)
+        e._L.sp_debug_set_look_ahead(e._h, int(la))
+        v, st = lnl(e, 1000, range(10, 18))
+        assert not st.any()
+        res[(la, sup)] = v
+    ref = res[("1", "0")]
+    for k, v in res.items():
+        assert np.max(np.abs(v / ref - 1)) < 1e-10, k
 
 
 @pytest.mark.parametrize("K,M,kw", [
@@ -153,14 +161,14 @@ def test_dataflow_chain_batch_sizes(engines, S):
     (1345, 1, {}), (1100, 5, {}), (1000, 1, dict(tau=2.5)), (1000, 1, dict(u=(0.4, 0.2))),
 ])
 def test_tiles_formed_at_first_touch_are_the_assembled_ones(K, M, kw):
-    """sp_set_lazy_cov: in the one-launch-per-panel mode the assembly leaves the tiles below the
+    """sp_set_lazy_cov: the assembly leaves the tiles below the
     diagonal to the kernel that touches them first (same spline code, coefficients gathered from a
     packed copy of the star's table): the log-likelihoods are IDENTICAL to those of the
     materialised assembly -- sizes with partial blocks, residual rows in tiles of their own, a
     temporal kernel, limb darkening."""
     res = []
     for lazy in (1, 0):
-        e = make_engine(15, 0, 1)
+        e = make_engine(15)
         e.set_lazy_cov(lazy)
         v, st = lnl(e, K, range(2, 8), M=M, **kw)
         assert not st.any() and np.all(np.isfinite(v))
@@ -175,7 +183,7 @@ def test_first_touch_ragged_and_failures():
 
     res = []
     for lazy in (1, 0):
-        e = make_engine(15, 0, 1)
+        e = make_engine(15)
         e.set_lazy_cov(lazy)
         K, S = 640, 6
         sts = [synthetic_star(30 + s, K) for s in range(S)]
@@ -193,36 +201,31 @@ def test_first_touch_ragged_and_failures():
     assert np.all(np.isfinite(np.delete(res[0][0], 4)))
 
 
-def test_failure_semantics_every_driver(engines):
+def test_failure_semantics(engines):
     """A covariance that is not positive definite gives -inf and the NOT_PD bit for THAT star only
-    (math.py:82-91, sp.py:1186-1188), whichever driver factors it."""
-    for chol, panel in MODES:
-        e = engines(15, chol, panel)
+    (math.py:82-91, sp.py:1186-1188)."""
+    e = engines(15)
+    for K in (700, 1000, 64):
         dv = np.full(6, 1e-6)
         dv[2] = -1.0
-        v, st = lnl(e, 700, range(6), data_var=dv)
-        assert v[2] == -np.inf and (st[2] & 1), (chol, panel)
+        v, st = lnl(e, K, range(6), data_var=dv)
+        assert v[2] == -np.inf and (st[2] & 1), K
         ok = np.arange(6) != 2
-        assert np.all(np.isfinite(v[ok])) and not st[ok].any(), (chol, panel)
-        good, _ = lnl(e, 700, [0, 1, 3, 4, 5])
-        assert np.array_equal(good, v[ok]), (chol, panel)
+        assert np.all(np.isfinite(v[ok])) and not st[ok].any(), K
+        good, _ = lnl(e, K, [0, 1, 3, 4, 5])
+        assert np.array_equal(good, v[ok]), K
 
 
-@pytest.mark.parametrize("chol", [0, 3])
-def test_three_steps_in_flight_K1000(chol):
+def test_three_steps_in_flight_K1000():
     """bench.py's default configuration: three independent 64-star, K = 1000 steps on three
     (handle, stream) pairs, enqueued before anything is synchronised, repeated; every step gives
-    exactly the bits of the same step run alone on its handle.  chol = 3: three dataflow chains
-    share the GPU (their workgroups wait on flags while holding their CU slots: progress must not
-    depend on all of them being resident)."""
+    exactly the bits of the same step run alone on its handle."""
     import torch
     from starry_process_amd.engine import engine_slots, make_stars
 
     S, K = 64, 1000
     mom = golden("moments_L15")
     slots = engine_slots(15, 2, None, 3)
-    for e, _ in slots:
-        e.set_chol_mode(chol)
     e0 = slots[0][0]
     sts = [synthetic_star(s, K) for s in range(S)]
     t_d = e0.f64(np.array([s["t"] for s in sts]))

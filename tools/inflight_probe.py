@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 from starry_process_amd._lib import check
-from chain_check import engine, setup, run
+from _common import engine, setup, run
 
 Fs = [int(x) for x in sys.argv[1:]] or [1, 2, 3, 4]
 S, K = 64, 1000
@@ -27,7 +27,7 @@ def spd(e, S, n):
 for F in Fs:
     slots = []
     for k in range(F):
-        e = engine(0, 1)
+        e = engine()
         st = torch.cuda.Stream(device=e.device)
         X = torch.randn(S, 512, 512, dtype=torch.float64, device=e.device)
         C = torch.zeros(S, 512, 512, dtype=torch.float64, device=e.device)

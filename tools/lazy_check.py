@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 from starry_process_amd.engine import make_stars
 from starry_process_amd.synthetic import synthetic_star
-from chain_check import engine
+from _common import engine
 
 def values(e, S, K, M=1, tau=None, nobs=None, u=(0.0, 0.0)):
     sts = [synthetic_star(s, K) for s in range(S)]
@@ -24,7 +24,7 @@ def values(e, S, K, M=1, tau=None, nobs=None, u=(0.0, 0.0)):
     torch.cuda.synchronize()
     return out.cpu().numpy().copy(), status.cpu().numpy().copy()
 
-el, em = engine(0, 1), engine(0, 1)
+el, em = engine(), engine()
 el.set_lazy_cov(True); em.set_lazy_cov(False)
 cases = [dict(S=8, K=200), dict(S=9, K=127), dict(S=5, K=128), dict(S=3, K=129), dict(S=16, K=513),
          dict(S=8, K=960, M=70), dict(S=64, K=1000), dict(S=7, K=1345), dict(S=12, K=1100, M=5),

@@ -9,11 +9,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 from starry_process_amd._lib import check
-from chain_check import engine, setup, run
+from _common import engine, setup, run
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-e = engine(0, 1)
+e = engine()
 a = setup(e, S, K)
 run(e, a, reps=5)
 f = e._L.sp_debug_panel2_trace
