@@ -281,33 +281,6 @@ def bench_shape(torch, dist, ydeg, Kc, S, tspan, tau, u, conditional, F, steps, 
            "whole_step_TFLOPs": fl / (ms * 1e-3) / 1e12,
            "whole_step_frac": fl / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
            "finite": bool(torch.isfinite(slots[0].out).all().item())}
-    if conditional:
-        # the a12-a13 products alone (A Sigma_y, then (A Sigma_y) A^T on the matrix cores,
-        # flux.py:337-343), one at a time, HIP events on the launch stream
-        e, st = slots[0].e, slots[0].stream
-        with torch.cuda.stream(st):
-            A = e.design_matrix(np.array([s["t"] for s in sts]), stars_h, inputs["rta1_d"])
-            B1 = e.empty(S, Kc, N)
-            raw = e.empty(S, Kc, Kc)
-            SigB = inputs["Sig_d"].unsqueeze(0).expand(S, N, N).contiguous()
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-
-            def products():
-                e.gemm_nt_batched(A, SigB, B1)
-                e.gemm_nt_batched(B1, A, raw)
-
-            for _ in range(3):
-                products()
-            ev[0].record(st)
-            for _ in range(10):
-                products()
-            ev[1].record(st)
-        torch.cuda.synchronize()
-        gms = ev[0].elapsed_time(ev[1]) / 10
-        gfl = S * (2.0 * Kc * N * N + 2.0 * Kc * Kc * N)
-        res["design_products_ms"] = gms
-        res["design_products_TFLOPs"] = gfl / (gms * 1e-3) / 1e12
-        res["design_products_frac"] = res["design_products_TFLOPs"] / FP64_PEAK_TFLOPS
     return res
 
 

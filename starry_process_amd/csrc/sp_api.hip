@@ -43,6 +43,11 @@ int sp_launch_defer_finish(int S, int K, int M, int Kp, const sp_star *stars, co
                            double *rowsum, hipStream_t st);
 int sp_launch_cholesky_systems(sp_handle *h, double *sys, int S, int K, int Kp,
                                int32_t *info, double *invL, hipStream_t st);
+int sp_launch_cond_pad_rows(double *A, int S, int K, int Kr, int N, hipStream_t st);
+int sp_launch_cond_system(const double *B1, const double *A, int N, int Kr, int S, int K, int M, int Kp,
+                          const double *t, const sp_star *stars, int temporal, const void *coef,
+                          const double *diag, const double *flux, double *sys, double *part,
+                          hipStream_t st);
 int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *grp, int K,
                               int Kp);
 int sp_launch_lnlike_reduce(const double *sys, int S, int K, int M, int Kp,
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(256) void cond_prep_kernel(
 
 // f[s][k][n] = v[s][n] cos(m th) + v[s][mirror n] sin(m th)   (wigner.h:289-339)
 __global__ __launch_bounds__(256) void cond_rz_kernel(
-    int ydeg, int N, int K, const int32_t *__restrict__ m_of,
+    int ydeg, int N, int K, int Kr, const int32_t *__restrict__ m_of,
     const int32_t *__restrict__ mirror, const double *__restrict__ v,
     const double *__restrict__ theta, double *__restrict__ f) {
   __shared__ double cn[SP_MAX_YDEG + 1], sn[SP_MAX_YDEG + 1];
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(256) void cond_rz_kernel(
   }
   __syncthreads();
   const double *vs = v + (size_t)s * N;
-  double *out = f + ((size_t)s * K + k) * N;
+  double *out = f + ((size_t)s * Kr + k) * N;
   for (int n = threadIdx.x; n < N; n += blockDim.x) {
     const int m = m_of[n];
     const double cm = cn[m < 0 ? -m : m];
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256) void cond_rz_kernel(
 }
 
 // mean[s] = (A mu_y)[0]   (flux.py:340)
-__global__ __launch_bounds__(256) void cond_mean_kernel(int N, int K,
+__global__ __launch_bounds__(256) void cond_mean_kernel(int N, int K /* rows per star in A */,
                                                         const double *__restrict__ A,
                                                         const double *__restrict__ mu,
                                                         double *__restrict__ mean) {
@@ -159,6 +164,7 @@ inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
   int S, K, M, Kp, N, NWIG;
+  int Kr;   // rows per star of the design-matrix buffers A, B1: roundup(K, 64), the rows beyond K zero
   size_t theta, rowsum, qv, coef, info, status, condmean, cs, vrow, Rinc, invL, A,
       B1, raw, part, sys, total;
 };
@@ -174,6 +180,7 @@ Layout make_layout(const sp_handle *h, int S, int K, int M, bool with_sys) {
   L.Kp = sp_roundup(K + M + (with_sys && h->defer_norm ? SP_DEFER_ROWS : 0), SP_NB);
   L.N = h->N;
   L.NWIG = h->NWIG;
+  L.Kr = sp_roundup(K, SP_NB);
   size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t o = off;
@@ -192,8 +199,8 @@ Layout make_layout(const sp_handle *h, int S, int K, int M, bool with_sys) {
   L.vrow = take(d * S * L.N);
   L.Rinc = take(d * S * L.NWIG);
   L.invL = take(d * (size_t)S * sp_lt_stride(L.Kp));
-  L.A = take(d * (size_t)S * K * L.N);
-  L.B1 = take(d * (size_t)S * K * L.N);
+  L.A = take(d * (size_t)S * L.Kr * L.N);
+  L.B1 = take(d * (size_t)S * L.Kr * L.N);
   L.raw = take(d * (size_t)S * K * K);
   L.part = (with_sys && h->defer_norm) ? take(d * (size_t)S * (L.Kp / SP_NB) * K) : off;
   L.sys = with_sys ? take(d * (size_t)S * L.Kp * L.Kp) : off;
@@ -233,9 +240,10 @@ int ensure_big(sp_handle *h, size_t bytes, void **out) {
   return SP_OK;
 }
 
-// design matrix for S stars into L.A (uses L.theta already filled)
+// design matrix for S stars into A_out (uses L.theta already filled); Kr rows per star in A_out and
+// in the scratch L.B1 (Kr == K: contiguous stars; Kr > K: the rows beyond K are zeroed)
 int build_design(sp_handle *h, const Layout &L, void *ws, const sp_star *stars,
-                 const double *rta1, double *A_out, hipStream_t st) {
+                 const double *rta1, double *A_out, hipStream_t st, int Kr) {
   const int S = L.S, K = L.K, N = L.N;
   double *cs = at<double>(ws, L.cs), *vrow = at<double>(ws, L.vrow);
   double *Rinc = at<double>(ws, L.Rinc), *theta = at<double>(ws, L.theta);
@@ -248,11 +256,12 @@ int build_design(sp_handle *h, const Layout &L, void *ws, const sp_star *stars,
   hipLaunchKernelGGL(cond_prep_kernel, dim3((N + 255) / 256, S), dim3(256), 0, st,
                      N, h->NWIG, h->d_l_of, h->d_blk, stars, rta1, Rinc, vrow);
   SP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(cond_rz_kernel, dim3(K, S), dim3(256), 0, st, h->ydeg, N, K,
+  hipLaunchKernelGGL(cond_rz_kernel, dim3(K, S), dim3(256), 0, st, h->ydeg, N, K, Kr,
                      h->d_m_of, h->d_mirror, vrow, theta, tmp);
   SP_LAUNCH_CHECK();
-  // all stars share Rx(pi/2): treat the S*K rows as one tall matrix
-  const long rows = (long)S * K;
+  if ((rc = sp_launch_cond_pad_rows(tmp, S, K, Kr, N, st))) return rc;
+  // all stars share Rx(pi/2): treat the S*Kr rows as one tall matrix (zero rows stay zero)
+  const long rows = (long)S * Kr;
   for (long r0 = 0; r0 < rows; r0 += 32768) {
     const int nr = (int)(rows - r0 < 32768 ? rows - r0 : 32768);
     rc = sp_launch_dotRx(h, tmp + (size_t)r0 * N, 0, N, 1, nr, h->d_Rx90, 0,
@@ -298,8 +307,8 @@ Layout sub_layout(const Layout &L, int s0, int Sg) {
   G.vrow += z * L.N * d;
   G.Rinc += z * L.NWIG * d;
   G.invL += z * sp_lt_stride(L.Kp) * d;
-  G.A += z * L.K * L.N * d;
-  G.B1 += z * L.K * L.N * d;
+  G.A += z * L.Kr * L.N * d;
+  G.B1 += z * L.Kr * L.N * d;
   G.raw += z * (size_t)L.K * L.K * d;
   G.part += z * (size_t)(L.Kp / SP_NB) * L.K * d;
   G.sys += z * (size_t)L.Kp * L.Kp * d;
@@ -327,8 +336,35 @@ int lnlike_assemble(sp_handle *h, const Layout &L, void *ws, int K, int M, const
     return rc;
   const double *rawp = nullptr;
   const double *condmean = nullptr;
+  if (conditional && (L.N % 64) == 0 && ((normalized && h->defer_norm) || !normalized)) {
+    // Conditional branch, fused (sp_cond.hip): B1 = A Sigma_y, then the LOWER tiles of B1 A^T land in
+    // the system assembled -- no K x K raw matrix written and read back (round 2: 0.5 GB per 64-star
+    // step), 40 % fewer flops in the second product.  The design-matrix buffers hold roundup(K, 64)
+    // rows per star (zero beyond K) so that every tile of the products is a full one.
+    const int N = L.N, Kr = L.Kr;
+    double *A = at<double>(ws, L.A), *B1 = at<double>(ws, L.B1);
+    if ((rc = build_design(h, L, ws, stars_dev, rta1_dev, A, st, Kr))) return rc;
+    hipLaunchKernelGGL(cond_mean_kernel, dim3(S), dim3(256), 0, st, N, Kr, A, h->d_mean_ylm, cm);
+    SP_LAUNCH_CHECK();
+    if ((rc = sp_launch_gemm_nt(A, N, (long)Kr * N, h->d_cov_ylm, N, 0, B1, N, (long)Kr * N, Kr, N, N, 1.0,
+                                0, 0, S, st)))
+      return rc;
+    if (normalized) {
+      double *part = at<double>(ws, L.part);
+      if ((rc = sp_launch_cond_system(B1, A, N, Kr, S, K, M, L.Kp, t_dev, stars_dev, temporal, nullptr,
+                                      nullptr, flux_dev, sys, part, st)))
+        return rc;
+      return sp_launch_defer_finish(S, K, M, L.Kp, stars_dev, meanvar_dev, cm, norm_order, zmax, part,
+                                    diag_dev, sys, coef, status, rowsum, st);
+    }
+    if ((rc = sp_launch_norm_coef(S, K, stars_dev, meanvar_dev, cm, 0, norm_order, zmax, rowsum, qv, coef,
+                                  status, st)))
+      return rc;
+    return sp_launch_cond_system(B1, A, N, Kr, S, K, M, L.Kp, t_dev, stars_dev, temporal, coef, diag_dev,
+                                 flux_dev, sys, nullptr, st);
+  }
   if (conditional) {
-    if ((rc = build_design(h, L, ws, stars_dev, rta1_dev, at<double>(ws, L.A), st)))
+    if ((rc = build_design(h, L, ws, stars_dev, rta1_dev, at<double>(ws, L.A), st, K)))
       return rc;
     if ((rc = build_conditional_raw(h, L, ws, st))) return rc;
     rawp = raw;
@@ -787,7 +823,7 @@ int sp_design_matrix(sp_handle *h, int S, int K, const double *t_dev,
   if (rc) return rc;
   if ((rc = sp_launch_theta(S, K, t_dev, stars_dev, at<double>(ws, L.theta), st)))
     return rc;
-  return build_design(h, L, ws, stars_dev, rta1_dev, A_dev, st);
+  return build_design(h, L, ws, stars_dev, rta1_dev, A_dev, st, K);
 }
 
 int sp_cov_conditional_batched(sp_handle *h, int S, int K, const double *t_dev,
@@ -810,7 +846,7 @@ int sp_cov_conditional_batched(sp_handle *h, int S, int K, const double *t_dev,
   double *qv = at<double>(ws, L.qv), *coef = at<double>(ws, L.coef);
   double *raw = at<double>(ws, L.raw), *cm = at<double>(ws, L.condmean);
   if ((rc = sp_launch_theta(S, K, t_dev, stars_dev, theta, st))) return rc;
-  if ((rc = build_design(h, L, ws, stars_dev, rta1_dev, at<double>(ws, L.A), st)))
+  if ((rc = build_design(h, L, ws, stars_dev, rta1_dev, at<double>(ws, L.A), st, K)))
     return rc;
   if ((rc = build_conditional_raw(h, L, ws, st))) return rc;
   if (normalized)
