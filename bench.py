@@ -42,6 +42,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# one hardware queue per stream in flight (starry_process_amd/__init__.py does the same; here before
+# anything can have touched the GPU)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 YDEG, UDEG, K, STARS_PER_GPU, COVPTS = 15, 2, 1000, int(os.environ.get("SP_BENCH_STARS", "64")), 300
 FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix = vector peak (AMD CDNA4 datasheet)
@@ -405,7 +408,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--in-flight", type=int, default=3,
+    ap.add_argument("--in-flight", type=int, default=4,
                     help="independent steps kept in flight on separate streams / handles")
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="untimed pre-warm after the --warmup steps: whole steps keep running until this "

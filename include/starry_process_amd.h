@@ -331,6 +331,22 @@ int sp_gp_condition(sp_handle *h, int K, int Ks, const double *Ktt_dev, const do
 int sp_latitude_integrals(int ydeg, double alpha, double beta, double *q_host,
                           double *Q_host);
 
+/* ---- upstream of the path, on the device ---------------------------
+ * (mu_y [N], Sigma_y [N, N]) on the device from the host-side pieces of the hyperparameters, by
+ * exact quadrature of rotations (starry_process_amd/upstream_device.py documents the method; it
+ * replaces the chain size.py:49-134 -> latitude.py:170-212 -> longitude.py:8-78 ->
+ * contrast.py:18-33 of the reference, whose eigen-square-root route is ill conditioned):
+ *   vecs_host [mv, N]  the vectors to rotate: the size first moment, then (unless first_is_col:
+ *                      dr = None, one vector serves as both) the columns of the second-moment factor;
+ *   phi_host, w_host [P]  latitude angles (both signs of the Gauss-Jacobi nodes) and their weights
+ *                      (sum 1); Q equispaced longitudes lam_q = 2 pi q / Q;
+ *   g = pi c sqrt(n), sqrt_n, epsy, epsy15 (contrast.py:21-33).
+ * One staged upload and nine launches on `stream`; scratch from the handle.                     */
+int sp_ylm_moments_quadrature(sp_handle *h, const double *vecs_host, int mv, int first_is_col,
+                              const double *phi_host, const double *w_host, int P, int Q, double g,
+                              double sqrt_n, double epsy, double epsy15, double *mean_dev,
+                              double *cov_dev, void *stream);
+
 /* ---- measurement hooks (bench.py) ------------------------------------------ */
 /* Between begin and end every launch of the trailing-update kernel (the
  * dominant kernel of the factorisation) is bracketed by HIP events on the

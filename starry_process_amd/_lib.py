@@ -87,6 +87,8 @@ PROTOTYPES = {
     "sp_set_ylm_moments": (_I, [_V, _V, _V]),
     "sp_set_ylm_moments_dev": (_I, [_V, _V, _V, _V]),
     "sp_get_polar_moments": (_I, [_V, _V, _V]),
+    "sp_ylm_moments_quadrature": (_I, [_V, _V, _I, _I, _V, _V, _I, _I, _D, _D, _D, _D,
+                                       _V, _V, _V]),
     "sp_debug_panel2_trace": (_I, [_V]),
     "sp_debug_set_look_ahead": (_I, [_V, _I]),
     "sp_profile_kind": (_I, [_V, _I, ctypes.POINTER(ctypes.c_long), c_double_p, c_double_p]),

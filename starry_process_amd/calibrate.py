@@ -141,7 +141,7 @@ class EnsembleLogProb(object):
 
     def __init__(self, t, flux, ferr=1.0e-3, p=1.0, i=None, u=None, ydeg=15, baseline_log_var=0.0,
                  baseline_mean=0.0, apply_jac=True, normalized=True,
-                 marginalize_over_inclination=True, covpts=None, device=None, depth=3):
+                 marginalize_over_inclination=True, covpts=None, device=None, depth=4):
         import torch
         import torch.distributed as dist
 

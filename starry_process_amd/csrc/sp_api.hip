@@ -220,6 +220,9 @@ int check_handle(const sp_handle *h) { return h ? SP_OK : SP_ERR_INVALID; }
 
 }  // namespace
 
+// (the handle's grow-only scratch for the other translation units)
+int ensure_big_scratch(sp_handle *h, size_t bytes, void **out) { return ensure_big(h, bytes, out); }
+
 namespace {
 // (growing synchronises the device: the old buffer may still be in use by launches of this
 //  handle on any stream; steady-state calls never get here)
@@ -467,6 +470,9 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
   h->lazy_cov = 1;
   h->ncu = 256;
   h->look_ahead = 1;
+  h->d_Rxm90 = nullptr;
+  h->d_lamcs = nullptr;
+  h->lamcs_Q = 0;
   const int N = h->N;
   h->l_of.resize(N);
   h->m_of.resize(N);
@@ -541,7 +547,7 @@ void sp_destroy(sp_handle *h) {
   (void)hipDeviceSynchronize();
   void *ptrs[] = {h->d_l_of, h->d_m_of,   h->d_mirror, h->d_blk,   h->d_Rx90,
                   h->d_wnp,  h->d_Wnp,    h->d_mean_ylm, h->d_cov_ylm, h->d_ez,
-                  h->d_Ez,   h->d_tmpNN,  h->d_scratch, h->d_xp, h->d_tab_scratch};
+                  h->d_Ez,   h->d_tmpNN,  h->d_scratch, h->d_xp, h->d_tab_scratch, h->d_Rxm90, h->d_lamcs};
   for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->gdone) (void)hipEventDestroy(e);
   for (hipStream_t s2 : h->gstream) (void)hipStreamDestroy(s2);

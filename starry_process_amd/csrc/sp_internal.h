@@ -29,6 +29,9 @@ struct sp_handle {
   // device constants
   int32_t *d_l_of, *d_m_of, *d_mirror, *d_blk;
   double *d_Rx90;               // packed Rx(pi/2)
+  double *d_Rxm90;              // packed Rx(-pi/2) (sp_upstream.hip; first use)
+  double *d_lamcs;              // cos / sin (m lam_q) of the lamcs_Q equispaced longitudes (sp_upstream.hip)
+  int lamcs_Q;
   double *d_wnp, *d_Wnp;        // marginalisation constants (flux.py:121-179)
   bool have_marginal;
   double *d_xp;                 // lag grid of the last kernel table
@@ -188,7 +191,7 @@ int sp_launch_Rx(sp_handle *h, const double *cs_dev /* [n,2] cos,sin */, int n,
                  double *R, double *dR, hipStream_t st);
 int sp_launch_dotRx(sp_handle *h, const double *M, long strideM, long rs,
                     long cs, int rows, const double *R, long strideR,
-                    double *out, int batch, hipStream_t st);
+                    double *out, int batch, hipStream_t st, int transposeR = 0);
 
 // ez, Ez (and the resident copies of mu, Sigma) from device pointers, one launch
 int sp_launch_polar_moments(sp_handle *h, const double *mu_src, const double *cov_src,

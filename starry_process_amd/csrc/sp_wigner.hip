@@ -248,11 +248,13 @@ __global__ __launch_bounds__(256) void rx_kernel(int ydeg,
 }
 
 // out[b][r][n] = sum_i M[b](r, l^2 + i) * R[b][blk[l] + i (2l+1) + (n - l^2)]
+// (rt: against the TRANSPOSED blocks, R[b][blk[l] + (n - l^2) (2l+1) + i] -- a rotation by the opposite
+//  angle, R(-theta) = R(theta)^T, without a second Wigner recursion)
 __global__ __launch_bounds__(256) void dotrx_kernel(
     int N, const int32_t *__restrict__ l_of, const int32_t *__restrict__ blk,
     const double *__restrict__ M, long strideM, long rs, long cs,
     const double *__restrict__ Rpk, long strideR, double *__restrict__ out,
-    int rows) {
+    int rows, int rt) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   const int r = blockIdx.y;
   const int b = blockIdx.z;
@@ -260,9 +262,10 @@ __global__ __launch_bounds__(256) void dotrx_kernel(
   const int l = l_of[n];
   const int w = 2 * l + 1, base = l * l;
   const double *Mr = M + (size_t)b * strideM + (size_t)r * rs;
-  const double *B = Rpk + (size_t)b * strideR + blk[l] + (n - base);
+  const double *B = Rpk + (size_t)b * strideR + blk[l] + (rt ? (n - base) * w : (n - base));
+  const int bs = rt ? 1 : w;
   double acc = 0.0;
-  for (int i = 0; i < w; ++i) acc += Mr[(size_t)(base + i) * cs] * B[i * w];
+  for (int i = 0; i < w; ++i) acc += Mr[(size_t)(base + i) * cs] * B[i * bs];
   out[((size_t)b * rows + r) * N + n] = acc;
 }
 
@@ -535,12 +538,12 @@ int sp_launch_Rx(sp_handle *h, const double *cs_dev, int n, double *R,
 
 int sp_launch_dotRx(sp_handle *h, const double *M, long strideM, long rs,
                     long cs, int rows, const double *R, long strideR,
-                    double *out, int batch, hipStream_t st) {
+                    double *out, int batch, hipStream_t st, int transposeR) {
   if (rows <= 0 || batch <= 0) return SP_OK;
   if (rows > 65535 || batch > 65535) return SP_ERR_INVALID;
   dim3 grid((h->N + 255) / 256, rows, batch);
   hipLaunchKernelGGL(dotrx_kernel, grid, dim3(256), 0, st, h->N, h->d_l_of,
-                     h->d_blk, M, strideM, rs, cs, R, strideR, out, rows);
+                     h->d_blk, M, strideM, rs, cs, R, strideR, out, rows, transposeR);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }

@@ -55,8 +55,14 @@ def quadrature_nodes(ydeg, alpha, beta):
 
 
 def ylm_moments_device(engine, r=defaults["r"], dr=defaults["dr"], a=defaults["a"],
-                       b=defaults["b"], c=defaults["c"], n=defaults["n"], **kwargs):
-    """(mu_y [N], Sigma_y [N, N]) as device tensors of ``engine``'s GPU."""
+                       b=defaults["b"], c=defaults["c"], n=defaults["n"], native=True, **kwargs):
+    """(mu_y [N], Sigma_y [N, N]) as device tensors of ``engine``'s GPU.
+
+    native (default): the host computes the size moments and the quadrature nodes and hands them to
+    ONE library call, sp_ylm_moments_quadrature (csrc/sp_upstream.hip), which enqueues the rotations
+    and the two moment products; native=False composes the same computation from the path's ops
+    through this module (Rx, dotRx, tensordotRz, gemm_nt) -- 0.48 ms of host time per call against
+    0.15, kept as the readable statement of the method and as a cross-check."""
     e = engine
     ydeg, N = e.ydeg, e.N
     n = CheckBoundsOp(name="n", lower=0, upper=np.inf)(n)
@@ -73,6 +79,18 @@ def ylm_moments_device(engine, r=defaults["r"], dr=defaults["dr"], a=defaults["a
     first_is_col = dr is None
     vecs = cols if first_is_col else np.vstack([s1[None, :], cols])      # [mv, N]
     mv = vecs.shape[0]
+    if native:
+        from ._lib import check, hptr
+
+        vecs_c = np.ascontiguousarray(vecs, dtype=np.float64)
+        phi_c, w_c = np.ascontiguousarray(phi), np.ascontiguousarray(wphi)
+        mean, cov = e.empty(N), e.empty(N, N)
+        check(e._L.sp_ylm_moments_quadrature(
+            e._h, hptr(vecs_c), int(mv), int(first_is_col), hptr(phi_c), hptr(w_c), int(P), int(Q),
+            float(np.pi * float(c) * np.sqrt(float(n))), float(np.sqrt(float(n))),
+            float(kwargs.get("epsy", defaults["epsy"])), float(kwargs.get("epsy15", defaults["epsy15"])),
+            e._p(mean), e._p(cov), e._stream()))
+        return mean, cov
     # sqrt of the joint weights, with the contrast scale g = pi c sqrt(n) folded in:
     #   Sigma_y = sum (g sqrt(W) row)^T (g sqrt(W) row) - m1 m1^T,   m1 = g mom1,   mu_y = sqrt(n) m1
     g = np.pi * float(c) * np.sqrt(float(n))

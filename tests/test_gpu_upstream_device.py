@@ -141,3 +141,16 @@ def test_device_equals_cpu_quadrature(L, name):
     mu_o, S_o = orc.ylm_moments_quadrature(s1, cols, alpha, beta, c, n, L)
     assert np.abs(mu - mu_o).max() < 1e-13 * np.abs(mu_o).max()
     assert np.abs(S - S_o).max() < 1e-12 * np.abs(S_o).max()
+
+
+@pytest.mark.parametrize("name", ["default", "hilat", "spread"])
+def test_native_call_matches_the_composed_ops(name):
+    """sp_ylm_moments_quadrature (one library call: staged upload + nine launches, csrc/sp_upstream.hip)
+    against the same method composed from the path's ops in Python: the same rotations and sums up to
+    their order (the longitudes' cos / sin come from a table instead of a Chebyshev recurrence)."""
+    g = golden("moments_L15")
+    mu_n, S_n = _moments(15, g[name + "_hyper"])
+    mu_c, S_c = _moments(15, g[name + "_hyper"], native=False)
+    assert np.abs(mu_n - mu_c).max() < 1e-13 * np.abs(mu_c).max()
+    assert np.abs(S_n - S_c).max() < 1e-13 * np.abs(S_c).max()
+    assert np.array_equal(S_n, S_n.T)
