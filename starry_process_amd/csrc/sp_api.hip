@@ -177,7 +177,9 @@ Layout make_layout(const sp_handle *h, int S, int K, int M, bool with_sys) {
   L.S = S;
   L.K = K;
   L.M = M;
-  L.Kp = sp_roundup(K + M + (with_sys && h->defer_norm ? SP_DEFER_ROWS : 0), SP_NB);
+  // (sized for the deferred normalisation whatever the handle's current setting: it is the superset,
+  //  so a workspace sized before sp_set_defer_norm changes is never too small)
+  L.Kp = sp_roundup(K + M + (with_sys ? SP_DEFER_ROWS : 0), SP_NB);
   L.N = h->N;
   L.NWIG = h->NWIG;
   L.Kr = sp_roundup(K, SP_NB);
@@ -202,7 +204,7 @@ Layout make_layout(const sp_handle *h, int S, int K, int M, bool with_sys) {
   L.A = take(d * (size_t)S * L.Kr * L.N);
   L.B1 = take(d * (size_t)S * L.Kr * L.N);
   L.raw = take(d * (size_t)S * K * K);
-  L.part = (with_sys && h->defer_norm) ? take(d * (size_t)S * (L.Kp / SP_NB) * K) : off;
+  L.part = with_sys ? take(d * (size_t)S * (L.Kp / SP_NB) * K) : off;
   L.sys = with_sys ? take(d * (size_t)S * L.Kp * L.Kp) : off;
   L.total = off;
   return L;
