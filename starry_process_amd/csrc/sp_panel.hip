@@ -402,7 +402,8 @@ int sp_launch_panel2(double *sys, long ld, long stride, int S, int ntile, int j,
   // where there is room.
   {
     const long n64 = (long)S * ((ntile - j - 1) + ((a.mode & P_LOOKAHEAD) ? 1 : 0));
-    a.pair = P_PAIRS && (a.mode & P_TITEMS) && n64 > (long)P_WGS * ncu;
+    // (up to an eighth over: the stragglers of a short second round cost less than the pairs' slower products)
+    a.pair = P_PAIRS && (a.mode & P_TITEMS) && 8 * n64 > 9L * P_WGS * ncu;
   }
   const int per_star = ((a.mode & P_DITEMS) ? 1 : 0) + ((a.mode & P_TITEMS) ? panel_titems(ntile, j, a.pair) : 0) +
                        ((a.mode & P_LOOKAHEAD) ? 1 : 0);
