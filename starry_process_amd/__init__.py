@@ -25,7 +25,7 @@ def __getattr__(name):
 
         return getattr(upstream, name)
     if name in ("ops", "flux", "sp", "engine", "ensemble", "upstream", "upstream_device", "hostconst",
-                "calibrate", "math"):
+                "calibrate", "math", "grad"):
         import importlib
 
         return importlib.import_module("." + name, __name__)

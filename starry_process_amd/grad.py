@@ -1,0 +1,287 @@
+"""
+End-to-end gradient of the log-likelihood (the part beyond the single ops): what
+the reference obtains by letting Theano chain the ``grad`` / ``L_op`` methods of its Ops through the
+graph of ``StarryProcess.log_likelihood`` (sp.py:1052-1188; verified by finite differences in the
+reference's tests/test_lnlike.py:100-136).
+
+Here the graph is ``torch.autograd`` over fp64 tensors on the GPU, and its heavy nodes are the
+library's own reverse-mode kernels:
+
+  * ``lnL(C, r)``                the factorisation ``sp_cho_factor`` forward; backward in closed form,
+                                 ``C_bar = 1/2 (alpha alpha^T - C^-1)``, ``r_bar = -alpha`` with
+                                 ``alpha = C^-1 r`` (what chaining ``Cholesky.L_op`` and ``Solve.L_op``,
+                                 math.py:40-100, gives; tests/test_gpu_linalg_rev.py shows the two agree),
+                                 both solves on the device (``sp_cho_solve``);
+  * ``special_tensordotRz``      backward ``sp_special_tensordotRz_rev`` (wigner.h:464-531);
+  * the glue between them -- rotation of the moments to the polar frame (flux.py:54-62), mean / variance
+    (flux.py:297-308), spline build (flux.py:310-330), the K x K gather interpolation (flux.py:256-276),
+    the normalisation correction with its alpha(z), beta(z) series (sp.py:705-727, ops/norm/norm.py:26-44),
+    noise and baseline (sp.py:1135-1151) -- is elementwise / small-matrix torch arithmetic that autograd
+    differentiates by itself.
+
+``log_likelihood_with_grad`` returns d lnL / d(mu_y, Sigma_y): the gradient with respect to the hot path's
+own inputs.  ``hyper_gradient`` takes it on to (r, a, b, c, n): c and n enter the moments as plain scale
+factors (contrast.py:21-33), r, a, b through the upstream integrals, whose directional derivatives are
+taken by central differences of the device quadrature (upstream_device.py: smooth and accurate to
+rounding in its parameters, 0.3 ms per evaluation) -- one reverse sweep through the expensive part, six
+cheap upstream evaluations, instead of ten full likelihoods for finite differences of everything.
+
+One star, the marginalised branch (with or without normalisation); this is a diagnostic / optimisation
+aid (``mci.optimize()``-style callers), not part of the timed hot path.
+"""
+import numpy as np
+
+from .defaults import defaults
+from .engine import get_engine
+
+__all__ = ["log_likelihood_with_grad", "hyper_gradient"]
+
+_cache = {}
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def _constants(e, u):
+    """Device constants for limb darkening ``u``: dense blockdiag Rx(pi/2), w, W (flux.py:181-231), rTA1L(u)."""
+    from . import _lib, hostconst
+
+    torch = _torch()
+    key = (e.ydeg, e.device_index, tuple(np.asarray(u, dtype=float).reshape(-1)))
+    if key in _cache:
+        return _cache[key]
+    ydeg, N = e.ydeg, e.N
+    Rpk = e.Rx(np.array([0.5 * np.pi]), deriv=False)[0][0].cpu().numpy()
+    D = np.zeros((N, N))
+    off = 0
+    for l in range(ydeg + 1):
+        w_ = 2 * l + 1
+        D[l * l:(l + 1) ** 2, l * l:(l + 1) ** 2] = Rpk[off:off + w_ * w_].reshape(w_, w_)
+        off += w_ * w_
+    wnp, Wnp = hostconst.marginal_constants(ydeg)
+    rta1 = np.asarray(e.rTA1L(np.asarray(u, dtype=float).reshape(-1)[: e.udeg])).reshape(-1)
+    idx = _lib.index_tables(ydeg)
+    rho = rta1[idx["m0"]][idx["l_of"]]
+    W = Wnp * rho[:, None] * rho[None, :]
+    # w (N): w[l-block] = rTA1[l-block] . wnp[l]  (flux.py:196-198): mean = sum_n w[n] ez[n]
+    wv = np.zeros(N)
+    off = 0
+    for l in range(ydeg + 1):
+        w_ = 2 * l + 1
+        wv[l * l:(l + 1) ** 2] = rta1[l * l:(l + 1) ** 2] @ wnp[off:off + w_ * w_].reshape(w_, w_)
+        off += w_ * w_
+    _cache[key] = (e.f64(D), e.f64(wv), e.f64(W), e.f64(rta1))
+    return _cache[key]
+
+
+def _functions(e):
+    torch = _torch()
+
+    class SpecialTensordotRz(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, W, M, theta):
+            ctx.save_for_backward(W, M, theta)
+            return e.special_tensordotRz(W, M.contiguous(), theta)
+
+        @staticmethod
+        def backward(ctx, bf):
+            W, M, theta = ctx.saved_tensors
+            bM, _ = e.special_tensordotRz_rev(W, M.contiguous(), theta, bf.contiguous())
+            return None, bM, None
+
+    class GaussianLogLike(torch.autograd.Function):
+        """-1/2 r^T C^-1 r - 1/2 log det C - K/2 log 2 pi; -inf when C is not positive definite."""
+
+        @staticmethod
+        def forward(ctx, C, r):
+            K = C.shape[0]
+            L, info = e.cho_factor(C.contiguous())
+            if int(info.max().item()) != 0:
+                ctx.failed = True
+                return C.new_tensor(-float("inf"))
+            ctx.failed = False
+            alpha = e.cho_solve(L, r.reshape(K, 1).contiguous()).reshape(K)
+            ctx.save_for_backward(L, alpha)
+            return -0.5 * torch.dot(r, alpha) - torch.log(torch.diagonal(L)).sum() - 0.5 * K * np.log(2 * np.pi)
+
+        @staticmethod
+        def backward(ctx, g):
+            if ctx.failed:
+                return None, None
+            L, alpha = ctx.saved_tensors
+            K = L.shape[0]
+            Cinv = e.cho_solve(L, torch.eye(K, dtype=L.dtype, device=L.device))
+            return g * 0.5 * (torch.outer(alpha, alpha) - Cinv), -g * alpha
+
+    class DesignMatrix(torch.autograd.Function):
+        """A(theta, inc) = ((1_K x rTA1) Rx(-inc)) Rz(theta) Rx(pi/2)  (flux.py:88-105, 278-281); backward with
+        the library's reverse rotation (tensordotRz_rev) and the derivative matrices of sp_Rx."""
+
+        @staticmethod
+        def forward(ctx, theta, inc, rta1):
+            K = theta.shape[0]
+            R, dR = e.Rx(np.array([-float(inc.item()), 0.5 * np.pi, -0.5 * np.pi]), deriv=True)
+            M0 = rta1.reshape(1, -1).expand(K, -1).contiguous()
+            M1 = e.dotRx(M0, R[0])
+            A = e.dotRx(e.tensordotRz(M1, theta.contiguous()), R[1])
+            ctx.save_for_backward(theta, M0, M1, R, dR)
+            return A
+
+        @staticmethod
+        def backward(ctx, bA):
+            theta, M0, M1, R, dR = ctx.saved_tensors
+            bM2 = e.dotRx(bA.contiguous(), R[2])          # Rx(pi/2)^T = Rx(-pi/2)
+            bM1, btheta = e.tensordotRz_rev(M1, theta.contiguous(), bM2)
+            # M1 = M0 Rx(-inc): d/d inc = -M0 Rx'(-inc)
+            binc = -(bM1 * e.dotRx(M0, dR[0])).sum().reshape(1)
+            return btheta, binc, None
+
+    return SpecialTensordotRz, GaussianLogLike, DesignMatrix
+
+
+def _alpha_beta(z, order):
+    fac = z * 0.0 + 1.0
+    alpha, beta = z * 0.0, z * 0.0
+    for n in range(order + 1):
+        alpha = alpha + fac
+        beta = beta + 2 * n * fac
+        fac = fac * z * (2 * n + 3)
+    return alpha, beta
+
+
+def log_likelihood_with_grad(mean_ylm, cov_ylm, t, flux, data_var, i=defaults["i"], p=defaults["p"], u=None,
+                             tau=None, temporal_kernel="matern32", baseline_mean=0.0, baseline_var=0.0,
+                             marginalize_over_inclination=True, normalized=True, covpts=defaults["covpts"],
+                             ydeg=defaults["ydeg"], udeg=defaults["udeg"],
+                             norm_order=defaults["normalization_order"],
+                             zmax=defaults["normalization_zmax"], device=None):
+    """(lnL, grads) for ONE light curve; NumPy in, NumPy out.  ``grads`` holds d lnL / d of
+    "mean_ylm" [N], "cov_ylm" [N, N] (its N^2 entries treated as independent: symmetrise it for a symmetric
+    perturbation), "p", "tau" (when a timescale is given) and, on the conditional branch, "i" (per degree)."""
+    torch = _torch()
+    e = get_engine(ydeg, udeg, device)
+    u = np.zeros(e.udeg) if u is None else np.asarray(u, dtype=float).reshape(-1)[: e.udeg]
+    D, wv, W, rta1 = _constants(e, u)
+    Special, LogLike, Design = _functions(e)
+    t = np.asarray(t, dtype=np.float64).reshape(-1)
+    K = t.shape[0]
+    td = e.f64(t)
+    leaf = lambda v: e.f64(np.atleast_1d(np.asarray(v, dtype=np.float64))).clone().requires_grad_(True)  # noqa: E731
+    mu = leaf(np.asarray(mean_ylm).reshape(-1))
+    Sig = e.f64(np.asarray(cov_ylm, dtype=np.float64)).clone().requires_grad_(True)
+    per, inc = leaf(p), leaf(i)
+    # theta = 2 pi mod(t / p, 1) (flux.py:262, 279): the integer part is data
+    tp = td / per
+    theta = 2 * np.pi * (tp - torch.floor(tp.detach()))
+    if marginalize_over_inclination:
+        # polar frame (flux.py:54-62)
+        ez = D.t() @ mu
+        Ez = D.t() @ (Sig + torch.outer(mu, mu)) @ D
+        mean = torch.dot(wv, ez)
+        # kernel on the lag grid and its cubic coefficients (flux.py:297-330)
+        dx = 2 * np.pi / covpts
+        xp = np.arange(-dx, 2 * np.pi + 2.5 * dx, dx)
+        yp = Special.apply(W, Ez, e.f64(xp)) - mean ** 2
+        y0, y1, y2, y3 = yp[:-3], yp[1:-2], yp[2:-1], yp[3:]
+        a0 = y1
+        a1 = -y0 / 3.0 - 0.5 * y1 + y2 - y3 / 6.0
+        a2 = 0.5 * (y0 + y2) - y1
+        a3 = 0.5 * ((y1 - y2) + (y3 - y0) / 3.0)
+        # K x K interpolation (flux.py:256-276); the interval index is data
+        if K == 1:
+            cov = (torch.sum(W * Ez) - mean ** 2).reshape(1, 1)
+        else:
+            x = torch.abs(theta[:, None] - theta[None, :]).reshape(-1)
+            ii = torch.floor(x.detach() / dx).to(torch.int64)
+            x0 = (x - e.f64(xp)[ii + 1]) / dx
+            cov = (a0[ii] + a1[ii] * x0 + a2[ii] * x0 ** 2 + a3[ii] * x0 ** 3).reshape(K, K)
+    else:
+        # A = ((1_K x rTA1) Rx(-i)) Rz(theta) Rx(pi/2); mean = (A mu)_0, cov = A Sigma A^T (flux.py:278-281, 337-343)
+        A = Design.apply(theta, inc * (np.pi / 180.0), rta1)
+        mean = (A @ mu)[0]
+        cov = A @ Sig @ A.t()
+    tau_leaf = None
+    if tau is not None:
+        # temporal.py:8-16
+        tau_leaf = leaf(tau)
+        dt = torch.abs(td[:, None] - td[None, :])
+        if temporal_kernel == "matern32":
+            xx = np.sqrt(3.0) * dt / tau_leaf
+            cov = cov * ((1 + xx) * torch.exp(-xx))
+        elif temporal_kernel == "expsquared":
+            cov = cov * torch.exp(-(dt ** 2) / (2 * tau_leaf))
+        else:
+            raise ValueError("temporal_kernel must be 'matern32' or 'expsquared'")
+    gp_mean = mean
+    zval = 0.0
+    if normalized:
+        # sp.py:705-727 with mu = 1 + mean; the GP mean of the normalised process is zero (sp.py:669-670)
+        mu1 = 1.0 + mean
+        m = cov.mean()
+        q = cov.sum(dim=1) / (K * m)
+        z = m / mu1 ** 2
+        pp = 1.0 - q
+        alpha, beta = _alpha_beta(z, int(norm_order))
+        cov = (alpha / mu1 ** 2) * cov + z * ((alpha + beta) * torch.outer(pp, pp) - alpha * torch.outer(q, q))
+        gp_mean = mean * 0.0
+        zval = float(z.item())
+    dv = np.asarray(data_var, dtype=np.float64)
+    noise = e.f64(np.full(K, float(dv)) if dv.ndim == 0 else dv.reshape(-1))
+    C = cov + torch.diag(noise) + float(baseline_var)
+    r = e.f64(np.asarray(flux, dtype=np.float64).reshape(-1)) - (gp_mean + float(baseline_mean))
+    lnl = LogLike.apply(C, r)
+    leaves = {"mean_ylm": mu, "cov_ylm": Sig, "p": per}
+    if not marginalize_over_inclination:
+        leaves["i"] = inc
+    if tau_leaf is not None:
+        leaves["tau"] = tau_leaf
+    if not bool(torch.isfinite(lnl)) or (normalized and zval > zmax):
+        return -np.inf, {k: np.zeros(tuple(v.shape)) if v.numel() > 1 else 0.0 for k, v in leaves.items()}
+    lnl.backward()
+    grads = {}
+    for k, v in leaves.items():
+        g = v.grad if v.grad is not None else torch.zeros_like(v)
+        grads[k] = g.cpu().numpy() if v.numel() > 1 else float(g.item())
+    return float(lnl.item()), grads
+
+
+def hyper_gradient(t, flux, data_var, r=defaults["r"], dr=defaults["dr"], a=defaults["a"], b=defaults["b"],
+                   c=defaults["c"], n=defaults["n"], h=1e-4, **kwargs):
+    """(lnL, {"r": ., "a": ., "b": ., "c": ., "n": ., "p": ., ...}): the log-likelihood of one light curve and its
+    gradient with respect to the spot hyperparameters (moments by the device quadrature, upstream_device.py;
+    "dr" too when a spread of radii is given) and whatever else ``log_likelihood_with_grad`` differentiates
+    (p; i on the conditional branch; tau).
+    kwargs: as for ``log_likelihood_with_grad`` (i, p, u, tau, normalized, marginalize_over_inclination, ...)."""
+    from .upstream_device import ylm_moments_device
+
+    ydeg = kwargs.get("ydeg", defaults["ydeg"])
+    e = get_engine(ydeg, kwargs.get("udeg", defaults["udeg"]), kwargs.get("device"))
+
+    def moments(r_, dr_, a_, b_):
+        mu, Sig = ylm_moments_device(e, r=r_, dr=dr_, a=a_, b=b_, c=c, n=n)
+        return mu.cpu().numpy(), Sig.cpu().numpy()
+
+    mu, Sig = moments(r, dr, a, b)
+    lnl, g = log_likelihood_with_grad(mu, Sig, t, flux, data_var, **kwargs)
+    gmu, gSig = g["mean_ylm"], g["cov_ylm"]
+    N = mu.shape[0]
+    eps = np.ones(N) * defaults["epsy"]
+    eps[15 ** 2:] = defaults["epsy15"]
+    S0 = Sig - np.diag(eps)                       # the part of Sigma_y that scales with c and n
+    out = {k: v for k, v in g.items() if k not in ("mean_ylm", "cov_ylm")}
+    out.update({"c": float(gmu @ mu / c + 2.0 * np.sum(gSig * S0) / c),      # mu ~ c, Sigma ~ c^2 (contrast.py:21-33)
+                "n": float(gmu @ mu / n + np.sum(gSig * S0) / n)})           # mu ~ n, Sigma ~ n
+    x0 = {"r": r, "dr": dr, "a": a, "b": b}
+    for name in ("r", "dr", "a", "b"):
+        if x0[name] is None:
+            continue
+        step = h * max(abs(float(x0[name])), 0.1)
+        lo, hi = dict(x0), dict(x0)
+        lo[name], hi[name] = x0[name] - step, x0[name] + step
+        m0, S0_ = moments(lo["r"], lo["dr"], lo["a"], lo["b"])
+        m1, S1_ = moments(hi["r"], hi["dr"], hi["a"], hi["b"])
+        out[name] = float(gmu @ ((m1 - m0) / (2 * step)) + np.sum(gSig * ((S1_ - S0_) / (2 * step))))
+    return lnl, out

@@ -255,6 +255,38 @@ class StarryProcess(object):
             val = -np.inf
         return Eager(val)
 
+    def log_likelihood_grad(
+        self,
+        t,
+        flux,
+        data_cov,
+        i=defaults["i"],
+        p=defaults["p"],
+        u=defaults["u"][: defaults["udeg"]],
+        baseline_mean=defaults["baseline_mean"],
+        baseline_var=defaults["baseline_var"],
+    ):
+        """(lnL, grads): the log-likelihood of ONE light curve (scalar or per-point data variance, scalar
+        baseline terms) and its gradient -- what ``theano.grad(sp.log_likelihood(...), [r, a, b, c, n, p, ...])``
+        is in the reference (grad.py: one reverse sweep through the library's reverse-mode kernels).  A process
+        built from hyperparameters returns d/d(r, dr, a, b, c, n) and d/dp, d/dtau, d/di (conditional branch);
+        one built from explicit moments returns d/d(mean_ylm, cov_ylm) in their place."""
+        from .grad import hyper_gradient, log_likelihood_with_grad
+
+        kw = dict(i=float(np.asarray(i)), p=float(np.asarray(p)), u=np.asarray(u, dtype=np.float64),
+                  tau=self._tau if self._time_variable else None,
+                  temporal_kernel=self._temporal or "matern32", baseline_mean=float(baseline_mean),
+                  baseline_var=float(baseline_var),
+                  marginalize_over_inclination=self._marginalize_over_inclination, normalized=self._normalized,
+                  covpts=self._covpts, ydeg=self._ydeg, udeg=self._udeg, norm_order=self._normN,
+                  zmax=self._normzmax, device=self._kwargs.get("device"))
+        if self._dev_moments is not None:
+            lnl, g = hyper_gradient(t, flux, data_cov, r=self._r, dr=self._dr, a=self._a, b=self._b, c=self._c,
+                                    n=self._n, **kw)
+        else:
+            lnl, g = log_likelihood_with_grad(self._mean_ylm, self._cov_ylm, t, flux, data_cov, **kw)
+        return Eager(np.float64(lnl)), g
+
     # -- prior samples (sp.py:489-516, 729-765, 1237-1282) -------------------------------
     # The random numbers are NumPy's: the reference's Theano RandomStream cannot be
     # reproduced, so these methods are pinned by their moments, not by sample values.

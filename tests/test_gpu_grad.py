@@ -1,0 +1,191 @@
+"""
+End-to-end gradient of the log-likelihood (starry_process_amd/grad.py), pinned the way
+the reference pins its own (tests/test_lnlike.py:100-136, ``theano.gradient.verify_grad``: the analytic
+gradient against finite differences of the function) -- with the ORACLE as the function:
+
+  * the value the differentiable graph computes is the oracle's log-likelihood (1e-9 relative);
+  * d lnL / d(mu_y, Sigma_y): against central differences of the oracle's log-likelihood along random
+    directions in (mu_y, Sigma_y), both branches, normalised or not, with and without a temporal kernel;
+  * d lnL / d(r, a, b, c, n), d/dp, d/di, d/dtau: against central differences of the oracle's log-likelihood
+    evaluated on the oracle's own upstream quadrature (oracle.ylm_moments_quadrature) -- the reference test's
+    parameters, data set (t = linspace(0, 3, 100), unit-variance noise, normalized=False) and both branches.
+
+Tolerances: central differences with one Richardson step (truncation O(h^4), rounding O(eps lnL / h)) leave
+about 1e-8 of the gradient's scale; 2e-6 relative is asserted.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden
+from starry_process_amd.synthetic import synthetic_star
+
+pytestmark = pytest.mark.gpu
+
+YDEG = 15
+
+
+def _oracle_lnlike(mu, Sig, t, flux, data_var, marg=True, normalized=True, tau=None, i=60.0, p=1.0,
+                   kernel="matern32"):
+    import oracle.sp_oracle as orc
+
+    tk = orc.Matern32Kernel if kernel == "matern32" else orc.ExpSquaredKernel
+    op = orc.OracleProcess(mu, Sig, ydeg=YDEG, udeg=2, marginalize_over_inclination=marg, normalized=normalized,
+                           tau=tau, temporal_kernel=tk)
+    return op.log_likelihood(t, flux, data_var, i=i, p=p)
+
+
+def _central(f, h):
+    """Central difference of f about 0 with one Richardson step: error O(h^4) (the normalised likelihood of a
+    low-noise light curve has third derivatives large enough that the plain O(h^2) rule needs h < 1e-7)."""
+    d1 = (f(h) - f(-h)) / (2 * h)
+    d2 = (f(0.5 * h) - f(-0.5 * h)) / h
+    return (4.0 * d2 - d1) / 3.0
+
+
+def _oracle_moments(r, a, b, c, n):
+    import oracle.sp_oracle as orc
+    from starry_process_amd.upstream import ab_to_alphabeta, size_moments
+
+    s1, _ = size_moments(r, None, YDEG)
+    alpha, beta = ab_to_alphabeta(a, b)
+    return orc.ylm_moments_quadrature(s1, s1[None, :], alpha, beta, c, n, YDEG)
+
+
+def _reference_data():
+    """tests/test_lnlike.py:108-112."""
+    rng = np.random.RandomState(42)
+    t = np.linspace(0, 3, 100)
+    return t, rng.randn(len(t)), 1.0
+
+
+def _moments():
+    g = golden("moments_L15")
+    return g["default_mean_ylm"], g["default_cov_ylm"]
+
+
+CASES = [
+    dict(marg=True, normalized=False, tau=None),
+    dict(marg=True, normalized=True, tau=None),
+    dict(marg=False, normalized=False, tau=None),
+    dict(marg=False, normalized=True, tau=None),
+    dict(marg=True, normalized=True, tau=0.7),
+    dict(marg=False, normalized=False, tau=0.7),
+]
+
+
+def _data(case):
+    if case["normalized"]:
+        st = synthetic_star(3, 96)
+        return st["t"], st["flux"], 1e-6, st["p"], st["i"]
+    t, f, v = _reference_data()
+    return t, f, v, 1.3, 70.0
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%s-%s-tau%s" % ("marg" if c["marg"] else "cond",
+                                                                         "norm" if c["normalized"] else "raw", c["tau"]))
+def test_value_and_moment_gradient_match_the_oracle(case):
+    from starry_process_amd.grad import log_likelihood_with_grad
+
+    mu, Sig = _moments()
+    t, flux, dv, p, inc = _data(case)
+    kw = dict(marginalize_over_inclination=case["marg"], normalized=case["normalized"], tau=case["tau"], i=inc, p=p)
+    lnl, g = log_likelihood_with_grad(mu, Sig, t, flux, dv, ydeg=YDEG, **kw)
+    okw = dict(marg=case["marg"], normalized=case["normalized"], tau=case["tau"], i=inc, p=p)
+    ref = _oracle_lnlike(mu, Sig, t, flux, dv, **okw)
+    assert np.isfinite(ref)
+    assert abs(lnl - ref) < 1e-9 * abs(ref)
+    rng = np.random.RandomState(7)
+    for trial in range(2):
+        dmu = rng.randn(mu.shape[0]) * np.abs(mu).max()
+        B = rng.randn(*Sig.shape)
+        dS = (B + B.T) * 0.5 * np.abs(Sig).max() / 16.0
+        if trial == 1:      # the low degrees carry the signal: a direction confined to them
+            dmu[25:] = 0.0
+            dS[25:, :] = 0.0
+            dS[:, 25:] = 0.0
+        analytic = g["mean_ylm"] @ dmu + np.sum(g["cov_ylm"] * dS)
+        f = lambda h: _oracle_lnlike(mu + h * dmu, Sig + h * dS, t, flux, dv, **okw)    # noqa: E731
+        # two step sizes: their disagreement is the differences' own uncertainty (rounding noise of the oracle's
+        # likelihood divided by h -- 1e-5 absolute on the low-noise normalised light curve, which matters where
+        # the directional derivative happens to be small: the conditional normalised case)
+        fd1, fd2 = _central(f, 4e-6), _central(f, 8e-6)
+        fd, unc = 0.5 * (fd1 + fd2), abs(fd1 - fd2)
+        print("directional derivative %.10g, differences %.10g +- %.1g" % (analytic, fd, unc))
+        assert unc < 1e-4 * abs(fd)
+        assert abs(analytic - fd) < 2e-6 * abs(fd) + 2 * unc, (trial, analytic, fd1, fd2)
+
+
+@pytest.mark.parametrize("marg", [True, False], ids=["marg", "cond"])
+@pytest.mark.parametrize("param", ["r", "a", "b", "c", "n", "i", "p", "tau"])
+def test_hyper_gradient_against_finite_differences_of_the_oracle(param, marg):
+    """The reference's test_lnlike_grad, parameter by parameter (plus tau)."""
+    from starry_process_amd.defaults import defaults
+    from starry_process_amd.grad import hyper_gradient
+
+    if param == "i" and marg:
+        pytest.skip("the inclination is integrated out")
+    t, flux, dv = _reference_data()
+    hp = {k: float(defaults[k]) for k in ("r", "a", "b", "c", "n")}
+    ex = dict(i=65.0, p=1.1, tau=0.9 if param == "tau" else None)
+    lnl, g = hyper_gradient(t, flux, dv, ydeg=YDEG, normalized=False, marginalize_over_inclination=marg, **hp, **ex)
+
+    def f(x):
+        q, e2 = dict(hp), dict(ex)
+        (q if param in q else e2)[param] = x
+        mu, Sig = _oracle_moments(**q)
+        return _oracle_lnlike(mu, Sig, t, flux, dv, marg=marg, normalized=False, **e2)
+
+    x0 = hp[param] if param in hp else ex[param]
+    assert abs(lnl - f(x0)) < 1e-9 * abs(lnl)
+    fd = _central(lambda h: f(x0 + h), 1e-4 * max(abs(x0), 0.1))
+    assert abs(g[param] - fd) < 2e-6 * max(abs(fd), 1e-3 * abs(lnl)), (param, g[param], fd)
+
+
+def test_normalised_hyper_gradient_and_failure():
+    """Normalised process on a realistic light curve; and a star the likelihood rejects returns -inf with a
+    zero gradient rather than NaNs."""
+    from starry_process_amd.defaults import defaults
+    from starry_process_amd.grad import hyper_gradient, log_likelihood_with_grad
+
+    st = synthetic_star(5, 128)
+    hp = {k: float(defaults[k]) for k in ("r", "a", "b", "c", "n")}
+    lnl, g = hyper_gradient(st["t"], st["flux"], st["data_cov"], p=st["p"], ydeg=YDEG, **hp)
+    for param in ("a", "c"):
+        def f(x):
+            q = dict(hp)
+            q[param] = x
+            mu, Sig = _oracle_moments(**q)
+            return _oracle_lnlike(mu, Sig, st["t"], st["flux"], st["data_cov"], p=st["p"])
+        fd = _central(lambda h: f(hp[param] + h), 1e-3 * max(hp[param], 0.1))   # (below 1e-4: rounding noise)
+        assert abs(g[param] - fd) < 2e-6 * max(abs(fd), 1e-3 * abs(lnl)), (param, g[param], fd)
+    mu, Sig = _moments()
+    bad, gb = log_likelihood_with_grad(mu, -Sig, st["t"], st["flux"], 1e-12, ydeg=YDEG, normalized=False)
+    assert bad == -np.inf and not np.any(gb["cov_ylm"]) and gb["p"] == 0.0
+
+
+def test_facade_log_likelihood_grad():
+    """StarryProcess.log_likelihood_grad: the value is log_likelihood's, the gradient hyper_gradient's; a process
+    built from explicit moments (a sum of two populations) returns the gradient with respect to the moments."""
+    from starry_process_amd import StarryProcess
+    from starry_process_amd.grad import hyper_gradient
+
+    st = synthetic_star(2, 80)
+    sp = StarryProcess(r=20.0, a=0.5, b=0.3, c=0.08, n=5.0, tau=1.5, upstream="device")
+    lnl, g = sp.log_likelihood_grad(st["t"], st["flux"], st["data_cov"], p=st["p"])
+    ref = float(sp.log_likelihood(st["t"], st["flux"], st["data_cov"], p=st["p"]).eval())
+    assert abs(float(lnl.eval()) - ref) < 1e-9 * abs(ref)
+    _, g2 = hyper_gradient(st["t"], st["flux"], st["data_cov"], r=20.0, a=0.5, b=0.3, c=0.08, n=5.0, tau=1.5,
+                           p=st["p"])
+    assert set(g) == {"r", "a", "b", "c", "n", "p", "tau"} and all(g[k] == g2[k] for k in g)
+    # per-point data variance, a spread of radii, the conditional branch
+    sp = StarryProcess(r=20.0, dr=5.0, marginalize_over_inclination=False, normalized=False, upstream="device")
+    var = np.linspace(1e-6, 2e-6, 80)
+    lnl, g = sp.log_likelihood_grad(st["t"], st["flux"], var, i=st["i"], p=st["p"], baseline_var=1e-4)
+    ref = float(sp.log_likelihood(st["t"], st["flux"], var, i=st["i"], p=st["p"], baseline_var=1e-4).eval())
+    assert abs(float(lnl.eval()) - ref) < 1e-9 * abs(ref)
+    assert set(g) == {"r", "dr", "a", "b", "c", "n", "p", "i"} and all(np.isfinite(v) for v in g.values())
+    both = StarryProcess(r=15.0, upstream="device") + StarryProcess(r=25.0, a=0.2, upstream="device")
+    lnl, g = both.log_likelihood_grad(st["t"], st["flux"], st["data_cov"], p=st["p"])
+    ref = float(both.log_likelihood(st["t"], st["flux"], st["data_cov"], p=st["p"]).eval())
+    assert abs(float(lnl.eval()) - ref) < 1e-9 * abs(ref)
+    assert g["mean_ylm"].shape == (256,) and g["cov_ylm"].shape == (256, 256)
