@@ -408,6 +408,9 @@ int sp_debug_set_look_ahead(sp_handle *h, int on);
  * 64 x 3 x 16 int64 (pivot block, work item of star 0 {diagonal block, first tile, last tile},
  * stamp).  tools/panel2_trace.py                                                             */
 int sp_debug_panel2_trace(long long *out);
+/* (debug, same builds) the block every star's first item factors in its tail, per launch:
+ * 16 x 64 x 4 int64 (pivot block j, star, {first item start, block start, block end, CU key}).     */
+int sp_debug_panel2_chain(long long *out);
 
 #ifdef __cplusplus
 }

@@ -90,6 +90,7 @@ PROTOTYPES = {
     "sp_ylm_moments_quadrature": (_I, [_V, _V, _I, _I, _V, _V, _I, _I, _D, _D, _D, _D,
                                        _V, _V, _V]),
     "sp_debug_panel2_trace": (_I, [_V]),
+    "sp_debug_panel2_chain": (_I, [_V]),
     "sp_debug_set_look_ahead": (_I, [_V, _I]),
     "sp_profile_kind": (_I, [_V, _I, ctypes.POINTER(ctypes.c_long), c_double_p, c_double_p]),
     "sp_set_lazy_cov": (_I, [_V, _I]),

@@ -52,12 +52,19 @@
 // (variant build only, tools/ab_build.sh trace -DSP_PANEL_TRACE: wall-clock stamps of star 0's work
 //  items; rows = pivot blocks, roles: 0 the D item, 1 the first T item, 2 the last; sp_debug_panel2_trace)
 __device__ long long g_p2trace[64 * 3 * 16];
+// ... and of EVERY star's tail block per launch: [j < 16][star < 64] x (first item start, block start, block end, CU key)
+__device__ long long g_p2chain[16 * 64 * 4];
+#define P2_CHAIN(k, v)                                                                          \
+  do {                                                                                          \
+    if (tid == 0 && a.j < 16 && mtx < 64) g_p2chain[((a.j * 64) + mtx) * 4 + (k)] = (v);        \
+  } while (0)
 #define P2_STAMP(role, k)                                                                       \
   do {                                                                                          \
     if (mtx == 0 && tid == 0 && a.j < 64 && (role) >= 0) g_p2trace[(a.j * 3 + (role)) * 16 + (k)] = wall_clock64(); \
   } while (0)
 #else
 #define P2_STAMP(role, k) do { } while (0)
+#define P2_CHAIN(k, v) do { } while (0)
 #endif
 
 #ifndef P_WGS
@@ -105,6 +112,16 @@ struct PanelArgs {
 
 typedef double pd4 __attribute__((ext_vector_type(4)));
 
+#ifdef SP_PANEL_TRACE
+// (trace builds) the CU a workgroup runs on: HW_REG_XCC_ID[2:0] | HW_REG_HW_ID[15:8] (CU, SH, SE) -- 256 distinct
+// values on this part (tools/micro/hwid.hip)
+__device__ __forceinline__ long long cu_key() {
+  const unsigned hw = __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));
+  const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;
+  return (long long)(xcc * 256 + hw);
+}
+#endif
+
 // items of a star in a launch: [D item] then the row tiles below the pivot block -- the next pivot
 // row tile alone (it is on the critical path: 64 rows), then PAIRS of row tiles (128 rows per
 // workgroup: the pivot rows' fragments feed eight MFMAs instead of four, half the workgroups per
@@ -125,10 +142,17 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
   const long ld = a.ld;
   const int Kd = 64 * (kb1 - kb0);
   const double *img = img_star + (size_t)(a.j & 1) * SP_LT_IMG;
+  const bool chain = NR == 1 && !la && i0 == a.j + 1 && (a.mode & P_TAILD);   // this item factors the next block
 #ifdef SP_PANEL_TRACE
   const int role = i0 == a.j + 1 ? 1 : (i0 + NR == a.ntile ? 2 : -1);
 #endif
   P2_STAMP(role, 0);
+  if (NR == 1 && !la && i0 == a.j + 1) P2_CHAIN(0, wall_clock64());
+#ifndef P_NO_CHAIN_PRIO
+  // the next pivot row tile is the launch's critical chain from its first instruction, not only from
+  // its diagonal block on: its wavefronts go first wherever they share a SIMD
+  if (chain) __builtin_amdgcn_s_setprio(3);
+#endif
   double *Ct = M + (size_t)(64 * i0) * ld + 64 * cb;           // tiles (i0 .., cb)
   const double *Ab = M + (size_t)(64 * i0) * ld + 64 * kb0;    // own rows, the product's columns
   const double *Bb = M + (size_t)(64 * cb) * ld + 64 * kb0;    // the pivot row tile
@@ -270,7 +294,7 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
     const int i = i0 + h;
     if (i > a.last) break;
     double *sX = smem;
-    __syncthreads();               // (the image / the previous half's X has been read by every wavefront)
+      __syncthreads();               // (the image / the previous half's X has been read by every wavefront)
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
       double *dst = sX + (16 * wave + fr) * XLD + 16 * nb + 4 * fk;
@@ -319,15 +343,18 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
         }
       __builtin_amdgcn_s_setprio(3);
       P2_STAMP(0, 0);
+      P2_CHAIN(1, wall_clock64());
+      P2_CHAIN(3, cu_key());
 #ifdef SP_PANEL_TRACE
       panel_diag_core(Dt, ld, nact, img_star + (size_t)((a.j + 1) & 1) * SP_LT_IMG,
-                      a.info ? a.info + mtx : nullptr, smem, tid, nullptr, nullptr,
+                      a.info ? a.info + mtx : nullptr, smem, tid,
                       (mtx == 0 && a.j < 64) ? &g_p2trace[(a.j * 3) * 16 + 8] : nullptr);
 #else
       panel_diag_core(Dt, ld, nact, img_star + (size_t)((a.j + 1) & 1) * SP_LT_IMG,
                       a.info ? a.info + mtx : nullptr, smem, tid);
 #endif
       __builtin_amdgcn_s_setprio(0);
+      P2_CHAIN(2, wall_clock64());
       P2_STAMP(0, 2);
     }
   }
@@ -347,7 +374,7 @@ __global__ __launch_bounds__(256, P_WGS) void panel_kernel(PanelArgs a) {
     P2_STAMP(0, 0);
     double *img = img_star + (size_t)(a.j & 1) * SP_LT_IMG;
 #ifdef SP_PANEL_TRACE
-    panel_diag_item(M, a.ld, a.j, a.nact, img, a.info ? a.info + mtx : nullptr, smem, tid, nullptr, nullptr,
+    panel_diag_item(M, a.ld, a.j, a.nact, img, a.info ? a.info + mtx : nullptr, smem, tid,
                     (mtx == 0 && a.j < 64) ? &g_p2trace[(a.j * 3) * 16 + 8] : nullptr);
 #else
     panel_diag_item(M, a.ld, a.j, a.nact, img, a.info ? a.info + mtx : nullptr, smem, tid);
@@ -425,6 +452,17 @@ extern "C" int sp_debug_panel2_trace(long long *out) {
     return SP_OK;
   }
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p2trace), sizeof(long long) * 64 * 3 * 16) != hipSuccess) return SP_ERR_HIP;
+  return SP_OK;
+#else
+  (void)out;
+  return SP_ERR_INVALID;
+#endif
+}
+
+// (debug, variant builds) every star's tail block per launch: 16 x 64 x 4 int64
+extern "C" int sp_debug_panel2_chain(long long *out) {
+#ifdef SP_PANEL_TRACE
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p2chain), sizeof(long long) * 16 * 64 * 4) != hipSuccess) return SP_ERR_HIP;
   return SP_OK;
 #else
   (void)out;

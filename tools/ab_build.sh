@@ -11,8 +11,9 @@ for f in sp_host.cpp sp_wigner.hip sp_gemm.hip sp_panel.hip sp_cond.hip sp_upstr
   case $f in sp_wigner.hip|sp_assemble.hip|sp_table.hip|sp_host.cpp) fl="$fl -ffp-contract=off";; esac
   case $f in sp_cholesky.hip|sp_gemm.hip|sp_panel.hip|sp_cond.hip) fl="$fl -mllvm -amdgpu-mfma-vgpr-form=1";; esac
   /opt/rocm/bin/hipcc $fl "$@" -I. -c $f -o $tmp/${f%.*}.o &
+  pids="$pids $!"
 done
-wait
+for p in $pids; do wait $p; done      # (set -e: a failed compile stops the build)
 /opt/rocm/bin/hipcc -shared --offload-arch=gfx950 -o ../libsp_hip_$name.so $tmp/*.o
 rm -rf $tmp
 echo built ../libsp_hip_$name.so

@@ -43,3 +43,18 @@ for j in range(64):
                 name, us(p[0]), d(p, 0, 1), d(p, 1, 2), d(p, 2, 3), d(p, 3, 4), d(p, 4, 5), d(p, 5, 6),
                 us(p[6] if p[6] else p[5]))
     print(line)
+
+# every star's tail block: how the 64 chains of a launch sit on the CUs
+cb = np.zeros(16 * 64 * 4, dtype=np.int64)
+check(e._L.sp_debug_panel2_chain(cb.ctypes.data_as(ctypes.c_void_p)))
+cb = cb.reshape(16, 64, 4)
+print("per launch: first items start (min..max) | blocks start | blocks end | block duration min / median / max | CUs used, most chains on one CU")
+for j in range(16):
+    c = cb[j][cb[j][:, 2] > 0]
+    if not len(c):
+        continue
+    f0, b0, b1 = [us(c[:, k].astype(np.float64)) for k in range(3)]
+    dur = b1 - b0
+    keys, cnt = np.unique(c[:, 3], return_counts=True)
+    print("j %2d | first %7.1f..%7.1f | block start %7.1f..%7.1f | end %7.1f..%7.1f | %5.1f / %5.1f / %5.1f | %d CUs, max %d" % (
+        j, f0.min(), f0.max(), b0.min(), b0.max(), b1.min(), b1.max(), dur.min(), np.median(dur), dur.max(), len(keys), cnt.max()))
