@@ -161,16 +161,20 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
   // accumulators of G = T^T: g[h][m][r] = T[64 h + 16 wave + fr][16 m + 4 fk + r]
   pd4 g[NR][4];
   double *crow = Ct + (size_t)(16 * wave + fr) * ld + 4 * fk;
+#ifndef P_IMG_PREFETCH
+#define P_IMG_PREFETCH 1
+#endif
   PanelRegs<PK> ra[NR], rb;
   // (tiles evaluated at first touch: the first operand slices are requested after the evaluation --
   //  48 registers of loads in flight across it made the compiler spill the spline's constants and
   //  reload them for every entry)
   const bool any_lazy = may_lazy && a.lz.theta && cb > 0 && i0 < a.lz.nfull;
-  if (Kd > 0 && !any_lazy) {
+  auto first_loads = [&]() {
 #pragma unroll
     for (int h = 0; h < NR; ++h) stage_load_fast<PK>(Ab, ld, 64 * h, 0, ra[h], tid);
     stage_load_fast<PK>(Bb, ld, 0, 0, rb, tid);
-  }
+  };
+  if (Kd > 0 && !any_lazy) first_loads();
 #pragma unroll
   for (int h = 0; h < NR; ++h) {
     // (first super-panel of a system whose assembly left the tile to its first touch, sp_cov.h:
@@ -187,26 +191,23 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
       lazy_cov_row(a.lz, mtx, 64 * (i0 + h) + 16 * wave + fr, 64 * cb + 4 * fk, g[h], smem, tid);
     }
   }
-  if (Kd > 0 && any_lazy) {
-#pragma unroll
-    for (int h = 0; h < NR; ++h) stage_load_fast<PK>(Ab, ld, 64 * h, 0, ra[h], tid);
-    stage_load_fast<PK>(Bb, ld, 0, 0, rb, tid);
-  }
+  if (Kd > 0 && any_lazy) first_loads();
   P2_STAMP(role, 1);
+
+  // the image of the pivot block's inverse (the solve's A fragments): requested behind the LAST slice's
+  // loads, so that its round trip runs under that slice's MFMAs instead of after them
+  d2v im[5];
+  auto image_loads = [&](bool now = false) {
+    if (la || (!(P_IMG_PREFETCH && NR == 1) && !now)) return;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) im[c] = *reinterpret_cast<const d2v *>(img + 2 * (tid + 256 * c));
+  };
+  if (Kd == 0) image_loads(true);
 
   // G -= B_panel A_panel^T: the pivot rows are the MFMA's A operand (rows through PI), the own rows its B
   {
     const int pfr = sp_pi16(fr);
-    for (int k0 = 0; k0 < Kd; k0 += PK) {
-#pragma unroll
-      for (int h = 0; h < NR; ++h) stage_store<PK>(ra[h], -1.0, sA + h * 64 * PLDW, tid);
-      stage_store<PK>(rb, 1.0, sB, tid);
-      __syncthreads();
-      if (k0 + PK < Kd) {
-#pragma unroll
-        for (int h = 0; h < NR; ++h) stage_load_fast<PK>(Ab, ld, 64 * h, k0 + PK, ra[h], tid);
-        stage_load_fast<PK>(Bb, ld, 0, k0 + PK, rb, tid);
-      }
+    auto mfma_slice = [&]() {
       const double *pa = sB + pfr * PLDW + fk;               // pivot rows 16 m + PI(fr)
       const double *pb = sA + (16 * wave + fr) * PLDW + fk;   // own rows 64 h + 16 wave + fr
       // (NR = 2: unrolled by two k-steps only -- fully unrolled the scheduler hoists the fragment
@@ -223,6 +224,27 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
           g[h][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b, g[h][3], 0, 0, 0);
         }
       }
+    };
+    // (the last slice is peeled off the loop: the image's registers are live from there on only)
+    int k0 = 0;
+    for (; k0 + PK < Kd; k0 += PK) {
+#pragma unroll
+      for (int h = 0; h < NR; ++h) stage_store<PK>(ra[h], -1.0, sA + h * 64 * PLDW, tid);
+      stage_store<PK>(rb, 1.0, sB, tid);
+      __syncthreads();
+#pragma unroll
+      for (int h = 0; h < NR; ++h) stage_load_fast<PK>(Ab, ld, 64 * h, k0 + PK, ra[h], tid);
+      stage_load_fast<PK>(Bb, ld, 0, k0 + PK, rb, tid);
+      mfma_slice();
+      __syncthreads();
+    }
+    if (k0 < Kd) {
+#pragma unroll
+      for (int h = 0; h < NR; ++h) stage_store<PK>(ra[h], -1.0, sA + h * 64 * PLDW, tid);
+      stage_store<PK>(rb, 1.0, sB, tid);
+      __syncthreads();
+      image_loads();
+      mfma_slice();
       __syncthreads();
     }
   }
@@ -242,14 +264,22 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
   }
   P2_STAMP(role, 3);
   // the image: one copy per workgroup through LDS (each wavefront needs all of it)
-  {
-    d2v im[5];
+  if (!(P_IMG_PREFETCH && NR == 1)) image_loads(true);
 #pragma unroll
-    for (int c = 0; c < 5; ++c) im[c] = *reinterpret_cast<const d2v *>(img + 2 * (tid + 256 * c));
-#pragma unroll
-    for (int c = 0; c < 5; ++c) *reinterpret_cast<d2v *>(smem + 2 * (tid + 256 * c)) = im[c];
-  }
+  for (int c = 0; c < 5; ++c) *reinterpret_cast<d2v *>(smem + 2 * (tid + 256 * c)) = im[c];
   __syncthreads();
+  // (the diagonal tile of the first row tile's eager update: requested now, it arrives under the solve)
+  pd4 dacp[4];
+#ifndef P_DAC_PREFETCH
+#define P_DAC_PREFETCH 1
+#endif
+  if (P_DAC_PREFETCH && NR == 1 && i0 <= a.last) {
+    const double *Dt0 = M + (size_t)(64 * i0) * ld + 64 * i0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dacp[m][r] = Dt0[(size_t)(16 * wave + fk + 4 * r) * ld + 16 * m + fr];
+  }
   // Y = X^T = L_d^-1 G, block rows nb = 3 .. 0: y[nb] = sum_{kb <= nb} Linv(nb, kb) G(kb);
   // y[h][nb][r] = X[64 h + 16 wave + fr][16 nb + 4 fk + r]
   pd4 y[NR][4];
@@ -304,9 +334,14 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
     double *Dt = M + (size_t)(64 * i) * ld + 64 * i;
     pd4 dac[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < 4; ++m) {
+      if (P_DAC_PREFETCH && NR == 1 && h == 0) {
+        dac[m] = dacp[m];
+      } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dac[m][r] = Dt[(size_t)(16 * wave + fk + 4 * r) * ld + 16 * m + fr];
+        for (int r = 0; r < 4; ++r) dac[m][r] = Dt[(size_t)(16 * wave + fk + 4 * r) * ld + 16 * m + fr];
+      }
+    }
     __syncthreads();
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
@@ -321,10 +356,14 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
         dac[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(-y[h][nb][3], hi.y, dac[m], 0, 0, 0);
       }
     }
+    // (a full next pivot block goes from these registers straight into its factorisation, which writes
+    //  the tile itself; a partial one reads its rows below the active part back from memory)
+    if (!(chain && a.next_nact == 64)) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Dt[(size_t)(16 * wave + fk + 4 * r) * ld + 16 * m + fr] = dac[m][r];
+        for (int r = 0; r < 4; ++r) Dt[(size_t)(16 * wave + fk + 4 * r) * ld + 16 * m + fr] = dac[m][r];
+    }
     P2_STAMP(role, 6);
     if (NR == 1 && (a.mode & P_TAILD) && i == a.j + 1 && a.next_nact > 0) {
       // the next pivot block, complete now and still in registers: factored here, in the shadow of
