@@ -1027,6 +1027,7 @@ int sp_lnlike_ensemble(sp_handle *h, int S, int K, int M, const double *t_dev,
     if (!h->gfork) SP_HIP(hipEventCreateWithFlags(&h->gfork, hipEventDisableTiming));
     SP_HIP(hipEventRecord(h->gfork, st));
   }
+  const bool fused_reduce = sp_panel_fuses_reduce(h, K, L.Kp);
   std::vector<Layout> LG(G, L);
   std::vector<sp_chol_group> CG(G);
   std::vector<int> first(G);
@@ -1037,7 +1038,13 @@ int sp_lnlike_ensemble(sp_handle *h, int S, int K, int M, const double *t_dev,
     hipStream_t sg = g == 0 ? st : h->gstream[g - 1];
     if (g > 0) SP_HIP(hipStreamWaitEvent(sg, h->gfork, 0));
     CG[g] = sp_chol_group{at<double>(ws, LG[g].sys), at<int32_t>(ws, LG[g].info),
-                          at<double>(ws, LG[g].invL), s1 - s0, sg, LazyCov{}};
+                          at<double>(ws, LG[g].invL), s1 - s0, sg, LazyCov{}, SpReduceArgs{}};
+    // the reduction rides in the tail of the last panel launch when the system's shape allows
+    if (fused_reduce)
+      CG[g].red = SpReduceArgs{lnlike_dev + s0, at<uint32_t>(ws, LG[g].status),
+                               status_dev ? status_dev + s0 : nullptr, stars_dev + s0,
+                               (normalized && h->defer_norm) ? (const void *)at<double>(ws, LG[g].coef) : nullptr,
+                               K, M, K + M + 3};
   }
   // Tiles formed at first touch (LazyCov, sp_cov.h): the marginal path under the deferred
   // normalisation.
@@ -1066,9 +1073,10 @@ int sp_lnlike_ensemble(sp_handle *h, int S, int K, int M, const double *t_dev,
   }
   for (int g = 0; g < G; ++g) {
     const int s0 = first[g];
-    int rc = lnlike_finish(LG[g], ws, K, M, lnlike_dev + s0,
-                           status_dev ? status_dev + s0 : nullptr, CG[g].st, stars_dev + s0,
-                           normalized && h->defer_norm);
+    int rc = fused_reduce ? SP_OK
+                          : lnlike_finish(LG[g], ws, K, M, lnlike_dev + s0,
+                                          status_dev ? status_dev + s0 : nullptr, CG[g].st, stars_dev + s0,
+                                          normalized && h->defer_norm);
     if (rc) return rc;
     if (g > 0) {
       SP_HIP(hipEventRecord(h->gdone[g - 1], CG[g].st));

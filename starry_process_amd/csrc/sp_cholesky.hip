@@ -21,129 +21,23 @@
 
 #include "sp_tile.h"
 #include "sp_paneldiag.h"
+#include "sp_reduce.h"
 
 #define DLD 65  // padded row length of a diagonal block in cho_solve_kernel
 
 namespace {
 
-// lnlike = -1/2 sum_m |y_m|^2 - M sum_i log L_ii - K M / 2 log(2 pi)
-// (sp.py:1157-1188).  One workgroup per star.
-//
-// coef != nullptr: deferred normalisation (sp_assemble.hip, defer_finish_kernel).  The factored
-// matrix is B'' = Sigma + N / c1 and the true covariance is
-//     C = c1 (B'' + d_p p p^T + d_1 1 1^T + d_q q q^T),
-// with y_p, y_q, y_1 = L''^-1 p, q, 1 in the three rows below the residuals.  The matrix
-// determinant lemma and the Sherman-Morrison formula, one rank at a time (the two non-negative
-// terms first), give log det C and r^T C^-1 r from the Gram matrix of those rows and the
-// residuals'; a rank-1 step whose pivot 1 + d u^T B^-1 u is not positive means C is not positive
-// definite: the same -inf the reference's failed Cholesky gives (math.py:82-91, sp.py:1186-1188).
-struct RedCoef {   // = Coef of sp_assemble.hip
-  double c1, dp, dq, z, gpmean, m, mu, d1;
-};
-
+// one workgroup per star (sp_reduce.h)
 __global__ __launch_bounds__(256) void lnlike_reduce_kernel(
     const double *__restrict__ sys, long ld, long stride, int K, int M,
     const int32_t *__restrict__ info, double *__restrict__ lnlike,
     uint32_t *__restrict__ status, uint32_t *__restrict__ status_out,
     const sp_star *__restrict__ stars, const RedCoef *__restrict__ coef) {
-  __shared__ double red[4][12];
+  __shared__ double red[48];
   const int s = blockIdx.x;
-  const double *Mx = sys + (size_t)s * stride;
-  const int wave = threadIdx.x >> 6;
-  // sums of v[0 .. 12) over the workgroup, in every thread (all twelve always: constant indices
-  // keep v in registers; the unused ones are zero)
-  auto block_sum = [&](double (&v)[12]) {
-#pragma unroll
-    for (int a = 0; a < 12; ++a)
-      for (int off = 32; off > 0; off >>= 1) v[a] += __shfl_down(v[a], off, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-      for (int a = 0; a < 12; ++a) red[wave][a] = v[a];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int a = 0; a < 12; ++a) v[a] = (red[0][a] + red[1][a]) + (red[2][a] + red[3][a]);
-  };
-  double v[12];
-  for (int a = 0; a < 12; ++a) v[a] = 0.0;
-  const double *yp = Mx + (size_t)(K + M) * ld, *yq = yp + ld, *y1 = yq + ld;
-  const double *y0 = Mx + (size_t)K * ld;       // the first light curve's residuals ride in the same pass
-  for (int i = threadIdx.x; i < K; i += 256) {
-    v[0] += log(Mx[(size_t)i * ld + i]);
-    const double r = y0[i];
-    v[7] += r * r;
-    if (coef) {
-      const double a = yp[i], b = yq[i], c = y1[i];
-      v[1] += a * a; v[2] += a * b; v[3] += a * c; v[4] += b * b; v[5] += b * c; v[6] += c * c;
-      v[8] += r * a; v[9] += r * c; v[10] += r * b;
-    }
-  }
-  block_sum(v);
-  const double logdet = v[0];
-  // rank-1 steps on the 3 x 3 Gram matrix H (0 = p, 1 = 1, 2 = q): factor f_k and old column c_k
-  double f[3] = {0.0, 0.0, 0.0}, col[3][3], logs = 0.0;
-  bool notpd = false;
-  double c1 = 1.0;
-  if (coef) {
-    const RedCoef rc = coef[s];
-    c1 = rc.c1;
-    double H[3][3] = {{v[1], v[3], v[2]}, {v[3], v[6], v[5]}, {v[2], v[5], v[4]}};
-    const double d[3] = {rc.dp, rc.d1, rc.dq};
-    for (int k = 0; k < 3; ++k) {
-      for (int a = 0; a < 3; ++a) col[k][a] = H[a][k];
-      if (d[k] == 0.0) continue;
-      const double piv = 1.0 + d[k] * H[k][k];
-      if (!(piv > 0.0)) notpd = true;
-      logs += log(piv);
-      f[k] = d[k] / piv;
-      for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) H[a][b] -= f[k] * col[k][a] * col[k][b];
-    }
-  }
-  double quad = 0.0;
-  for (int m = 0; m < M; ++m) {
-    const double *y = Mx + (size_t)(K + m) * ld;
-    double w[12];
-    for (int a = 0; a < 12; ++a) w[a] = 0.0;
-    if (m == 0) {
-      w[0] = v[7]; w[1] = v[8]; w[2] = v[9]; w[3] = v[10];
-    } else {
-      for (int k = threadIdx.x; k < K; k += 256) {
-        const double r = y[k];
-        w[0] += r * r;
-        if (coef) {
-          w[1] += r * yp[k];
-          w[2] += r * y1[k];
-          w[3] += r * yq[k];
-        }
-      }
-      block_sum(w);
-    }
-    double g = w[0], h[3] = {w[1], w[2], w[3]};
-    for (int k = 0; k < 3; ++k) {
-      if (f[k] == 0.0) continue;
-      const double hk = h[k];
-      g -= f[k] * hk * hk;
-      for (int a = 0; a < 3; ++a) h[a] -= f[k] * hk * col[k][a];
-    }
-    quad += g;
-  }
-  if (threadIdx.x == 0) {
-    // (ragged ensembles: the padding rows have unit pivots and zero residuals, only
-    //  the constants know the number of valid cadences)
-    const int nobs = (stars && stars[s].nobs > 0 && stars[s].nobs < K) ? stars[s].nobs : K;
-    double val = -0.5 * quad / c1;
-    val -= M * (logdet + 0.5 * nobs * log(c1) + 0.5 * logs);
-    val -= 0.5 * nobs * M * 1.8378770664093453;  // log(2 pi)
-    uint32_t st = status ? status[s] : 0u;
-    if ((info && info[s]) || notpd) st |= SP_STAR_NOT_PD;
-    if (val != val) st |= SP_STAR_NAN;
-    if (st & (SP_STAR_NOT_PD | SP_STAR_ZMAX | SP_STAR_NAN)) val = -INFINITY;
-    lnlike[s] = val;
-    if (status) status[s] = st;
-    if (status_out) status_out[s] = st;
-  }
+  lnlike_reduce_body<false>(sys + (size_t)s * stride, ld, K, M, info ? info + s : nullptr, lnlike + s,
+                            status ? status + s : nullptr, status_out ? status_out + s : nullptr,
+                            stars ? stars + s : nullptr, coef ? coef + s : nullptr, red, threadIdx.x);
 }
 
 // copy a batch of K x K matrices into zero/identity padded Kp x Kp systems
@@ -329,6 +223,7 @@ static int cholesky_panel2(sp_handle *h, int ngroups, const sp_chol_group *grp, 
   const long ld = Kp, stride = (long)Kp * Kp, lts = sp_lt_stride(Kp);
   const int nsteps = (K + SP_NB - 1) / SP_NB, ntile = Kp / SP_NB;
   const bool la_on = h->look_ahead != 0;
+  const bool fuse_reduce = sp_panel_fuses_reduce(h, K, Kp);
   auto nact_of = [&](int j) { return K - j * SP_NB < SP_NB ? K - j * SP_NB : SP_NB; };
   for (int s0 = 0; s0 < nsteps; s0 += w) {
     {
@@ -358,13 +253,15 @@ static int cholesky_panel2(sp_handle *h, int ngroups, const sp_chol_group *grp, 
           sp_scope.add(fl, nl);
           int rc = SP_OK;
           if (d_alone)
-            rc = sp_launch_panel2(G.sys, ld, stride, G.S, ntile, j, s0, nact_of(j), 0, last, SP_PANEL_D, h->ncu,
-                                  G.invL, lts, G.info, G.st, nullptr);
+            rc = sp_launch_panel2(nullptr, G.sys, ld, stride, G.S, ntile, j, s0, nact_of(j), 0, last, SP_PANEL_D,
+                                  h->ncu, G.invL, lts, G.info, G.st, nullptr);
           const int what = rows > 0 ? (SP_PANEL_T | (tail ? SP_PANEL_TAILD : 0) | (la ? SP_PANEL_LA : 0) |
                                        (first_la ? SP_PANEL_FIRSTLA : 0))
                                     : 0;
+          // (the launch whose tail factors the LAST pivot block carries the reduction, if there is one)
+          const SpReduceArgs *red = (tail && j + 1 == nsteps - 1 && fuse_reduce) ? &G.red : nullptr;
           if (rc == SP_OK && what)
-            rc = sp_launch_panel2(G.sys, ld, stride, G.S, ntile, j, s0, nact_of(j), tail ? nact_of(j + 1) : 0,
+            rc = sp_launch_panel2(red, G.sys, ld, stride, G.S, ntile, j, s0, nact_of(j), tail ? nact_of(j + 1) : 0,
                                   last, what, h->ncu, G.invL, lts, G.info, G.st, lzp);
           if (rc != SP_OK) return rc;
         }
@@ -395,6 +292,19 @@ static int cholesky_panel2(sp_handle *h, int ngroups, const sp_chol_group *grp, 
 // previous panels of the group, k = 64 q) by the launch that solves it; the big trailing matrix is
 // touched once per super-panel with a rank-64w update instead of w rank-64 updates (at k = 64 that
 // update is HBM-bound: 8 flop per byte of C traffic; k = 64 w divides the traffic by w).
+static int superpanel_of(const sp_handle *h, int K) {
+  const int nsteps = (K + SP_NB - 1) / SP_NB;
+  return h->superpanel > 0 ? h->superpanel : (nsteps >= 16 ? 8 : 4);
+}
+
+// The last pivot block is partial and its row tile holds the rows below the matrix (nsteps == ntile), and it is
+// factored in the tail of launch nsteps - 2 (it is not the first block of a super-panel).
+bool sp_panel_fuses_reduce(const sp_handle *h, int K, int Kp) {
+  static const int on = [] { const char *e = getenv("SP_FUSE_REDUCE"); return e ? atoi(e) : 1; }();
+  const int nsteps = (K + SP_NB - 1) / SP_NB, ntile = Kp / SP_NB;
+  return on && nsteps >= 2 && nsteps == ntile && (nsteps - 1) % superpanel_of(h, K) != 0;
+}
+
 int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *grp, int K,
                               int Kp) {
   if (!h) return SP_ERR_INVALID;
@@ -403,13 +313,13 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
   // at the price of more left-looking work per block column; measured (round 1):
   // K = 1000 (16 panels) w = 2 / 4 / 6 / 8 / 12 / 16 -> 1.17 / 1.10 / 1.085 / 1.08 / 1.12 / 1.14 ms per
   // step; K = 3000 (47 panels): 8 best as well
-  const int w = h->superpanel > 0 ? h->superpanel : (nsteps >= 16 ? 8 : 4);
-  return cholesky_panel2(h, ngroups, grp, K, Kp, w);
+  (void)nsteps;
+  return cholesky_panel2(h, ngroups, grp, K, Kp, superpanel_of(h, K));
 }
 
 int sp_launch_cholesky_systems(sp_handle *h, double *sys, int S, int K, int Kp,
                                int32_t *info, double *invL, hipStream_t st) {
-  sp_chol_group g{sys, info, invL, S, st};
+  sp_chol_group g{sys, info, invL, S, st, LazyCov{}, SpReduceArgs{}};
   return sp_launch_cholesky_groups(h, 1, &g, K, Kp);
 }
 

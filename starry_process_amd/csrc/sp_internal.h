@@ -167,6 +167,18 @@ struct LazyCov {
   int tr0, tc0;            // system tile coordinates of the launch's tile (0, 0)
 };
 
+// What the workgroup that factors a group's LAST pivot block does behind it (sp_panel.hip): the
+// log-likelihood reduction of its star (sp_reduce.h), when the residual / normalisation rows live in
+// that block's row tile and the block is factored in a panel launch's tail (sp_panel_fuses_reduce).
+struct SpReduceArgs {
+  double *lnlike;               // null: no reduction (plain factorisations)
+  uint32_t *status, *status_out;
+  const sp_star *stars;
+  const void *coef;             // RedCoef per star (deferred normalisation) or null
+  int K, M;
+  int live_rows;                // rows of the padded system that carry data (0: all): the rest is identity padding
+};
+
 // one group of stars factored on its own stream
 struct sp_chol_group {
   double *sys;
@@ -175,7 +187,11 @@ struct sp_chol_group {
   int S;
   hipStream_t st;
   LazyCov lazy;
+  SpReduceArgs red;
 };
+
+// does the factorisation of a (K, Kp) system by this handle end in a panel launch's tail (which can carry the reduction)?
+bool sp_panel_fuses_reduce(const sp_handle *h, int K, int Kp);
 
 // host-side constant builders (sp_host.cpp)
 void sp_build_index_tables(int ydeg, int32_t *l_of, int32_t *m_of,
@@ -215,7 +231,7 @@ int sp_launch_gemm_nt(const double *A, long lda, long strideA, const double *B,
 // round-3 panel kernel (sp_panel.hip)
 struct DiagFuse;
 enum { SP_PANEL_D = 1, SP_PANEL_T = 2, SP_PANEL_TAILD = 4, SP_PANEL_LA = 8, SP_PANEL_FIRSTLA = 16 };
-int sp_launch_panel2(double *sys, long ld, long stride, int S, int ntile, int j, int s0, int nact,
+int sp_launch_panel2(const SpReduceArgs *red, double *sys, long ld, long stride, int S, int ntile, int j, int s0, int nact,
                      int next_nact, int last, int what, int ncu, double *img, long lts, int32_t *info,
                      hipStream_t st, const LazyCov *lazy);
 // symmetric trailing update C -= X X^T (lower 64 x 64 tiles, tile (0, 0) skipped) whose tile-(0, 0)

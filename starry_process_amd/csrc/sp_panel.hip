@@ -47,6 +47,7 @@
 #include "sp_cov.h"
 #include "sp_stage.h"
 #include "sp_paneldiag.h"
+#include "sp_reduce.h"
 
 #ifdef SP_PANEL_TRACE
 // (variant build only, tools/ab_build.sh trace -DSP_PANEL_TRACE: wall-clock stamps of star 0's work
@@ -108,6 +109,7 @@ struct PanelArgs {
   long lts;
   int32_t *info;
   LazyCov lz;
+  SpReduceArgs red;    // red.lnlike != null: the tail that factors the last pivot block reduces its star (sp_reduce.h)
 };
 
 typedef double pd4 __attribute__((ext_vector_type(4)));
@@ -371,6 +373,7 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
       __syncthreads();
       double *sD = smem;
       const int nact = a.next_nact;
+      const int nlive = a.red.live_rows > 0 ? a.red.live_rows - 64 * (a.j + 1) : 64;
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -387,11 +390,22 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
 #ifdef SP_PANEL_TRACE
       panel_diag_core(Dt, ld, nact, img_star + (size_t)((a.j + 1) & 1) * SP_LT_IMG,
                       a.info ? a.info + mtx : nullptr, smem, tid,
-                      (mtx == 0 && a.j < 64) ? &g_p2trace[(a.j * 3) * 16 + 8] : nullptr);
+                      (mtx == 0 && a.j < 64) ? &g_p2trace[(a.j * 3) * 16 + 8] : nullptr, nlive);
 #else
       panel_diag_core(Dt, ld, nact, img_star + (size_t)((a.j + 1) & 1) * SP_LT_IMG,
-                      a.info ? a.info + mtx : nullptr, smem, tid);
+                      a.info ? a.info + mtx : nullptr, smem, tid, nullptr, nlive);
 #endif
+      if (a.red.lnlike) {
+        // the last pivot block of the system: everything the reduction reads is final (the earlier
+        // columns by earlier launches, the last ones by this workgroup just now)
+        __threadfence();
+        __syncthreads();
+        lnlike_reduce_body<true>(M, ld, a.red.K, a.red.M, a.info ? a.info + mtx : nullptr, a.red.lnlike + mtx,
+                                 a.red.status ? a.red.status + mtx : nullptr,
+                                 a.red.status_out ? a.red.status_out + mtx : nullptr,
+                                 a.red.stars ? a.red.stars + mtx : nullptr,
+                                 a.red.coef ? static_cast<const RedCoef *>(a.red.coef) + mtx : nullptr, smem, tid);
+      }
       __builtin_amdgcn_s_setprio(0);
       P2_CHAIN(2, wall_clock64());
       P2_STAMP(0, 2);
@@ -444,7 +458,7 @@ __global__ __launch_bounds__(256, P_WGS) void panel_kernel(PanelArgs a) {
 //   what: SP_PANEL_D (D items only: pivot block j), or SP_PANEL_T (T items) with any of
 //   SP_PANEL_TAILD (the first T item factors block j + 1, next_nact active columns), SP_PANEL_LA (a
 //   look-ahead item for tile (j + 2, j + 1)), SP_PANEL_FIRSTLA (launch j - 1 had one).
-int sp_launch_panel2(double *sys, long ld, long stride, int S, int ntile, int j, int s0, int nact,
+int sp_launch_panel2(const SpReduceArgs *red, double *sys, long ld, long stride, int S, int ntile, int j, int s0, int nact,
                      int next_nact, int last, int what, int ncu, double *img, long lts, int32_t *info,
                      hipStream_t st, const LazyCov *lazy) {
   if (S <= 0) return SP_OK;
@@ -456,6 +470,8 @@ int sp_launch_panel2(double *sys, long ld, long stride, int S, int ntile, int j,
            ((what & SP_PANEL_FIRSTLA) ? P_FIRSTLA : 0);
   a.img = img; a.lts = lts; a.info = info;
   a.lz = lazy ? *lazy : LazyCov{};
+  a.red = red ? *red : SpReduceArgs{};
+  if (a.red.lnlike && !(a.mode & P_TAILD)) return SP_ERR_INVALID;
   if ((a.mode & P_DITEMS) && (a.mode & ~P_DITEMS)) return SP_ERR_INVALID;
   if ((a.mode & (P_TAILD | P_LOOKAHEAD | P_FIRSTLA)) && !(a.mode & P_TITEMS)) return SP_ERR_INVALID;
   if ((a.mode & P_LOOKAHEAD) && (j + 2 >= ntile || j <= s0)) return SP_ERR_INVALID;

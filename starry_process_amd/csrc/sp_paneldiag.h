@@ -68,7 +68,7 @@ __device__ __forceinline__ void panel_diag_load(const double *D, long ld, int na
 // sD holds the padded block (a barrier is taken here before it is read)
 __device__ __forceinline__ void panel_diag_core(double *D, long ld, int nact, double *__restrict__ img,
                                                 int32_t *info_star, double *lds, int tid,
-                                                long long *dbg = nullptr) {
+                                                long long *dbg = nullptr, int nlive = 64) {
   double *sD = lds, *sRd = lds + 64 * BLD;
   __syncthreads();
   if (dbg && tid == 0) dbg[0] = wall_clock64();
@@ -111,13 +111,15 @@ __device__ __forceinline__ void panel_diag_core(double *D, long ld, int nact, do
   if (nact < 64) {
     // rows nact .. 63 of the tile against the block just factored: X[r][n] = sum_{k <= n} A[r][k] Linv[n][k]
     // (columns >= nact: identity padding, they stay).  A21 takes the place of the padding rows of sD.
+    // (nlive: rows of the tile that carry data -- the rest is identity padding and solves to itself)
+    const int nrow = (nlive < 64 ? (nlive > nact ? nlive : nact) : 64) - nact;
     __syncthreads();
-    for (int e = tid; e < (64 - nact) * 64; e += 256) {
+    for (int e = tid; e < nrow * 64; e += 256) {
       const int r = nact + (e >> 6), c = e & 63;
       if (c < nact) sD[r * BLD + c] = D[(size_t)r * ld + c];
     }
     __syncthreads();
-    for (int e = tid; e < (64 - nact) * 64; e += 256) {
+    for (int e = tid; e < nrow * 64; e += 256) {
       const int r = nact + (e >> 6), n = e & 63;
       if (n >= nact) continue;
       double acc = sD[r * BLD + n] * sRd[n];
