@@ -32,10 +32,14 @@ __device__ __forceinline__ double block_sum(double v, double *red) {
 // rows of W o Ez: grid (ceil(N/4), ntab), one wavefront per row n
 //   r1[n] = sum_j W[n,j] Ez[n,j],  r2[n] = sum_j W[n,j] Ez[n,mirror(j)],
 //   W[n,j] = Wnp[n,j] * rTA1[m0(l_n)] * rTA1[m0(l_j)]          (flux.py:199-209)
+// and the row's term of the first moment (flux.py:196-198, 297-300), which table_finish_kernel used to take
+// with one thread per n walking its 2 l + 1 entries of wnp one memory round trip after the other (8 of its 14 us):
+//   m1[n] = (sum_r rTA1[l^2 + r] wnp[l][r][n - l^2]) ez[n]
 __global__ __launch_bounds__(256) void table_rows_kernel(
     int N, const int32_t *__restrict__ l_of, const int32_t *__restrict__ mirror,
     const double *__restrict__ Wnp, const double *__restrict__ Ez,
-    const double *__restrict__ rta1_all, double *__restrict__ rows_all) {
+    const double *__restrict__ rta1_all, double *__restrict__ rows_all,
+    const int32_t *__restrict__ blk, const double *__restrict__ wnp, const double *__restrict__ ez) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.x * 4 + wave;
   if (n >= N) return;
@@ -52,10 +56,14 @@ __global__ __launch_bounds__(256) void table_rows_kernel(
   }
   a = wave_sum(a);
   b = wave_sum(b);
+  const int w = 2 * ln + 1;
+  double m1 = lane < w ? rta1[ln * ln + lane] * wnp[blk[ln] + lane * w + (n - ln * ln)] : 0.0;   // (2 ydeg + 1 <= 64)
+  m1 = wave_sum(m1);
   if (lane == 0) {
-    double *rows = rows_all + (size_t)blockIdx.y * 2 * N;
+    double *rows = rows_all + (size_t)blockIdx.y * 3 * N;
     rows[n] = a;
     rows[N + n] = b;
+    rows[2 * N + n] = m1 * ez[n];
   }
 }
 
@@ -77,7 +85,7 @@ __global__ __launch_bounds__(256) void table_finish_kernel(
   const int tid = threadIdx.x;
   const int np = covpts + 4;
   const double *rta1 = rta1_all + (size_t)blockIdx.x * N;
-  const double *rows = rows_all + (size_t)blockIdx.x * 2 * N;
+  const double *rows = rows_all + (size_t)blockIdx.x * 3 * N;
   double *tab = tab_all + (size_t)blockIdx.x * 5 * np;
 
   for (int n = tid; n < N; n += 256) {
@@ -87,15 +95,9 @@ __global__ __launch_bounds__(256) void table_finish_kernel(
   }
   __syncthreads();
 
-  // first moment: w[l] = rTA1[l-block] . wnp[l];  mean = sum_l w[l] . ez[l-block]
+  // first moment: w[l] = rTA1[l-block] . wnp[l];  mean = sum_l w[l] . ez[l-block]  (terms by table_rows_kernel)
   double part = 0.0;
-  for (int n = tid; n < N; n += 256) {
-    const int l = l_of[n], w = 2 * l + 1, c = n - l * l;
-    const double *B = wnp + blk[l] + c;
-    double wn = 0.0;
-    for (int r = 0; r < w; ++r) wn += s_rta1[l * l + r] * B[r * w];
-    part += wn * ez[n];
-  }
+  for (int n = tid; n < N; n += 256) part += rows[2 * N + n];
   const double mean = block_sum(part, s_red);
 
   // variance = <W, Ez> - mean^2 (flux.py:305-308)
@@ -174,7 +176,7 @@ int sp_launch_kernel_table(sp_handle *h, const double *rta1_dev, int ntab,
       sizeof(double) * ((size_t)3 * h->N + covpts + 4 + 2 * (h->ydeg + 1) + 4);
   if (lds > 150 * 1024) return SP_ERR_INVALID;
   // row-reduction scratch [ntab][2][N], grown on demand (rare: new ntab)
-  const size_t need = sizeof(double) * (size_t)ntab * 2 * h->N;
+  const size_t need = sizeof(double) * (size_t)ntab * 3 * h->N;
   if (h->tab_scratch_bytes < need) {
     SP_HIP(hipDeviceSynchronize());
     if (h->d_tab_scratch) SP_HIP(hipFree(h->d_tab_scratch));
@@ -191,7 +193,7 @@ int sp_launch_kernel_table(sp_handle *h, const double *rta1_dev, int ntab,
   }
   hipLaunchKernelGGL(table_rows_kernel, dim3((h->N + 3) / 4, ntab), dim3(256), 0, st,
                      h->N, h->d_l_of, h->d_mirror, h->d_Wnp, h->d_Ez, rta1_dev,
-                     h->d_tab_scratch);
+                     h->d_tab_scratch, h->d_blk, h->d_wnp, h->d_ez);
   SP_LAUNCH_CHECK();
   hipLaunchKernelGGL(table_finish_kernel, dim3(ntab), dim3(256), lds, st, h->ydeg, h->N,
                      h->d_l_of, h->d_blk, h->d_wnp, h->d_ez, rta1_dev, h->d_tab_scratch,

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void dotrx_kernel(
 // the second moment goes through LDS twice (S R_l2, then R_l1^T .), so the
 // intermediate never touches HBM.  The same workgroups copy mu / Sigma into the
 // handle's resident buffers.  Same summation order as three dotrx_kernel passes.
-__global__ __launch_bounds__(256) void polar_moments_kernel(
+__global__ __launch_bounds__(1024) void polar_moments_kernel(
     int N, const int32_t *__restrict__ blk, const double *__restrict__ Rpk,
     const double *__restrict__ mu, const double *__restrict__ cov, double *__restrict__ mu_dst,
     double *__restrict__ cov_dst, double *__restrict__ ez, double *__restrict__ Ez) {
@@ -285,31 +285,31 @@ __global__ __launch_bounds__(256) void polar_moments_kernel(
   const int l1 = blockIdx.y, l2 = blockIdx.x;
   const int n1 = 2 * l1 + 1, n2 = 2 * l2 + 1, b1 = l1 * l1, b2 = l2 * l2;
   const int tid = threadIdx.x;
-  for (int e = tid; e < n1 * n1; e += 256) sR1[e] = Rpk[blk[l1] + e];
-  for (int e = tid; e < n2 * n2; e += 256) sR2[e] = Rpk[blk[l2] + e];
-  for (int e = tid; e < n1 * n2; e += 256) {
+  for (int e = tid; e < n1 * n1; e += 1024) sR1[e] = Rpk[blk[l1] + e];
+  for (int e = tid; e < n2 * n2; e += 1024) sR2[e] = Rpk[blk[l2] + e];
+  for (int e = tid; e < n1 * n2; e += 1024) {
     const int i = e / n2, j = e % n2;
     const double c = cov[(size_t)(b1 + i) * N + b2 + j];
     if (cov_dst != cov) cov_dst[(size_t)(b1 + i) * N + b2 + j] = c;
     sS[i * LD + j] = c + mu[b1 + i] * mu[b2 + j];
   }
   if (l2 == 0 && mu_dst != mu)
-    for (int i = tid; i < n1; i += 256) mu_dst[b1 + i] = mu[b1 + i];
+    for (int i = tid; i < n1; i += 1024) mu_dst[b1 + i] = mu[b1 + i];
   __syncthreads();
-  for (int e = tid; e < n1 * n2; e += 256) {
+  for (int e = tid; e < n1 * n2; e += 1024) {
     const int i = e / n2, j = e % n2;
     double acc = 0.0;
     for (int k = 0; k < n2; ++k) acc += sS[i * LD + k] * sR2[k * n2 + j];
     sT[i * LD + j] = acc;
   }
   if (l2 == 0)
-    for (int i = tid; i < n1; i += 256) {
+    for (int i = tid; i < n1; i += 1024) {
       double acc = 0.0;
       for (int k = 0; k < n1; ++k) acc += mu[b1 + k] * sR1[k * n1 + i];
       ez[b1 + i] = acc;
     }
   __syncthreads();
-  for (int e = tid; e < n1 * n2; e += 256) {
+  for (int e = tid; e < n1 * n2; e += 1024) {
     const int i = e % n1, j = e / n1;   // consecutive threads -> consecutive addresses of a row of Ez
     double acc = 0.0;
     for (int k = 0; k < n1; ++k) acc += sT[k * LD + j] * sR1[k * n1 + i];
@@ -556,7 +556,7 @@ int sp_launch_polar_moments(sp_handle *h, const double *mu_src, const double *co
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(polar_moments_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(polar_moments_kernel, dim3(h->ydeg + 1, h->ydeg + 1), dim3(256), lds, st, h->N,
+  hipLaunchKernelGGL(polar_moments_kernel, dim3(h->ydeg + 1, h->ydeg + 1), dim3(1024), lds, st, h->N,
                      h->d_blk, h->d_Rx90, mu_src, cov_src, h->d_mean_ylm, h->d_cov_ylm, h->d_ez,
                      h->d_Ez);
   SP_LAUNCH_CHECK();
