@@ -409,7 +409,8 @@ int sp_debug_set_look_ahead(sp_handle *h, int on);
  * stamp).  tools/panel2_trace.py                                                             */
 int sp_debug_panel2_trace(long long *out);
 /* (debug, same builds) the block every star's first item factors in its tail, per launch:
- * 16 x 64 x 4 int64 (pivot block j, star, {first item start, block start, block end, CU key}).     */
+ * 16 x 64 x 4 int64 (pivot block j, star, {first item start, block start, block end, CU key}), then
+ * 16 x 1024 int32: the CU key + 1 of every workgroup of the launch (0: none).                     */
 int sp_debug_panel2_chain(long long *out);
 
 #ifdef __cplusplus

@@ -48,6 +48,7 @@
 #include "sp_stage.h"
 #include "sp_paneldiag.h"
 #include "sp_reduce.h"
+#include <atomic>
 
 #ifdef SP_PANEL_TRACE
 // (variant build only, tools/ab_build.sh trace -DSP_PANEL_TRACE: wall-clock stamps of star 0's work
@@ -55,6 +56,19 @@
 __device__ long long g_p2trace[64 * 3 * 16];
 // ... and of EVERY star's tail block per launch: [j < 16][star < 64] x (first item start, block start, block end, CU key)
 __device__ long long g_p2chain[16 * 64 * 4];
+// ... and where the workgroups of a launch run: [j < 16][blockIdx < 1024] -> CU key
+__device__ int g_p2cu[16 * 1024];
+// ... and when they start and end: [j < 16][blockIdx < 1024][2] (wall clock)
+__device__ long long g_p2wg[16 * 1024 * 2];
+struct P2WgStamp {
+  int j, on;
+  __device__ P2WgStamp(int j_, bool on_) : j(j_), on(on_ && j_ < 16 && blockIdx.x < 1024 && threadIdx.x == 0) {
+    if (on) g_p2wg[(j * 1024 + blockIdx.x) * 2] = wall_clock64();
+  }
+  __device__ ~P2WgStamp() {
+    if (on) g_p2wg[(j * 1024 + blockIdx.x) * 2 + 1] = wall_clock64();
+  }
+};
 #define P2_CHAIN(k, v)                                                                          \
   do {                                                                                          \
     if (tid == 0 && a.j < 16 && mtx < 64) g_p2chain[((a.j * 64) + mtx) * 4 + (k)] = (v);        \
@@ -105,6 +119,8 @@ struct PanelArgs {
   int last;            // row tiles i <= last keep their own diagonal tile up to date
   int mode;
   int pair;            // row tiles below the next pivot row tile are dealt in pairs (128-row items)
+  int lay;             // 1: chain-aware layout of the launch (see panel_kernel)
+  int seq;             // launch number (tags the chain workgroups' words in the stars' scratch)
   double *img;         // per star `lts` doubles: two image slots (sp_tile.h)
   long lts;
   int32_t *info;
@@ -114,15 +130,13 @@ struct PanelArgs {
 
 typedef double pd4 __attribute__((ext_vector_type(4)));
 
-#ifdef SP_PANEL_TRACE
-// (trace builds) the CU a workgroup runs on: HW_REG_XCC_ID[2:0] | HW_REG_HW_ID[15:8] (CU, SH, SE) -- 256 distinct
-// values on this part (tools/micro/hwid.hip)
+// the CU a workgroup runs on: HW_REG_XCC_ID[2:0] | HW_REG_HW_ID[15:8] (CU, SH, SE) -- 256 distinct values on
+// this part (tools/micro/hwid.hip)
 __device__ __forceinline__ long long cu_key() {
   const unsigned hw = __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));
   const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;
   return (long long)(xcc * 256 + hw);
 }
-#endif
 
 // items of a star in a launch: [D item] then the row tiles below the pivot block -- the next pivot
 // row tile alone (it is on the critical path: 64 rows), then PAIRS of row tiles (128 rows per
@@ -413,9 +427,93 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
   }
 }
 
+// Chain-aware layout of a launch (PanelArgs.lay).  On an idle GPU the hardware deals the workgroups of a launch
+// to the CUs of an XCD in a fixed order with period 32 (tools/panel2_trace.py <S> <K> <j>: XCD-local dispatch
+// indices k, k + 32 and k + 64 share a CU), and the critical chain of a launch -- the first item and the
+// diagonal block in its tail, 24 us of mostly dependent fp64 vector instructions -- takes 42-46 us when its
+// CU also runs two items' worth of fp64 MFMAs (same pipes; the launches of the first super-panel all ended on
+// it with the other CUs idle).  So the launch is laid out by CU:
+//   k = 0 .. spx - 1 (spx stars per XCD)     the chain items, one CU each;
+//   k = 32 + s, 64 + s                       SLEEPERS: a workgroup that holds the chain CU's other slots and does
+//                                            nothing.  It first checks that it really shares the CU of star s's
+//                                            chain workgroup (both read the hardware's CU identifiers; with other
+//                                            kernels on the GPU the deal is irregular and it leaves at once), then
+//                                            sleeps until that workgroup is done (or 100 us);
+//   the other k                              the launch's other items, one row tile each (and the look-ahead items),
+//                                            on the other 32 - spx CUs; what does not fit there takes sleepers'
+//                                            places, then k >= 96.  (Tried here: 128-row pair items to make
+//                                            everything fit -- a pair gets a third of its CU's MFMA issue like any
+//                                            workgroup and ends at twice the others' time; the look-ahead item as
+//                                            the chain's fixed CU mate -- the blocks of the second super-panel,
+//                                            which have their CU to themselves otherwise, go from 14 to 17-20 us.)
+// Nobody waits for a sleeper and the chain waits for nobody: only time is at stake.
+__device__ __forceinline__ unsigned long long *chain_words(double *img_star) {
+  return reinterpret_cast<unsigned long long *>(img_star + SP_IMG_DOUBLES);   // [0] seq << 32 | CU key, [1] seq when done
+}
+
 __global__ __launch_bounds__(256, P_WGS) void panel_kernel(PanelArgs a) {
   __shared__ __attribute__((aligned(16))) double smem[P_LDS];
   const int tid = threadIdx.x;
+#ifdef SP_PANEL_TRACE
+  if (tid == 0 && a.j < 16 && blockIdx.x < 1024 && (a.mode & P_TITEMS)) g_p2cu[a.j * 1024 + blockIdx.x] = (int)cu_key() + 1;
+  P2WgStamp wg_stamp(a.j, (a.mode & P_TITEMS) != 0);
+#endif
+  if (a.lay) {
+    const int x = blockIdx.x & 7, k = blockIdx.x >> 3, spx = a.S >> 3;
+    const int c = k & 31, rnd = k >> 5, nb = 32 - spx;
+    const int nsingle = a.ntile - a.j - 2;                      // row tiles below the chain's: one item each
+    const int nl = (a.mode & P_LOOKAHEAD) ? 1 : 0;
+    const int reg = 3 * nb;                                     // places on the CUs the chains leave
+    const int extra = spx * (nsingle + nl) - reg;               // items beyond them ...
+    const int nslots = 2 * spx;                                 // ... go to the chain CUs' other slots first
+    int pos;
+    if (k < 96 && c < spx) {
+      const int mtx = x * spx + c;
+      double *img_star = a.img + (size_t)mtx * a.lts;
+      unsigned long long *F = chain_words(img_star);
+      if (rnd == 0) {
+        // the chain: row tile j + 1, then pivot block j + 1
+        if (tid == 0)
+          __hip_atomic_store(F, ((unsigned long long)(unsigned)a.seq << 32) | (unsigned long long)cu_key(),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool fla = a.mode & P_FIRSTLA;
+        panel_tile_item<1>(a, a.sys + (size_t)mtx * a.stride, mtx, a.j + 1, a.j, fla ? a.j - 1 : a.s0, a.j, false,
+                           !fla, img_star, smem, tid);
+        if (tid == 0) __hip_atomic_store(F + 1, (unsigned long long)(unsigned)a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+      const int so = rnd == 2 ? c : spx + c;                    // this slot among the chain CUs' spare ones
+      if (so >= extra) {
+        if (tid == 0) {
+          // sleeper (the other wavefronts leave; this one keeps the slot)
+          const unsigned long long mine = ((unsigned long long)(unsigned)a.seq << 32) | (unsigned long long)cu_key();
+          const long long t0 = wall_clock64();
+          unsigned long long v;
+          while (((v = __hip_atomic_load(F, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != (unsigned)a.seq &&
+                 wall_clock64() - t0 < 250)
+            __builtin_amdgcn_s_sleep(4);
+          if (v == mine)
+            while (__hip_atomic_load(F + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)a.seq &&
+                   wall_clock64() - t0 < 10000)
+              __builtin_amdgcn_s_sleep(32);
+        }
+        return;
+      }
+      pos = reg + so;
+    } else {
+      pos = k < 96 ? rnd * nb + (c - spx) : reg + nslots + (k - 96);
+    }
+    const int sl = pos % spx, idx = pos / spx;                   // star of the XCD, item of the star
+    if (idx >= nsingle + nl) return;
+    const int mtx = x * spx + sl;
+    double *M = a.sys + (size_t)mtx * a.stride;
+    double *img_star = a.img + (size_t)mtx * a.lts;
+    if (idx < nsingle)
+      panel_tile_item<1>(a, M, mtx, a.j + 2 + idx, a.j, a.s0, a.j, false, true, img_star, smem, tid);
+    else
+      panel_tile_item<1>(a, M, mtx, a.j + 2, a.j + 1, a.s0, a.j, true, true, img_star, smem, tid);
+    return;
+  }
   const int nd = (a.mode & P_DITEMS) ? 1 : 0;                                      // D items per star
   const int nt = (a.mode & P_TITEMS) ? panel_titems(a.ntile, a.j, a.pair) : 0;   // T items per star
   const int nl = (a.mode & P_LOOKAHEAD) ? 1 : 0;                                   // look-ahead items per star
@@ -490,7 +588,23 @@ int sp_launch_panel2(const SpReduceArgs *red, double *sys, long ld, long stride,
   const int per_star = ((a.mode & P_DITEMS) ? 1 : 0) + ((a.mode & P_TITEMS) ? panel_titems(ntile, j, a.pair) : 0) +
                        ((a.mode & P_LOOKAHEAD) ? 1 : 0);
   if (per_star <= 0) return SP_OK;
-  const long nblk = sp_xcd_grid(S, per_star);
+  long nblk = sp_xcd_grid(S, per_star);
+  // chain-aware layout (panel_kernel): launches with a diagonal block in their tail, whole stars per XCD
+  a.lay = 0; a.seq = 0;
+  {
+    static const int lay_on = [] { const char *e = getenv("SP_PANEL_LAYOUT"); return e ? atoi(e) : 1; }();
+    static std::atomic<int> seq{0};
+    const int spx = S / 8;
+    if (lay_on && P_PAIRS && (a.mode & P_TAILD) && S % 8 == 0 && spx >= 1 && spx <= 16 && ntile - j - 2 >= 0) {
+      const int nrows = ntile - j - 2, la = (a.mode & P_LOOKAHEAD) ? 1 : 0;
+      a.lay = 1;
+      int sq = ++seq;
+      if (sq == 0) sq = ++seq;
+      a.seq = sq;
+      const long extra = (long)spx * (nrows + la) - 3L * (32 - spx), nslots = 2 * spx;
+      nblk = 8 * (96 + (extra > nslots ? extra - nslots : 0));
+    }
+  }
   if (nblk > 0x7fffffffL) return SP_ERR_INVALID;
   hipLaunchKernelGGL(panel_kernel, dim3((unsigned)nblk), dim3(256), 0, st, a);
   SP_LAUNCH_CHECK();
@@ -514,10 +628,14 @@ extern "C" int sp_debug_panel2_trace(long long *out) {
 #endif
 }
 
-// (debug, variant builds) every star's tail block per launch: 16 x 64 x 4 int64
+// (debug, variant builds) every star's tail block per launch: 16 x 64 x 4 int64, then the CU of every workgroup:
+// 16 x 1024 int32 (0: none) packed behind it
 extern "C" int sp_debug_panel2_chain(long long *out) {
 #ifdef SP_PANEL_TRACE
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p2chain), sizeof(long long) * 16 * 64 * 4) != hipSuccess) return SP_ERR_HIP;
+  if (hipMemcpyFromSymbol(out + 16 * 64 * 4, HIP_SYMBOL(g_p2cu), sizeof(int) * 16 * 1024) != hipSuccess) return SP_ERR_HIP;
+  if (hipMemcpyFromSymbol(out + 16 * 64 * 4 + 16 * 512, HIP_SYMBOL(g_p2wg), sizeof(long long) * 16 * 1024 * 2) != hipSuccess)
+    return SP_ERR_HIP;
   return SP_OK;
 #else
   (void)out;

@@ -45,9 +45,20 @@ for j in range(64):
     print(line)
 
 # every star's tail block: how the 64 chains of a launch sit on the CUs
-cb = np.zeros(16 * 64 * 4, dtype=np.int64)
+cb = np.zeros(16 * 64 * 4 + 16 * 512 + 16 * 1024 * 2, dtype=np.int64)
 check(e._L.sp_debug_panel2_chain(cb.ctypes.data_as(ctypes.c_void_p)))
-cb = cb.reshape(16, 64, 4)
+cu = cb[16 * 64 * 4:16 * 64 * 4 + 16 * 512].view(np.int32).reshape(16, 1024)
+wg = cb[16 * 64 * 4 + 16 * 512:].reshape(16, 1024, 2)
+cb = cb[:16 * 64 * 4].reshape(16, 64, 4)
+if len(sys.argv) > 3:
+    # where the workgroups of launch j ran: XCD-local dispatch index -> CU (key within the XCD), per XCD
+    j = int(sys.argv[3])
+    for x in range(2):
+        ks = cu[j][x::8]
+        ks = ks[ks > 0] - 1
+        cus = {k: i for i, k in enumerate(sorted(set(ks)))}
+        print("launch %d, XCD slot %d: %d workgroups on %d CUs; CU index by dispatch order:" % (j, x, len(ks), len(cus)))
+        print(" ".join("%2d" % cus[k] for k in ks))
 print("per launch: first items start (min..max) | blocks start | blocks end | block duration min / median / max | CUs used, most chains on one CU")
 for j in range(16):
     c = cb[j][cb[j][:, 2] > 0]
@@ -58,3 +69,22 @@ for j in range(16):
     keys, cnt = np.unique(c[:, 3], return_counts=True)
     print("j %2d | first %7.1f..%7.1f | block start %7.1f..%7.1f | end %7.1f..%7.1f | %5.1f / %5.1f / %5.1f | %d CUs, max %d" % (
         j, f0.min(), f0.max(), b0.min(), b0.max(), b1.min(), b1.max(), dur.min(), np.median(dur), dur.max(), len(keys), cnt.max()))
+
+print("workgroups of a launch (first 1024): end - launch start, by XCD-local dispatch index k (XCD slot 0): per CU = k mod 32")
+for j in range(16):
+    w = wg[j]
+    ok = (w[:, 1] > 0) & (w[:, 0] > 0)
+    if not ok.any():
+        continue
+    t00 = w[ok, 0].min()
+    dur = np.where(ok, (w[:, 1] - t00) / 100.0, np.nan)
+    loc = dur[0::8]
+    loc = loc[:96] if len(loc) >= 96 else loc
+    n = len(loc)
+    print("j %2d: %4d workgroups, ends: median %5.1f, 90%% %5.1f, max %5.1f us | XCD 0 by round: %s" % (
+        j, ok.sum(), np.nanmedian(dur), np.nanpercentile(dur[ok], 90), np.nanmax(dur),
+        " / ".join("%.0f-%.0f" % (np.nanmin(loc[r * 32:(r + 1) * 32]), np.nanmax(loc[r * 32:(r + 1) * 32]))
+                   for r in range((n + 31) // 32) if np.isfinite(loc[r * 32:(r + 1) * 32]).any())))
+    if len(sys.argv) > 3 and int(sys.argv[3]) == j:
+        for r in range((n + 31) // 32):
+            print("   round %d: " % r + " ".join("%3.0f" % v for v in loc[r * 32:(r + 1) * 32]))
