@@ -412,9 +412,10 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
       if (a.red.lnlike) {
         // the last pivot block of the system: everything the reduction reads is final (the earlier
         // columns by earlier launches, the last ones by this workgroup just now)
-        __threadfence();
+        // (same workgroup, same CU: the barrier's workgroup-scope ordering is all the visibility it takes -- an
+        //  agent-scope release here would write the XCD's whole L2 back, 2-9 us)
         __syncthreads();
-        lnlike_reduce_body<true>(M, ld, a.red.K, a.red.M, a.info ? a.info + mtx : nullptr, a.red.lnlike + mtx,
+        lnlike_reduce_body<false>(M, ld, a.red.K, a.red.M, a.info ? a.info + mtx : nullptr, a.red.lnlike + mtx,
                                  a.red.status ? a.red.status + mtx : nullptr,
                                  a.red.status_out ? a.red.status_out + mtx : nullptr,
                                  a.red.stars ? a.red.stars + mtx : nullptr,
