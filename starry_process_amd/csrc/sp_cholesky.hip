@@ -248,6 +248,10 @@ static int cholesky_panel2(sp_handle *h, int ngroups, const sp_chol_group *grp, 
           const bool la = la_on && q >= 1 && j + 2 < ntile && j + 1 < nsteps && q + 1 < w && rows > 0;
           const bool first_la = la_on && q >= 2 && rows > 0;   // (launch j - 1 qualified: q - 1 >= 1, j + 1 < ntile)
           const int nl = d_alone && rows > 0 ? 2 : 1;
+          if (!d_alone && rows <= 0) {   // the last pivot block with no row tile below it: factored in launch j - 1's tail
+            sp_scope.add(fl, 0);
+            continue;
+          }
           SpProfScope prof(h, G.st, SP_PROF_CHAIN, fl, nl);
           SpProfScope prof1(h, G.st, SP_PROF_PANEL_LAUNCH, fl, nl);
           sp_scope.add(fl, nl);

@@ -36,9 +36,9 @@ for name in ("one_step_trace.txt", "prof_elp.txt", "inflight_probe.txt"):
     copy(os.path.join(O, name), "r03_" + name)
 
 
-def steps_of(d):   # launches per step in the PMC runs: count the lnlike_reduce dispatches (one per step)
+def steps_of(d):   # launches per step in the PMC runs: count the defer_finish dispatches (one per step)
     f = last(d + "/**/*kernel_trace.csv")
-    return sum(1 for r in csv.DictReader(open(f)) if "lnlike_reduce_kernel" in r["Kernel_Name"]) if f else 0
+    return sum(1 for r in csv.DictReader(open(f)) if "defer_finish_kernel" in r["Kernel_Name"]) if f else 0
 
 
 fd, wd = os.path.join(O, "pmc_FETCH_SIZE"), os.path.join(O, "pmc_WRITE_SIZE")
