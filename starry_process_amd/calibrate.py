@@ -135,13 +135,18 @@ class EnsembleLogProb(object):
     one batched likelihood call for this rank's stars; nothing is copied back or synchronised
     until every sample is enqueued, and sample k runs on stream k mod ``depth`` with its own
     library handle and workspace (engine.engine_slots), so that the latency-bound phases of
-    one sample overlap the throughput-bound phases of its neighbours.  Under an initialised
+    one sample overlap the throughput-bound phases of its neighbours.  The moments of ALL samples
+    are produced on one more stream with a handle of its own, ahead of the likelihood streams
+    (an event per sample): the quadrature is a chain of a dozen small kernels, 0.3-0.4 ms of
+    latency per sample that a likelihood stream would otherwise sit through with its share of
+    the GPU idle: 0.726 -> 0.69 ms per sample with three likelihood streams + this one (a fifth stream in
+    flight loses more than it hides: 0.83 -- the same cliff bench.py sees at five steps in flight).  Under an initialised
     ``torch.distributed`` job the stars are sharded over the ranks and the per-sample sums are
     combined with ONE all-reduce for the whole batch."""
 
     def __init__(self, t, flux, ferr=1.0e-3, p=1.0, i=None, u=None, ydeg=15, baseline_log_var=0.0,
                  baseline_mean=0.0, apply_jac=True, normalized=True,
-                 marginalize_over_inclination=True, covpts=None, device=None, depth=4):
+                 marginalize_over_inclination=True, covpts=None, device=None, depth=3):
         import torch
         import torch.distributed as dist
 
@@ -176,7 +181,8 @@ class EnsembleLogProb(object):
                            baseline_var=np.full(hi - lo, 10.0 ** baseline_log_var),
                            baseline_mean=per(baseline_mean, 0.0),
                            data_var=per(np.asarray(ferr, dtype=np.float64) ** 2, 1.0), table=table)
-        self._slots = engine_slots(ydeg, udeg, device, depth)
+        slots = engine_slots(ydeg, udeg, device, max(2, int(depth) + 1))
+        self._slots, self._up = slots[:-1], slots[-1]          # likelihood slots; the upstream's own engine + stream
         e0 = self._slots[0][0]
         self._t = e0.f64(np.ascontiguousarray(t[lo:hi]))
         self._flux = e0.f64(np.ascontiguousarray(flux[lo:hi, None, :]))
@@ -204,10 +210,17 @@ class EnsembleLogProb(object):
         outs = e0.empty(ns, max(nl, 1))
         torch.cuda.synchronize(e0.device)
         if nl:
+            eu, su = self._up
+            keep = []                                   # (the moments stay alive until the batch is done)
             for k, (r, a, b, c, n) in enumerate(samples):
+                with torch.cuda.stream(su):
+                    mean, cov = ylm_moments_device(eu, r=r, a=a, b=b, c=c, n=n)
+                    ready = torch.cuda.Event()
+                    ready.record(su)
+                keep.append((mean, cov, ready))
                 e, stream = self._slots[k % len(self._slots)]
                 with torch.cuda.stream(stream):
-                    mean, cov = ylm_moments_device(e, r=r, a=a, b=b, c=c, n=n)
+                    stream.wait_event(ready)
                     e.set_moments_dev(mean, cov)
                     tab = mv = None
                     if self._marg:

@@ -251,8 +251,11 @@ __global__ __launch_bounds__(256) void assemble_kernel(
   const int nobs = star_nobs(st, K);
   const double var1 = (!FROM_MATRIX && nobs == 1) ? meanvar[2 * st.table + 1] : 0.0;
   double *ob = out + (size_t)s * strideo;
-  // thread -> 4 consecutive columns, 16 rows per pass
-  const int cj = (threadIdx.x & 15) * 4, ri = threadIdx.x >> 4;
+  // thread -> columns cl, cl + 16, cl + 32, cl + 48 of a row, 16 rows per pass: the 16 lanes of a row look up
+  // ADJACENT columns -- neighbouring phases, neighbouring table segments, which the two arrays of 16-byte entries
+  // put on distinct bank groups (four consecutive columns per thread spread a row's lanes over ~80 segments: 37 %
+  // of the LDS cycles of this kernel were bank conflicts)
+  const int cl = threadIdx.x & 15, ri = threadIdx.x >> 4;
   const int lim = SYSTEM ? Kp : K;
   double csum[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(
     double rsum = 0.0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int lj = cj + e, j = j0 + lj;
+      const int lj = cl + 16 * e, j = j0 + lj;
       double val = 0.0;
       if (i < nobs && j < nobs) {
         double rawv;
@@ -309,20 +312,15 @@ __global__ __launch_bounds__(256) void assemble_kernel(
     // (tiles the factorisation forms itself at first touch: sums taken above, nothing written)
     // (not the first block column: its panel launch has no product to form the tile behind)
     if (DEFER && ti > tj && tj > 0 && ti < lazy_nfull) continue;
-    double *dst = ob + (size_t)i * ldo + j0 + cj;
-    if (j0 + cj + 3 < lim && (((size_t)dst) & 15) == 0) {
-      *reinterpret_cast<dd2 *>(dst) = dd2{v[0], v[1]};
-      *reinterpret_cast<dd2 *>(dst + 2) = dd2{v[2], v[3]};
-    } else {
+    double *dst = ob + (size_t)i * ldo + j0 + cl;
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (j0 + cj + e < lim) dst[e] = v[e];
-    }
+    for (int e = 0; e < 4; ++e)
+      if (j0 + cl + 16 * e < lim) dst[16 * e] = v[e];
   }
   if (DEFER && ti > tj) {
     // column sums = row sums of the mirror tile (tj, ti), which is never formed
 #pragma unroll
-    for (int e = 0; e < 4; ++e) s_col[ri * 64 + cj + e] = csum[e];
+    for (int e = 0; e < 4; ++e) s_col[ri * 64 + cl + 16 * e] = csum[e];
     __syncthreads();
     if (threadIdx.x < 64) {
       double a = 0.0;

@@ -8,7 +8,7 @@ S, K = 64, 1000
 sts = [synthetic_star(s, K) for s in range(S)]
 t = np.array([s["t"] for s in sts]); flux = np.array([s["flux"] for s in sts]); p = np.array([s["p"] for s in sts])
 samples = np.array([[20.0 + 0.01 * i, 0.4, 0.27, 0.1, 10.0] for i in range(120)])
-depth = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+depth = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 lp = EnsembleLogProb(t, flux, ferr=1e-3, p=p, depth=depth)
 lp(samples[:6]); torch.cuda.synchronize()
 t0 = time.perf_counter(); vals = lp(samples); dt = (time.perf_counter() - t0) / len(samples)
