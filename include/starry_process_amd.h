@@ -403,6 +403,10 @@ int sp_allgather_lnlike(sp_handle *h, void *nccl_comm, const double *local_dev, 
 /* (debug) the look-ahead items of the panel launches (csrc/sp_cholesky.hip) on (default; environment
  * SP_PANEL_LA) or off: the factor is the same to rounding, the critical path of a panel is not.  */
 int sp_debug_set_look_ahead(sp_handle *h, int on);
+/* (debug) the panel launches' layout by CU (chain items first, sleepers on their CUs' other slots; default on,
+ * environment SP_PANEL_LAYOUT) and the reduction in the tail of the last panel launch (default on where the
+ * system's shape allows, SP_FUSE_REDUCE): where work runs and who reduces, never what is computed.     */
+int sp_debug_set_panel_layout(sp_handle *h, int layout, int fuse_reduce);
 /* (debug) wall-clock stamps of the panel kernel (csrc/sp_panel.hip); only in a library built with
  * -DSP_PANEL_TRACE (tools/ab_build.sh), SP_ERR_INVALID otherwise.  out == NULL resets; else
  * 64 x 3 x 16 int64 (pivot block, work item of star 0 {diagonal block, first tile, last tile},

@@ -472,6 +472,8 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
   h->lazy_cov = 1;
   h->ncu = 256;
   h->look_ahead = 1;
+  h->panel_layout = 1;
+  h->fuse_reduce = 1;
   h->d_Rxm90 = nullptr;
   h->d_lamcs = nullptr;
   h->lamcs_Q = 0;
@@ -523,6 +525,10 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
     }
     const char *e12 = getenv("SP_PANEL_LA");
     h->look_ahead = e12 ? atoi(e12) : 1;
+    const char *e13 = getenv("SP_PANEL_LAYOUT");
+    h->panel_layout = e13 ? atoi(e13) : 1;
+    const char *e14 = getenv("SP_FUSE_REDUCE");
+    h->fuse_reduce = e14 ? atoi(e14) : 1;
     const char *e2 = getenv("SP_SUPER");
     h->superpanel = e2 ? atoi(e2) : 0;   // 0: chosen from K (sp_launch_cholesky_groups)
     if (h->superpanel < 0) h->superpanel = 0;
@@ -734,6 +740,14 @@ int sp_set_defer_norm(sp_handle *h, int on) {
 int sp_debug_set_look_ahead(sp_handle *h, int on) {
   if (!h) return SP_ERR_INVALID;
   h->look_ahead = on ? 1 : 0;
+  return SP_OK;
+}
+
+// (debug) the panel launches' layout by CU and the reduction in the last launch's tail, on / off: same bits
+int sp_debug_set_panel_layout(sp_handle *h, int layout, int fuse_reduce) {
+  if (!h) return SP_ERR_INVALID;
+  h->panel_layout = layout ? 1 : 0;
+  h->fuse_reduce = fuse_reduce ? 1 : 0;
   return SP_OK;
 }
 

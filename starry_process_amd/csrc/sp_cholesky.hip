@@ -257,7 +257,7 @@ static int cholesky_panel2(sp_handle *h, int ngroups, const sp_chol_group *grp, 
           sp_scope.add(fl, nl);
           int rc = SP_OK;
           if (d_alone)
-            rc = sp_launch_panel2(nullptr, G.sys, ld, stride, G.S, ntile, j, s0, nact_of(j), 0, last, SP_PANEL_D,
+            rc = sp_launch_panel2(h->panel_layout, nullptr, G.sys, ld, stride, G.S, ntile, j, s0, nact_of(j), 0, last, SP_PANEL_D,
                                   h->ncu, G.invL, lts, G.info, G.st, nullptr);
           const int what = rows > 0 ? (SP_PANEL_T | (tail ? SP_PANEL_TAILD : 0) | (la ? SP_PANEL_LA : 0) |
                                        (first_la ? SP_PANEL_FIRSTLA : 0))
@@ -265,7 +265,7 @@ static int cholesky_panel2(sp_handle *h, int ngroups, const sp_chol_group *grp, 
           // (the launch whose tail factors the LAST pivot block carries the reduction, if there is one)
           const SpReduceArgs *red = (tail && j + 1 == nsteps - 1 && fuse_reduce) ? &G.red : nullptr;
           if (rc == SP_OK && what)
-            rc = sp_launch_panel2(red, G.sys, ld, stride, G.S, ntile, j, s0, nact_of(j), tail ? nact_of(j + 1) : 0,
+            rc = sp_launch_panel2(h->panel_layout, red, G.sys, ld, stride, G.S, ntile, j, s0, nact_of(j), tail ? nact_of(j + 1) : 0,
                                   last, what, h->ncu, G.invL, lts, G.info, G.st, lzp);
           if (rc != SP_OK) return rc;
         }
@@ -304,9 +304,8 @@ static int superpanel_of(const sp_handle *h, int K) {
 // The last pivot block is partial and its row tile holds the rows below the matrix (nsteps == ntile), and it is
 // factored in the tail of launch nsteps - 2 (it is not the first block of a super-panel).
 bool sp_panel_fuses_reduce(const sp_handle *h, int K, int Kp) {
-  static const int on = [] { const char *e = getenv("SP_FUSE_REDUCE"); return e ? atoi(e) : 1; }();
   const int nsteps = (K + SP_NB - 1) / SP_NB, ntile = Kp / SP_NB;
-  return on && nsteps >= 2 && nsteps == ntile && (nsteps - 1) % superpanel_of(h, K) != 0;
+  return h->fuse_reduce && nsteps >= 2 && nsteps == ntile && (nsteps - 1) % superpanel_of(h, K) != 0;
 }
 
 int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *grp, int K,

@@ -65,6 +65,8 @@ struct sp_handle {
   int groups;                   // concurrent star groups (SP_GROUPS, default 1)
   int ncu;                      // compute units of the device
   int look_ahead;               // panel launches carry a look-ahead item (sp_cholesky.hip; SP_PANEL_LA, default 1)
+  int panel_layout;             // panel launches laid out by CU (sp_panel.hip; SP_PANEL_LAYOUT, default 1)
+  int fuse_reduce;              // the reduction rides in the last panel launch's tail where it can (SP_FUSE_REDUCE, default 1)
   std::vector<hipStream_t> gstream;
   std::vector<hipEvent_t> gdone;
   hipEvent_t gfork;
@@ -231,7 +233,7 @@ int sp_launch_gemm_nt(const double *A, long lda, long strideA, const double *B,
 // round-3 panel kernel (sp_panel.hip)
 struct DiagFuse;
 enum { SP_PANEL_D = 1, SP_PANEL_T = 2, SP_PANEL_TAILD = 4, SP_PANEL_LA = 8, SP_PANEL_FIRSTLA = 16 };
-int sp_launch_panel2(const SpReduceArgs *red, double *sys, long ld, long stride, int S, int ntile, int j, int s0, int nact,
+int sp_launch_panel2(int layout, const SpReduceArgs *red, double *sys, long ld, long stride, int S, int ntile, int j, int s0, int nact,
                      int next_nact, int last, int what, int ncu, double *img, long lts, int32_t *info,
                      hipStream_t st, const LazyCov *lazy);
 // symmetric trailing update C -= X X^T (lower 64 x 64 tiles, tile (0, 0) skipped) whose tile-(0, 0)

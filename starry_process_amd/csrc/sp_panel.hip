@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256, P_WGS) void panel_kernel(PanelArgs a) {
 //   what: SP_PANEL_D (D items only: pivot block j), or SP_PANEL_T (T items) with any of
 //   SP_PANEL_TAILD (the first T item factors block j + 1, next_nact active columns), SP_PANEL_LA (a
 //   look-ahead item for tile (j + 2, j + 1)), SP_PANEL_FIRSTLA (launch j - 1 had one).
-int sp_launch_panel2(const SpReduceArgs *red, double *sys, long ld, long stride, int S, int ntile, int j, int s0, int nact,
+int sp_launch_panel2(int layout, const SpReduceArgs *red, double *sys, long ld, long stride, int S, int ntile, int j, int s0, int nact,
                      int next_nact, int last, int what, int ncu, double *img, long lts, int32_t *info,
                      hipStream_t st, const LazyCov *lazy) {
   if (S <= 0) return SP_OK;
@@ -593,7 +593,7 @@ int sp_launch_panel2(const SpReduceArgs *red, double *sys, long ld, long stride,
   // chain-aware layout (panel_kernel): launches with a diagonal block in their tail, whole stars per XCD
   a.lay = 0; a.seq = 0;
   {
-    static const int lay_on = [] { const char *e = getenv("SP_PANEL_LAYOUT"); return e ? atoi(e) : 1; }();
+    const int lay_on = layout;
     static std::atomic<int> seq{0};
     const int spx = S / 8;
     if (lay_on && P_PAIRS && (a.mode & P_TAILD) && S % 8 == 0 && spx >= 1 && spx <= 16 && ntile - j - 2 >= 0) {

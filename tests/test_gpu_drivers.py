@@ -128,9 +128,10 @@ def test_awkward_sizes_against_the_oracle(engines, K, M):
 
 @pytest.mark.parametrize("S", [1, 3, 8, 13, 64, 100])
 def test_batch_sizes_and_pair_items(engines, S):
-    """Items are dealt to the XCDs in contiguous runs (whole stars when 8 divides the batch); launches
-    whose 64-row items would not fit the CUs in one round use 128-row pair items (S = 64, 100 at
-    K = 700: the first panels).  A star's value does not depend on any of that."""
+    """Items are dealt to the XCDs in contiguous runs (whole stars when 8 divides the batch: those launches are
+    laid out by CU, chain items first); batches that 8 does not divide use the star-major deal, with 128-row
+    pair items where 64-row ones would not fit the CUs in one round (S = 100 at K = 700: the first panels).
+    A star's value does not depend on any of that."""
     e = engines(15)
     a, st = lnl(e, 700, range(S))
     b, _ = lnl(e, 700, range(S))
@@ -154,6 +155,22 @@ def test_look_ahead_and_super_panel_width_do_not_change_the_answer(monkeypatch):
     ref = res[("1", "0")]
     for k, v in res.items():
         assert np.max(np.abs(v / ref - 1)) < 1e-10, k
+
+
+@pytest.mark.parametrize("K,M,S", [(1000, 1, 64), (1000, 3, 16), (700, 1, 8), (1345, 1, 24), (960, 70, 8), (200, 1, 40)])
+def test_layout_by_cu_and_fused_reduction_do_not_change_a_bit(K, M, S):
+    """The panel launches laid out by CU (chain items first, sleepers, the other items on the other CUs) against
+    the star-major deal with pair items, and the reduction in the last launch's tail against the kernel of its
+    own: where work runs and who reduces, never what is computed."""
+    res = []
+    for layout, fuse in ((1, 1), (0, 1), (1, 0), (0, 0)):
+        e = make_engine(15)
+        e._L.sp_debug_set_panel_layout(e._h, layout, fuse)
+        v, st = lnl(e, K, range(5, 5 + S), M=M)
+        assert not st.any() and np.all(np.isfinite(v))
+        res.append(v)
+    for v in res[1:]:
+        assert np.array_equal(res[0], v)
 
 
 @pytest.mark.parametrize("K,M,kw", [
