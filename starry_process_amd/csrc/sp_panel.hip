@@ -291,10 +291,14 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
 #endif
   if (P_DAC_PREFETCH && NR == 1 && i0 <= a.last) {
     const double *Dt0 = M + (size_t)(64 * i0) * ld + 64 * i0;
+    // (only the blocks on and below the diagonal: wavefront w owns rows 16 w .., column blocks m <= w -- nobody
+    //  reads a diagonal tile's upper blocks, neither the factorisation nor the trailing update's lower tiles)
 #pragma unroll
     for (int m = 0; m < 4; ++m)
+      if (m <= wave) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dacp[m][r] = Dt0[(size_t)(16 * wave + fk + 4 * r) * ld + 16 * m + fr];
+        for (int r = 0; r < 4; ++r) dacp[m][r] = Dt0[(size_t)(16 * wave + fk + 4 * r) * ld + 16 * m + fr];
+      }
   }
   // Y = X^T = L_d^-1 G, block rows nb = 3 .. 0: y[nb] = sum_{kb <= nb} Linv(nb, kb) G(kb);
   // y[h][nb][r] = X[64 h + 16 wave + fr][16 nb + 4 fk + r]
@@ -353,7 +357,7 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
     for (int m = 0; m < 4; ++m) {
       if (P_DAC_PREFETCH && NR == 1 && h == 0) {
         dac[m] = dacp[m];
-      } else {
+      } else if (m <= wave) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) dac[m][r] = Dt[(size_t)(16 * wave + fk + 4 * r) * ld + 16 * m + fr];
       }
@@ -363,6 +367,7 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
     for (int nb = 0; nb < 4; ++nb) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
+        if (m > wave) continue;      // (10 of the tile's 16 blocks)
         const double *f = sX + (16 * m + fr) * XLD + 16 * nb + 4 * fk;
         const d2v lo = *reinterpret_cast<const d2v *>(f);
         const d2v hi = *reinterpret_cast<const d2v *>(f + 2);
@@ -377,8 +382,10 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
     if (!(chain && a.next_nact == 64)) {
 #pragma unroll
       for (int m = 0; m < 4; ++m)
+        if (m <= wave) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Dt[(size_t)(16 * wave + fk + 4 * r) * ld + 16 * m + fr] = dac[m][r];
+          for (int r = 0; r < 4; ++r) Dt[(size_t)(16 * wave + fk + 4 * r) * ld + 16 * m + fr] = dac[m][r];
+        }
     }
     P2_STAMP(role, 6);
     if (NR == 1 && (a.mode & P_TAILD) && i == a.j + 1 && a.next_nact > 0) {
@@ -393,7 +400,7 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int li = 16 * wave + fk + 4 * r, lj = 16 * m + fr;
-          double v = (li < nact && lj < nact) ? dac[m][r] : (li == lj ? 1.0 : 0.0);
+          double v = (li < nact && lj < nact && m <= wave) ? dac[m][r] : (li == lj ? 1.0 : 0.0);
           if (lj > li) v = 0.0;
           sD[li * BLD + lj] = v;
         }
