@@ -586,6 +586,23 @@ def main():
         torch.cuda.synchronize()
         pcie_rate = S * nrep / (time.perf_counter() - t1)
 
+    # the same steps in flight over a longer run (not `value`): a timed region of K = 20 steps holds five
+    # rounds of F = 4, of which the first starts with the streams in lockstep and the last drains with
+    # nothing left to overlap; a sampler's thousands of evaluations see the sustained rate
+    sustained = None
+    if world == 1 and not args.no_extras:
+        nlong = 240
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(nlong):
+            slots[i % F].run()
+        torch.cuda.synchronize()
+        dtl = time.perf_counter() - t1
+        sustained = {"steps": nlong, "steps_in_flight": F, "evals_per_s": S * nlong / dtl,
+                     "ms_per_step": 1e3 * dtl / nlong}
+        fls, _ = step_work(S, K)
+        sustained["whole_step_frac"] = fls / (sustained["ms_per_step"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
+
     # the other shapes of BASELINE.json, after the headline and never in `value`
     extras = None
     if world == 1 and not args.no_extras:
@@ -708,6 +725,7 @@ def main():
             "prewarm": {"steps": prewarm_steps, "min_ms": args.prewarm_ms, "timed": False},
             "steps_in_flight": F,
             "one_step_at_a_time": one,
+            "sustained": sustained,
             "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
             "pcie_inclusive_evals_per_s": pcie_rate,
             "upstream_ms_per_sample": upstream_ms,

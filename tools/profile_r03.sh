@@ -22,7 +22,7 @@ done
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $O/pmc_sq -- python3 bench.py --no-cpu --no-extras --in-flight 1 --steps 4 --warmup 1 --prewarm-ms 0 > $O/pmc_sq.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc GRBM_GUI_ACTIVE -d $O/pmc_grbm -- python3 bench.py --no-cpu --no-extras --in-flight 1 --steps 4 --warmup 1 --prewarm-ms 0 > $O/pmc_grbm.log 2>&1
 # the sampler level and the concurrency probe
-timeout -k 10 300 python3 tools/prof_elp.py 4 > $O/prof_elp.txt 2>&1
+timeout -k 10 300 python3 tools/prof_elp.py > $O/prof_elp.txt 2>&1
 timeout -k 10 300 python3 tools/inflight_probe.py 1 2 3 4 > $O/inflight_probe.txt 2>&1
 python3 tools/collect_r03.py $O
 ls $O
