@@ -126,11 +126,12 @@ def test_awkward_sizes_against_the_oracle(engines, K, M):
     assert np.max(np.abs(v[:nref] - ref) / scale) < TOL
 
 
-@pytest.mark.parametrize("S", [1, 3, 8, 13, 64, 100])
+@pytest.mark.parametrize("S", [1, 3, 8, 13, 16, 64, 100, 128, 136])
 def test_batch_sizes_and_pair_items(engines, S):
     """Items are dealt to the XCDs in contiguous runs (whole stars when 8 divides the batch: those launches are
     laid out by CU, chain items first); batches that 8 does not divide use the star-major deal, with 128-row
     pair items where 64-row ones would not fit the CUs in one round (S = 100 at K = 700: the first panels).
+    S = 8 / 16 / 64 / 128: one, two, eight and sixteen stars per XCD in the layout by CU; 136: seventeen, beyond it.
     A star's value does not depend on any of that."""
     e = engines(15)
     a, st = lnl(e, 700, range(S))
