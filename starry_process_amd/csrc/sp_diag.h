@@ -67,11 +67,28 @@ __device__ __forceinline__ double row_bcast(double v) {
   return __builtin_amdgcn_update_dpp(v, v, 0x150 + J, 0xf, 0xf, true);
 }
 
+// a += bcast_J(b) * (-c): the row broadcast folded into the multiply-add (v_fmac_f64 is a VOP2 on gfx90a+ and
+// takes a DPP64 row_newbcast on its first source): ONE instruction per updated entry where a v_mov_b64_dpp and
+// a v_fma_f64 were two -- the leaf is bound by the instructions it issues, not by its pivot chain.  Same value
+// bit for bit (a product's sign is exact).  The caller keeps two wait states between the VALU write of b and
+// this read of it through DPP (s_nop 1: inline assembly is opaque to the hazard recogniser).
+template <int J, bool NOP = false>
+__device__ __forceinline__ void fmac_bcast(double &a, double b, double c) {
+  if (NOP)
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(a)
+                 : "v"(b), "v"(c), "n"(J));
+  else
+    asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(a)
+                 : "v"(b), "v"(c), "n"(J));
+}
+
 // rank-1 step of leaf column C on the columns J..15 of every row
 template <int C, int J>
 struct LeafUpd {
   static __device__ __forceinline__ void run(double (&a)[16], double l) {
-    a[J] = fma(-l, row_bcast<J>(l), a[J]);
+    fmac_bcast<J, J == C + 2>(a[J], l, l);     // (the first of a column waits out the hazard, wherever it is scheduled)
     LeafUpd<C, J + 1>::run(a, l);
   }
 };
