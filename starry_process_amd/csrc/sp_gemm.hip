@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void mm_nt_kernel(
     if (df.sys) {
       __builtin_amdgcn_s_setprio(3);
       panel_diag_item(df.sys + (size_t)mtx * df.stride, df.ld, df.j, df.nact,
-                      df.img + (size_t)mtx * df.lts + (size_t)(df.j & 1) * SP_LT_IMG,
+                      df.img + (size_t)mtx * df.lts + sp_img_off(df.j),
                       df.info ? df.info + mtx : nullptr, lds, threadIdx.x);
     }
     return;

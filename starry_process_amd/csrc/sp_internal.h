@@ -241,7 +241,7 @@ int sp_launch_panel2(int layout, const SpReduceArgs *red, double *sys, long ld, 
 int sp_launch_syrk_diag(const double *X, long ld, long stride, double *T, int n, int kd, int batch,
                         hipStream_t st, const LazyCov *lazy, const DiagFuse *df);
 
-// per-star scratch of the factorisation: two image slots (sp_tile.h: SP_LT_IMG doubles each).  Doubles.
+// per-star scratch of the factorisation: three image slots + the chain words (sp_tile.h).  Doubles.
 static inline long sp_lt_stride(int) { return 2 * 4096L; }
 
 #endif

@@ -157,7 +157,7 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
   const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fk = lane >> 4;
   const long ld = a.ld;
   const int Kd = 64 * (kb1 - kb0);
-  const double *img = img_star + (size_t)(a.j & 1) * SP_LT_IMG;
+  const double *img = img_star + sp_img_off(a.j);
   const bool chain = NR == 1 && !la && i0 == a.j + 1 && (a.mode & P_TAILD);   // this item factors the next block
 #ifdef SP_PANEL_TRACE
   const int role = i0 == a.j + 1 ? 1 : (i0 + NR == a.ntile ? 2 : -1);
@@ -409,11 +409,11 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
       P2_CHAIN(1, wall_clock64());
       P2_CHAIN(3, cu_key());
 #ifdef SP_PANEL_TRACE
-      panel_diag_core(Dt, ld, nact, img_star + (size_t)((a.j + 1) & 1) * SP_LT_IMG,
+      panel_diag_core(Dt, ld, nact, img_star + sp_img_off(a.j + 1),
                       a.info ? a.info + mtx : nullptr, smem, tid,
                       (mtx == 0 && a.j < 64) ? &g_p2trace[(a.j * 3) * 16 + 8] : nullptr, nlive);
 #else
-      panel_diag_core(Dt, ld, nact, img_star + (size_t)((a.j + 1) & 1) * SP_LT_IMG,
+      panel_diag_core(Dt, ld, nact, img_star + sp_img_off(a.j + 1),
                       a.info ? a.info + mtx : nullptr, smem, tid, nullptr, nlive);
 #endif
       if (a.red.lnlike) {
@@ -456,7 +456,7 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
 //                                            which have their CU to themselves otherwise, go from 14 to 17-20 us.)
 // Nobody waits for a sleeper and the chain waits for nobody: only time is at stake.
 __device__ __forceinline__ unsigned long long *chain_words(double *img_star) {
-  return reinterpret_cast<unsigned long long *>(img_star + SP_IMG_DOUBLES);   // [0] seq << 32 | CU key, [1] seq when done
+  return reinterpret_cast<unsigned long long *>(img_star + SP_IMG_WORDS);   // [0] seq << 32 | CU key, [1] seq when done
 }
 
 __global__ __launch_bounds__(256, P_WGS) void panel_kernel(PanelArgs a) {
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256, P_WGS) void panel_kernel(PanelArgs a) {
   double *img_star = a.img + (size_t)mtx * a.lts;
   if (strip < nd) {
     P2_STAMP(0, 0);
-    double *img = img_star + (size_t)(a.j & 1) * SP_LT_IMG;
+    double *img = img_star + sp_img_off(a.j);
 #ifdef SP_PANEL_TRACE
     panel_diag_item(M, a.ld, a.j, a.nact, img, a.info ? a.info + mtx : nullptr, smem, tid,
                     (mtx == 0 && a.j < 64) ? &g_p2trace[(a.j * 3) * 16 + 8] : nullptr);

@@ -23,10 +23,13 @@ __device__ __forceinline__ bool sp_xcd_decode(int b, int batch, int ntiles, int 
 static inline long sp_xcd_grid(long batch, long ntiles) { return 8L * ((batch * ntiles + 7) / 8); }
 
 
-// per-star scratch of the factorisation: two image slots of SP_LT_IMG doubles (L_d^-1 of the pivot
-// block in the fragment order of the panel kernel's solve, sp_paneldiag.h: 2560 doubles), used in
-// turn -- the launch of panel j reads slot j & 1 while the workgroup that factors block j + 1 in
-// its tail writes the other.  `lts` doubles apart from star to star (sp_lt_stride, sp_internal.h).
-#define SP_LT_IMG 4096
+// per-star scratch of the factorisation (`lts` = sp_lt_stride doubles apart from star to star, sp_internal.h):
+// THREE image slots of SP_IMG_SLOT doubles (L_d^-1 of a pivot block in the fragment order of the panel kernel's
+// solve, sp_paneldiag.h: 2560 doubles), slot j mod 3 for pivot block j -- a launch that handles the columns j and
+// j + 1 reads the images of blocks j and j + 1 while block j + 2's is being written -- and, behind them, the words
+// the chain workgroups of a launch publish (sp_panel.hip).
+#define SP_IMG_SLOT 2688
+#define SP_IMG_WORDS (3 * SP_IMG_SLOT)
+__host__ __device__ __forceinline__ size_t sp_img_off(int j) { return (size_t)(j % 3) * SP_IMG_SLOT; }
 
 #endif
