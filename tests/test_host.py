@@ -48,6 +48,11 @@ def test_no_device_is_an_error_not_a_fallback():
         from starry_process_amd.engine import Engine
 
         Engine(5, 2, 0)
+    # ... and the gradient (grad.py: torch autograd around the library's reverse-mode kernels) has no CPU path either
+    with pytest.raises(_lib.SPError):
+        from starry_process_amd.grad import log_likelihood_with_grad
+
+        log_likelihood_with_grad(np.zeros(256), np.eye(256), np.linspace(0, 1, 8), np.zeros(8), 1.0)
 
 
 @pytest.mark.parametrize("L", LS)
