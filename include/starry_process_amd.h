@@ -330,6 +330,12 @@ int sp_gp_condition(sp_handle *h, int K, int Ks, const double *Ktt_dev, const do
  * starry_process_amd/upstream.py.                                             */
 int sp_latitude_integrals(int ydeg, double alpha, double beta, double *q_host,
                           double *Q_host);
+/* n-point Gauss-Jacobi rule for the weight (1 - t)^a (1 + t)^b on (-1, 1), a, b > -1; weights
+ * normalised to sum 1.  The latitude expectation of the device upstream: cos(phi) ~ Beta(alpha,
+ * beta) over the WHOLE prior box of latitude.py:176-197 (alpha <= exp(5), beta <= exp(10)) --
+ * Golub-Welsch on the Jacobi matrix, so the zeroth moment that overflows in the textbook
+ * normalisation never appears.  Host only, no handle.                                       */
+int sp_gauss_jacobi(int n, double a, double b, double *nodes_host, double *weights_host);
 
 /* ---- upstream of the path, on the device ---------------------------
  * (mu_y [N], Sigma_y [N, N]) on the device from the host-side pieces of the hyperparameters, by

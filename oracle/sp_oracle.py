@@ -903,17 +903,37 @@ class OracleProcess(object):
 # restatements of Rx / dotRx / tensordotRz above).  It is an independent check of what
 # the reference's integrals (latitude.py:199-212, longitude.py:19-24, contrast.py:18-33)
 # ARE, and the checker of the device version.
+def gauss_jacobi(n, a, b):
+    """n-point Gauss-Jacobi rule for (1 - t)^a (1 + t)^b, weights summing to 1, by Golub-Welsch
+    with LAPACK's tridiagonal eigensolver (scipy.special.roots_jacobi overflows in its
+    normalisation for a + b > ~1 020; the normalisation cancels here)."""
+    from scipy.linalg import eigh_tridiagonal
+
+    k = np.arange(n, dtype=np.float64)
+    s = 2.0 * k + a + b
+    d = np.empty(n)
+    d[0] = (b - a) / (a + b + 2.0)
+    d[1:] = (b * b - a * a) / (s[1:] * (s[1:] + 2.0))
+    k1, s1 = k[1:], s[1:]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        e2 = 4.0 * k1 * (k1 + a) * (k1 + b) * (k1 + a + b) / (s1 * s1 * (s1 + 1.0) * (s1 - 1.0))
+    if n > 1:
+        e2[0] = 4.0 * (1.0 + a) * (1.0 + b) / ((2.0 + a + b) ** 2 * (3.0 + a + b))
+    if n == 1:
+        return d.copy(), np.ones(1)
+    t, V = eigh_tridiagonal(d, np.sqrt(e2))
+    w = V[0] ** 2
+    return t, w / w.sum()
+
+
 def ylm_moments_quadrature(size_first, size_factor_cols, alpha, beta, c, n, ydeg,
                            epsy=1e-12, epsy15=1e-9, refine=1):
     """size_first [N]; size_factor_cols [m, N] (columns of the size second-moment factor;
     pass size_first[None, :] for a fixed spot radius).  Returns (mu_y, Sigma_y)."""
-    from scipy.special import roots_jacobi
-
     N = (ydeg + 1) ** 2
     nq = refine * (ydeg + 2)
-    t, w = roots_jacobi(nq, beta - 1.0, alpha - 1.0)
+    t, w = gauss_jacobi(nq, beta - 1.0, alpha - 1.0)
     x = 0.5 * (1.0 + t)
-    w = w / w.sum()
     phis = np.concatenate([np.arccos(x), -np.arccos(x)])
     wphi = 0.5 * np.concatenate([w, w])
     nl = refine * (2 * ydeg + 3)

@@ -76,6 +76,7 @@ PROTOTYPES = {
     "sp_rTA1": (_I, [_V, _V]),
     "sp_rTA1L": (_I, [_V, _V, _I, _V]),
     "sp_latitude_integrals": (_I, [_I, _D, _D, _V, _V]),
+    "sp_gauss_jacobi": (_I, [_I, _D, _D, _V, _V]),
     "sp_allgather_lnlike": (_I, [_V, _V, _V, _I, _V, _V]),
     "sp_tensordotRz_rev": (_I, [_V, _V, _V, _I, _V, _V, _V, _V]),
     "sp_special_tensordotRz_rev": (_I, [_V, _V, _V, _V, _I, _V, _V, _V, _V]),

@@ -496,3 +496,83 @@ extern "C" int sp_latitude_integrals(int ydeg, double alpha, double beta, double
   }
   return SP_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Gauss-Jacobi rule for the weight (1 - t)^a (1 + t)^b on (-1, 1), a, b > -1,
+// weights normalised to sum 1 (the rule of an expectation under a Beta law).
+// Golub-Welsch: the nodes are the eigenvalues of the symmetric tridiagonal
+// Jacobi matrix of the orthonormal recurrence, the weights the squared first
+// components of its normalised eigenvectors -- the zeroth moment
+// 2^(a+b+1) B(a+1, b+1), which overflows / underflows for the shape
+// parameters at the edge of the reference's prior box (latitude.py:176-197:
+// beta up to exp(10)), never appears.  Implicit-shift QL on (d, e) that carries
+// only the first row of the eigenvector matrix.
+// ---------------------------------------------------------------------------
+extern "C" int sp_gauss_jacobi(int n, double a, double b, double *nodes, double *weights) {
+  if (n < 1 || n > 4096 || !(a > -1.0) || !(b > -1.0) || !nodes || !weights ||
+      !std::isfinite(a) || !std::isfinite(b))
+    return SP_ERR_INVALID;
+  std::vector<double> d(n), e(n, 0.0), z(n, 0.0);
+  const double ab = a + b;
+  d[0] = (b - a) / (ab + 2.0);
+  for (int k = 1; k < n; ++k) {
+    const double s = 2.0 * k + ab;
+    d[k] = (b - a) * (b + a) / (s * (s + 2.0));
+    // off-diagonal k-1 <-> k; for k = 1 the factor (k + a + b) / (2k + a + b - 1) is 1
+    const double num = (k == 1) ? 4.0 * (1.0 + a) * (1.0 + b) / ((s * s) * (s + 1.0))
+                                : 4.0 * k * (k + a) * (k + b) * (k + ab) / ((s * s) * (s + 1.0) * (s - 1.0));
+    e[k - 1] = std::sqrt(num);
+  }
+  z[0] = 1.0;
+  for (int l = 0; l < n; ++l) {
+    for (int iter = 0;; ++iter) {
+      int m = l;
+      for (; m < n - 1; ++m) {
+        const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
+        if (std::fabs(e[m]) <= 2.3e-16 * dd) break;
+      }
+      if (m == l) break;
+      if (iter == 200) return SP_ERR_INVALID;
+      double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+      double r = std::hypot(g, 1.0);
+      g = d[m] - d[l] + e[l] / (g + std::copysign(r, g));
+      double s = 1.0, c = 1.0, p = 0.0;
+      int i = m - 1;
+      for (; i >= l; --i) {
+        double f = s * e[i];
+        const double bb = c * e[i];
+        r = std::hypot(f, g);
+        e[i + 1] = r;
+        if (r == 0.0) {
+          d[i + 1] -= p;
+          e[m] = 0.0;
+          break;
+        }
+        s = f / r;
+        c = g / r;
+        g = d[i + 1] - p;
+        r = (d[i] - g) * s + 2.0 * c * bb;
+        p = s * r;
+        d[i + 1] = g + p;
+        g = c * r - bb;
+        f = z[i + 1];
+        z[i + 1] = s * z[i] + c * f;
+        z[i] = c * z[i] - s * f;
+      }
+      if (r == 0.0 && i >= l) continue;
+      d[l] -= p;
+      e[l] = g;
+      e[m] = 0.0;
+    }
+  }
+  std::vector<int> order(n);
+  for (int i = 0; i < n; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](int x, int y) { return d[x] < d[y]; });
+  double sum = 0.0;
+  for (int i = 0; i < n; ++i) sum += z[i] * z[i];
+  for (int i = 0; i < n; ++i) {
+    nodes[i] = d[order[i]];
+    weights[i] = z[order[i]] * z[order[i]] / sum;
+  }
+  return SP_OK;
+}

@@ -249,39 +249,61 @@ def log_likelihood_with_grad(mean_ylm, cov_ylm, t, flux, data_var, i=defaults["i
 
 
 def hyper_gradient(t, flux, data_var, r=defaults["r"], dr=defaults["dr"], a=defaults["a"], b=defaults["b"],
-                   c=defaults["c"], n=defaults["n"], h=1e-4, **kwargs):
+                   c=defaults["c"], n=defaults["n"], h=1e-4, upstream_kwargs=None, moments0=None, **kwargs):
     """(lnL, {"r": ., "a": ., "b": ., "c": ., "n": ., "p": ., ...}): the log-likelihood of one light curve and its
     gradient with respect to the spot hyperparameters (moments by the device quadrature, upstream_device.py;
     "dr" too when a spread of radii is given) and whatever else ``log_likelihood_with_grad`` differentiates
     (p; i on the conditional branch; tau).
-    kwargs: as for ``log_likelihood_with_grad`` (i, p, u, tau, normalized, marginalize_over_inclination, ...)."""
+    kwargs: as for ``log_likelihood_with_grad`` (i, p, u, tau, normalized, marginalize_over_inclination, ...);
+    moments0: (mu_y, Sigma_y) the value and the moment gradient are taken at, when they are not the device
+    quadrature's own (a process built with upstream="reference": same integrals, the reference's rounding);
+    upstream_kwargs: the constructor's numerical keywords of the moment integrals (epsy, epsy15, sfac, ...).
+    a and b are differentiated by central differences of the moments, one-sided within a step of the bounds
+    [0, 1] (ops/exceptions.py:30-48 raises outside); c = 0 or n = 0 (no spots: Sigma_y = diag(eps), mu_y = 0)
+    has a zero gradient in the other of the two and is returned as such."""
     from .upstream_device import ylm_moments_device
 
     ydeg = kwargs.get("ydeg", defaults["ydeg"])
     e = get_engine(ydeg, kwargs.get("udeg", defaults["udeg"]), kwargs.get("device"))
 
-    def moments(r_, dr_, a_, b_):
-        mu, Sig = ylm_moments_device(e, r=r_, dr=dr_, a=a_, b=b_, c=c, n=n)
+    ukw = dict(upstream_kwargs or {})
+
+    def moments(r_, dr_, a_, b_, c_=c, n_=n):
+        mu, Sig = ylm_moments_device(e, r=r_, dr=dr_, a=a_, b=b_, c=c_, n=n_, **ukw)
         return mu.cpu().numpy(), Sig.cpu().numpy()
 
     mu, Sig = moments(r, dr, a, b)
-    lnl, g = log_likelihood_with_grad(mu, Sig, t, flux, data_var, **kwargs)
+    mu_at, Sig_at = (mu, Sig) if moments0 is None else (np.asarray(moments0[0]), np.asarray(moments0[1]))
+    lnl, g = log_likelihood_with_grad(mu_at, Sig_at, t, flux, data_var, **kwargs)
     gmu, gSig = g["mean_ylm"], g["cov_ylm"]
     N = mu.shape[0]
-    eps = np.ones(N) * defaults["epsy"]
-    eps[15 ** 2:] = defaults["epsy15"]
+    eps = np.ones(N) * float(ukw.get("epsy", defaults["epsy"]))
+    eps[15 ** 2:] = float(ukw.get("epsy15", defaults["epsy15"]))
     S0 = Sig - np.diag(eps)                       # the part of Sigma_y that scales with c and n
     out = {k: v for k, v in g.items() if k not in ("mean_ylm", "cov_ylm")}
-    out.update({"c": float(gmu @ mu / c + 2.0 * np.sum(gSig * S0) / c),      # mu ~ c, Sigma ~ c^2 (contrast.py:21-33)
-                "n": float(gmu @ mu / n + np.sum(gSig * S0) / n)})           # mu ~ n, Sigma ~ n
+    if c != 0 and n != 0:
+        # mu ~ c n, Sigma ~ c^2 n (contrast.py:21-33)
+        out.update({"c": float(gmu @ mu / c + 2.0 * np.sum(gSig * S0) / c),
+                    "n": float(gmu @ mu / n + np.sum(gSig * S0) / n)})
+    else:
+        # at c = 0 (n = 0) the moments are linear (quadratic) in the vanishing parameter: take the
+        # derivative from the moments at unit value of it
+        m1, S1 = moments(r, dr, a, b, c_=c if c != 0 else 1.0, n_=n if n != 0 else 1.0)
+        S1 = S1 - np.diag(eps)
+        out.update({"c": float(gmu @ m1) if (c == 0 and n != 0) else 0.0,     # d mu / dc = mu(c = 1); d Sigma / dc = 0
+                    "n": float(gmu @ m1 + np.sum(gSig * S1)) if (n == 0 and c != 0) else 0.0})
     x0 = {"r": r, "dr": dr, "a": a, "b": b}
+    bounds = {"r": (0.0, 90.0), "dr": (0.0, 90.0), "a": (0.0, 1.0), "b": (0.0, 1.0)}
     for name in ("r", "dr", "a", "b"):
         if x0[name] is None:
             continue
-        step = h * max(abs(float(x0[name])), 0.1)
+        x = float(x0[name])
+        step = h * max(abs(x), 0.1)
+        lo_b, hi_b = bounds[name]
+        xl, xh = max(x - step, lo_b), min(x + step, hi_b)       # one-sided within a step of a bound
         lo, hi = dict(x0), dict(x0)
-        lo[name], hi[name] = x0[name] - step, x0[name] + step
-        m0, S0_ = moments(lo["r"], lo["dr"], lo["a"], lo["b"])
-        m1, S1_ = moments(hi["r"], hi["dr"], hi["a"], hi["b"])
-        out[name] = float(gmu @ ((m1 - m0) / (2 * step)) + np.sum(gSig * ((S1_ - S0_) / (2 * step))))
+        lo[name], hi[name] = xl, xh
+        m0, S0_ = (mu, Sig) if xl == x else moments(lo["r"], lo["dr"], lo["a"], lo["b"])
+        m1, S1_ = (mu, Sig) if xh == x else moments(hi["r"], hi["dr"], hi["a"], hi["b"])
+        out[name] = float(gmu @ ((m1 - m0) / (xh - xl)) + np.sum(gSig * ((S1_ - S0_) / (xh - xl))))
     return lnl, out

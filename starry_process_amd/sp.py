@@ -93,7 +93,8 @@ class StarryProcess(object):
 
         self._engine = get_engine(self._ydeg, self._udeg, kwargs.get("device"))
         dev_moments = None
-        if mean_ylm is None or cov_ylm is None:
+        from_hyper = mean_ylm is None or cov_ylm is None
+        if from_hyper:
             # upstream="reference" (default): the reference's algorithm on the host, comparable
             # digit by digit on the same host; upstream="device": the same integrals by exact
             # quadrature of rotations on the GPU (upstream_device.py), ~50x faster and free of
@@ -111,6 +112,7 @@ class StarryProcess(object):
             else:
                 raise ValueError("upstream must be 'reference' or 'device'")
         self._dev_moments = dev_moments
+        self._from_hyper = from_hyper      # built from (r, dr, a, b, c, n), not from explicit moments
         if dev_moments is None:
             self._host_moments = (np.asarray(mean_ylm, dtype=np.float64).reshape(-1),
                                   np.asarray(cov_ylm, dtype=np.float64))
@@ -280,9 +282,14 @@ class StarryProcess(object):
                   marginalize_over_inclination=self._marginalize_over_inclination, normalized=self._normalized,
                   covpts=self._covpts, ydeg=self._ydeg, udeg=self._udeg, norm_order=self._normN,
                   zmax=self._normzmax, device=self._kwargs.get("device"))
-        if self._dev_moments is not None:
+        if self._from_hyper:
+            # (whichever upstream built the moments: the chain rule through the hyperparameters runs on the
+            #  device quadrature, whose moments are the same integrals -- upstream_device.py)
+            ukw = {k: self._kwargs[k] for k in ("epsy", "epsy15", "spts", "eps4", "smoothing", "sfac", "cutoff",
+                                                "abmin", "log_alpha_max", "log_beta_max") if k in self._kwargs}
             lnl, g = hyper_gradient(t, flux, data_cov, r=self._r, dr=self._dr, a=self._a, b=self._b, c=self._c,
-                                    n=self._n, **kw)
+                                    n=self._n, upstream_kwargs=ukw,
+                                    moments0=None if self._dev_moments is not None else self._host_moments, **kw)
         else:
             lnl, g = log_likelihood_with_grad(self._mean_ylm, self._cov_ylm, t, flux, data_cov, **kw)
         return Eager(np.float64(lnl)), g

@@ -32,8 +32,8 @@ the same per-degree profile as reference-vs-reference on two hosts.  ``upstream.
 (the reference's algorithm, bit-comparable on the same host) stays the default.
 """
 import numpy as np
-from scipy.special import roots_jacobi
 
+from . import _lib
 from .defaults import defaults
 from .ops import CheckBoundsOp
 from .upstream import ab_to_alphabeta, size_moments
@@ -41,13 +41,21 @@ from .upstream import ab_to_alphabeta, size_moments
 __all__ = ["ylm_moments_device", "quadrature_nodes"]
 
 
+def gauss_jacobi(n, a, b):
+    """(nodes, weights summing to 1) of the n-point Gauss-Jacobi rule for (1 - t)^a (1 + t)^b:
+    the library's host routine (Golub-Welsch, csrc/sp_host.cpp).  scipy.special.roots_jacobi
+    normalises by the zeroth moment, which overflows once a + b exceeds ~1 020 -- a quarter of
+    the reference's prior box in b (latitude.py:176-197) -- and costs 0.3 ms per call."""
+    t, w = np.empty(n), np.empty(n)
+    _lib.check(_lib.lib().sp_gauss_jacobi(int(n), float(a), float(b), _lib.hptr(t), _lib.hptr(w)))
+    return t, w
+
+
 def quadrature_nodes(ydeg, alpha, beta):
     """(phi [P], w_phi [P], lam [Q]): latitude angles with their weights (sum 1) and the
     equispaced longitudes (weight 1 / Q each)."""
-    nq = ydeg + 2
-    t, w = roots_jacobi(nq, beta - 1.0, alpha - 1.0)   # weight (1 - t)^(beta-1) (1 + t)^(alpha-1)
+    t, w = gauss_jacobi(ydeg + 2, beta - 1.0, alpha - 1.0)   # weight (1 - t)^(beta-1) (1 + t)^(alpha-1)
     x = 0.5 * (1.0 + t)                                 # cos(phi) in (0, 1)
-    w = w / w.sum()
     phi = np.arccos(x)
     nl = 2 * ydeg + 3
     return (np.concatenate([phi, -phi]), 0.5 * np.concatenate([w, w]),

@@ -29,6 +29,8 @@ Files (L = ydeg):
                     the reference's own StarryProcess / cho_factor / cho_solve.
   rev_L{L}.npz      reverse-mode ops (tensordotRz_rev, special_tensordotRz_rev, rTA1L_rev)
   predict.npz       StarryProcess.predict (sp.py:767-903): conditional mean / covariance
+  upstream_grid.npz (mu_y, Sigma_y) and log-likelihoods of the reference over its whole (a, b)
+                    prior box, and its b scan of tests/test_lnlike.py (`make_golden.py upstream_grid`)
   upstream.npz      upstream-of-path pieces: size / latitude / longitude first
                     moments, log_jac, gauss2beta / beta2gauss, mu / sigma
   lnlike.npz        log-likelihoods for the BASELINE.json configs
@@ -266,6 +268,46 @@ def gen_upstream():
     out["lon_q"] = A(lon._q)
     out["lon_Q_diag"] = np.diag(A(lon._Q)).copy()
     save("upstream.npz", **out)
+
+
+def gen_upstream_grid():
+    """The reference's (mu_y, Sigma_y) over its whole latitude prior box (latitude.py:176-197),
+    ydeg = 15: a in {0, .5, 1} x b in {0, .25, .5, .74, .9, 1}, the other hyperparameters at their
+    defaults -- and its log-likelihood there, plus the b scan of tests/test_lnlike.py:60-97 on a
+    fixed light curve.  Sigma_y: rows of degree <= 8 in full (float64); of the rest the lower
+    triangle of the (l >= 9) x (l >= 9) block in float32 -- the reference's own rounding noise
+    there is 1e-3 of max|Sigma_y|, float32 carries more than it means."""
+    out = {}
+    st = synthetic_star(0, 300)
+    aa, bb = [0.0, 0.5, 1.0], [0.0, 0.25, 0.5, 0.74, 0.9, 1.0]
+    out["a"], out["b"] = np.array(aa), np.array(bb)
+    out["t"], out["flux"], out["data_cov"], out["p"] = st["t"], st["flux"], np.array(st["data_cov"]), np.array(st["p"])
+    il = np.tril_indices(256 - 81)
+    mean = np.empty((3, 6, 256))
+    top = np.empty((3, 6, 81, 256))
+    low = np.empty((3, 6, il[0].size), dtype=np.float32)
+    ll = np.empty((3, 6, 2))
+    for i, a in enumerate(aa):
+        for j, b in enumerate(bb):
+            sp = SP(ydeg=15, a=a, b=b)
+            S = A(sp._cov_ylm)
+            mean[i, j] = A(sp._mean_ylm)
+            top[i, j] = S[:81]
+            low[i, j] = S[81:, 81:][il]
+            ll[i, j, 0] = float(A(sp.log_likelihood(st["t"], st["flux"], st["data_cov"], p=st["p"])))
+            spc = SP(ydeg=15, a=a, b=b, marginalize_over_inclination=False, normalized=False)
+            ll[i, j, 1] = float(A(spc.log_likelihood(st["t"], st["flux"], st["data_cov"], p=st["p"], i=60.0)))
+            print("  a=%.2f b=%.2f  lnlike %.10g %.10g" % (a, b, ll[i, j, 0], ll[i, j, 1]))
+    out["mean_ylm"], out["cov_top"], out["cov_low_f32"], out["lnlike"] = mean, top, low, ll
+    b_arr = np.linspace(0.0, 1.0, 100)
+    scan = np.empty((100, 2))
+    for k, b in enumerate(b_arr):
+        sp = SP(ydeg=15, b=b)
+        scan[k, 0] = float(A(sp.log_likelihood(st["t"], st["flux"], st["data_cov"], p=st["p"])))
+        spc = SP(ydeg=15, b=b, marginalize_over_inclination=False, normalized=False)
+        scan[k, 1] = float(A(spc.log_likelihood(st["t"], st["flux"], st["data_cov"], p=st["p"], i=60.0)))
+    out["scan_b"], out["scan_lnlike"] = b_arr, scan
+    save("upstream_grid.npz", **out)
 
 
 def gen_rev(L, U=2):
@@ -516,6 +558,8 @@ if __name__ == "__main__":
         gen_lnlike_full()
     if "upstream" in which:
         gen_upstream()
+    if "upstream_grid" in which:   # (not in the default list: five minutes)
+        gen_upstream_grid()
     if "calibrate" in which:
         gen_calibrate()
     if "predict" in which:

@@ -397,14 +397,19 @@ def test_lnlike_array(marginalize_over_inclination):
     flux_err = 1e-3
     rng = np.random.RandomState(42)
     flux = flux + rng.randn(t.size) * flux_err
+    import warnings
+
     b_arr = np.linspace(0.0, 1.0, 100)
     ll = np.empty(b_arr.size)
-    for k, b in enumerate(b_arr):
-        p2 = dict(params, b=b)
-        ll[k] = float(StarryProcess(**p2, **kw).log_likelihood(t, flux, flux_err ** 2, p=defaults["p"],
-                                                              i=defaults["i"]))
-    assert np.isfinite(np.nanmax(ll))
-    assert abs(b_arr[np.nanargmax(ll)] - defaults["b"]) < 0.10
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")          # round 3: SciPy's Gauss-Jacobi overflowed for b >= 0.737
+        for k, b in enumerate(b_arr):
+            p2 = dict(params, b=b)
+            ll[k] = float(StarryProcess(**p2, **kw).log_likelihood(t, flux, flux_err ** 2, p=defaults["p"],
+                                                                  i=defaults["i"]))
+    assert not np.any(np.isnan(ll))             # the reference's scan has no NaN (tests/golden/upstream_grid.npz)
+    assert np.isfinite(ll).sum() >= 95          # (-inf: a covariance the factorisation rejects, math.py:82-91)
+    assert abs(b_arr[np.argmax(ll)] - defaults["b"]) < 0.10
 
 
 def test_ensemble_log_prob_many_samples():

@@ -177,6 +177,23 @@ def test_facade_log_likelihood_grad():
     _, g2 = hyper_gradient(st["t"], st["flux"], st["data_cov"], r=20.0, a=0.5, b=0.3, c=0.08, n=5.0, tau=1.5,
                            p=st["p"])
     assert set(g) == {"r", "a", "b", "c", "n", "p", "tau"} and all(g[k] == g2[k] for k in g)
+    # the DEFAULT constructor (upstream="reference") is a process built from hyperparameters too: same keys, the
+    # value is its own log_likelihood, the gradient the device chain's to the accuracy the two upstreams agree
+    spr = StarryProcess(r=20.0, a=0.5, b=0.3, c=0.08, n=5.0, tau=1.5)
+    lnl_r, g_r = spr.log_likelihood_grad(st["t"], st["flux"], st["data_cov"], p=st["p"])
+    ref_r = float(spr.log_likelihood(st["t"], st["flux"], st["data_cov"], p=st["p"]).eval())
+    assert abs(float(lnl_r.eval()) - ref_r) < 1e-9 * abs(ref_r)
+    assert set(g_r) == set(g)
+    for k in g:
+        assert abs(g_r[k] - g[k]) < 1e-3 * max(abs(g[k]), 1e-3 * max(abs(v) for v in g.values())), k
+    # custom stabilisers reach the chain rule; hyperparameters on the bounds of the prior box do not leave it
+    spe = StarryProcess(r=20.0, a=0.0, b=1.0, c=0.08, n=5.0, epsy=1e-10, epsy15=1e-8, upstream="device")
+    lnl_e, g_e = spe.log_likelihood_grad(st["t"], st["flux"], st["data_cov"], p=st["p"])
+    ref_e = float(spe.log_likelihood(st["t"], st["flux"], st["data_cov"], p=st["p"]).eval())
+    assert abs(float(lnl_e.eval()) - ref_e) < 1e-9 * abs(ref_e) and all(np.isfinite(v) for v in g_e.values())
+    sp0 = StarryProcess(r=20.0, c=0.0, upstream="device")
+    _, g_0 = sp0.log_likelihood_grad(st["t"], st["flux"], st["data_cov"], p=st["p"])
+    assert all(np.isfinite(v) for v in g_0.values()) and g_0["n"] == 0.0
     # per-point data variance, a spread of radii, the conditional branch
     sp = StarryProcess(r=20.0, dr=5.0, marginalize_over_inclination=False, normalized=False, upstream="device")
     var = np.linspace(1e-6, 2e-6, 80)

@@ -1,0 +1,88 @@
+"""
+The device upstream's quadrature over the WHOLE latitude prior box of the reference
+(latitude.py:176-197: a, b in [0, 1] -> alpha <= exp(5), beta <= exp(10)).
+
+CPU half (no GPU): the Gauss-Jacobi rule of the library (sp_gauss_jacobi, Golub-Welsch) is finite,
+ordered and equal to an independent LAPACK evaluation everywhere in the box -- round 3 used
+scipy.special.roots_jacobi, whose normalisation overflows for b >= 0.737 --, integrates the Beta
+law's moments exactly, and the method itself (oracle.ylm_moments_quadrature: the same rotations on
+the CPU) reproduces the reference's (mu_y, Sigma_y) at the 18 grid points of
+tests/golden/upstream_grid.npz within the per-degree bounds of tests/test_gpu_upstream_device.py.
+"""
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import golden
+from starry_process_amd import upstream
+from starry_process_amd.upstream_device import gauss_jacobi, quadrature_nodes
+
+
+def grid_cov_errors(S, g, i, j):
+    """(scale, max error rows l <= 4, rows l <= 8, (l >= 9)^2 block) against the grid fixture."""
+    top = g["cov_top"][i, j]
+    scale = np.abs(top).max()
+    d = np.abs(S[:81] - top)
+    il = np.tril_indices(256 - 81)
+    low = np.abs(S[81:, 81:][il] - g["cov_low_f32"][i, j].astype(np.float64)).max()
+    return scale, d[:25].max(), d.max(), low
+
+
+def test_gauss_jacobi_over_the_prior_box():
+    from oracle.sp_oracle import gauss_jacobi as gj_oracle
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                  # no overflow / invalid anywhere
+        for a in np.linspace(0.0, 1.0, 11):
+            for b in np.linspace(0.0, 1.0, 100):        # the b scan of tests/test_lnlike.py:84-88
+                alpha, beta = upstream.ab_to_alphabeta(a, b)
+                for n in (7, 17, 22):                   # ydeg + 2 for ydeg = 5, 15, 20
+                    t, w = gauss_jacobi(n, beta - 1.0, alpha - 1.0)
+                    assert np.all(np.isfinite(t)) and np.all(np.isfinite(w))
+                    assert np.all(np.diff(t) > 0) and t[0] > -1 and t[-1] < 1
+                    assert np.all(w > 0) and abs(w.sum() - 1) < 1e-14
+                    t2, w2 = gj_oracle(n, beta - 1.0, alpha - 1.0)
+                    assert np.abs(t - t2).max() < 1e-11 * (t2[-1] - t2[0])
+                    assert np.abs(w - w2).max() < 1e-11
+                phi, wphi, lam = quadrature_nodes(15, alpha, beta)
+                assert np.all(np.isfinite(phi)) and np.all(np.isfinite(wphi)) and abs(wphi.sum() - 1) < 1e-14
+
+
+@pytest.mark.parametrize("a,b", [(0.4, 0.27), (0.0, 0.0), (1.0, 1.0), (0.5, 0.74), (0.5, 0.9), (0.0, 1.0), (1.0, 0.0)])
+def test_gauss_jacobi_integrates_beta_moments(a, b):
+    """E[x^k], x ~ Beta(alpha, beta), k < 2n: prod_j (alpha + j) / (alpha + beta + j)."""
+    alpha, beta = upstream.ab_to_alphabeta(a, b)
+    n = 17
+    t, w = gauss_jacobi(n, beta - 1.0, alpha - 1.0)
+    x = 0.5 * (1.0 + t)
+    m = 1.0
+    for k in range(2 * n):
+        assert abs(np.sum(w * x ** k) / m - 1) < 1e-10, k
+        m *= (alpha + k) / (alpha + beta + k)
+
+
+def test_gauss_jacobi_rejects_bad_arguments():
+    from starry_process_amd._lib import SPError
+
+    for n, a, b in ((0, 0.0, 0.0), (5, -1.0, 0.0), (5, 0.0, -2.0), (5, np.nan, 0.0), (5, np.inf, 0.0)):
+        with pytest.raises(SPError):
+            gauss_jacobi(n, a, b)
+    t, w = gauss_jacobi(1, 2.0, 0.5)                    # one node: the mean of the law
+    assert abs(t[0] - (0.5 - 2.0) / (2.0 + 0.5 + 2.0)) < 1e-15 and w[0] == 1.0
+
+
+def test_quadrature_method_matches_reference_over_the_grid():
+    from oracle import sp_oracle as orc
+
+    g = golden("upstream_grid")
+    s1, _ = upstream.size_moments(20.0, None, 15)
+    for i, a in enumerate(g["a"]):
+        for j, b in enumerate(g["b"]):
+            alpha, beta = upstream.ab_to_alphabeta(a, b)
+            mu, S = orc.ylm_moments_quadrature(s1, s1[None, :], alpha, beta, 0.1, 10.0, 15)
+            assert np.all(np.isfinite(mu)) and np.all(np.isfinite(S))
+            mr = g["mean_ylm"][i, j]
+            assert np.abs(mu - mr).max() < 1e-9 * np.abs(mr).max(), (a, b)
+            scale, e4, e8, elow = grid_cov_errors(S, g, i, j)
+            assert e4 < 1e-7 * scale and e8 < 1e-5 * scale and elow < 5e-2 * scale, (a, b)
