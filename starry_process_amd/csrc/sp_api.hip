@@ -37,6 +37,10 @@ int sp_launch_assemble(int S, int K, int M, int Kp, int system,
                        const double *diag, int add_noise, const double *flux,
                        double *out, long ldo, long strideo, hipStream_t st, double *part = nullptr,
                        int lazy_nfull = 0);
+int sp_launch_assemble_sums(int S, int K, int M, int Kp, const double *theta, const double *t,
+                            const sp_star *stars, int covpts, const double *ptab, const double *meanvar,
+                            int temporal, const double *flux, double *sys, hipStream_t st, double *part,
+                            int lazy_nfull);
 int sp_launch_defer_finish(int S, int K, int M, int Kp, const sp_star *stars, const double *meanvar,
                            const double *condmean, int order, double zmax, const double *part,
                            const double *diag, double *sys, void *coef, uint32_t *status,
@@ -334,10 +338,10 @@ int lnlike_assemble(sp_handle *h, const Layout &L, void *ws, int K, int M, const
   int32_t *info = at<int32_t>(ws, L.info);
   uint32_t *status = at<uint32_t>(ws, L.status);
   int rc;
-  // (tiles formed at first touch: the stars' tables packed for the gathers, in the design-matrix
-  //  region the marginal path does not use)
-  if ((rc = sp_launch_theta(S, K, t_dev, stars_dev, theta, st, info, status, tab_dev, covpts,
-                            lazy_nfull > 0 ? at<double>(ws, L.A) : nullptr)))
+  // (the stars' tables packed for the spline gathers of the assembly and of the tiles formed at first
+  //  touch, in the design-matrix region the marginal path does not use)
+  double *ptab = (conditional || 4 * (size_t)(covpts + 4) > (size_t)L.Kr * L.N) ? nullptr : at<double>(ws, L.A);
+  if ((rc = sp_launch_theta(S, K, t_dev, stars_dev, theta, st, info, status, tab_dev, covpts, ptab)))
     return rc;
   const double *rawp = nullptr;
   const double *condmean = nullptr;
@@ -380,10 +384,14 @@ int lnlike_assemble(sp_handle *h, const Layout &L, void *ws, int K, int M, const
     // deferred normalisation: ONE pass over the K^2 entries (raw tiles + their row / column sums),
     // then the normalisation's vectors as three more rows of the system (sp_assemble.hip)
     double *part = at<double>(ws, L.part);
-    if ((rc = sp_launch_assemble(S, K, M, L.Kp, 1, theta, t_dev, stars_dev, cp, tab_dev, meanvar_dev,
-                                 h->d_xp, temporal, rawp, 1, qv, coef, diag_dev, 1, flux_dev, sys,
-                                 L.Kp, (long)L.Kp * L.Kp, st, part, lazy_nfull)))
-      return rc;
+    if (!rawp && ptab)
+      rc = sp_launch_assemble_sums(S, K, M, L.Kp, theta, t_dev, stars_dev, cp, ptab, meanvar_dev, temporal,
+                                   flux_dev, sys, st, part, lazy_nfull);
+    else
+      rc = sp_launch_assemble(S, K, M, L.Kp, 1, theta, t_dev, stars_dev, cp, tab_dev, meanvar_dev,
+                              h->d_xp, temporal, rawp, 1, qv, coef, diag_dev, 1, flux_dev, sys,
+                              L.Kp, (long)L.Kp * L.Kp, st, part, lazy_nfull);
+    if (rc) return rc;
     return sp_launch_defer_finish(S, K, M, L.Kp, stars_dev, meanvar_dev, condmean, norm_order, zmax,
                                   part, diag_dev, sys, coef, status, rowsum, st);
   }

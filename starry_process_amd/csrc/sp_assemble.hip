@@ -332,6 +332,146 @@ __global__ __launch_bounds__(256) void assemble_kernel(
   }
 }
 
+// The hot form of the assembly -- marginal branch, deferred normalisation (what assemble_kernel<false, true,
+// true> did until round 4): the RAW lower tiles of the padded system and their row / column sums, one 64 x 64
+// tile per workgroup.  Differences from the general kernel, all of them about latency (the kernel issues a
+// third of the instructions its duration has room for):
+//   * the star's table arrives packed (theta_kernel) and every load of the prologue -- table, phases, times --
+//     is in flight before the first wait (the general kernel's transposing copy loop waits out five memory round
+//     trips in a row);
+//   * the 16 entries of a thread are evaluated as ONE batch (SplineGen::many): index computations, gathers
+//     and Horner chains of different entries overlap;
+//   * the temporal kernel is a template parameter: no run-time switch (and no inlined exp) between entries.
+// Same operations per entry as the general kernel and as the tiles formed at first touch: same bits.
+#ifndef SP_ASM_EXPERIMENT
+#define SP_ASM_EXPERIMENT 0
+#endif
+#ifndef SP_ASM_BATCH
+#define SP_ASM_BATCH 16      // entries per SplineGen::many batch (4, 8 or 16)
+#endif
+template <int TK>
+__global__ __launch_bounds__(256) void assemble_sums_kernel(
+    int K, int M, int Kp, const double *__restrict__ theta, const double *__restrict__ t,
+    const sp_star *__restrict__ stars, int covpts, const double *__restrict__ ptab,
+    const double *__restrict__ meanvar, const double *__restrict__ flux, double *__restrict__ out, long ldo,
+    long strideo, int ntr, double *__restrict__ part, int lazy_nfull) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int s = blockIdx.y, np = covpts + 4, tid = threadIdx.x;
+  const sp_star st = stars[s];
+  const int tile = blockIdx.x;
+  int ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+  while (ti * (ti + 1) / 2 > tile) --ti;
+  while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+  const int tj = tile - ti * (ti + 1) / 2;
+  const int i0 = ti * 64, j0 = tj * 64;
+  double *s_tab = lds;                       // 4 np
+  double *s_th = s_tab + 4 * np;             // phases: rows 0 .. 63, columns 64 .. 127
+  double *s_t = s_th + 128;                  // times, the same (TK != 0)
+  double *s_col = s_t + 128;                 // [16][64] column-sum partials
+  const int nobs = star_nobs(st, K);
+  {
+    // thread l < 128: the phase (and time) of row i0 + l or column j0 + l - 64
+    const int idx = tid < 64 ? i0 + tid : j0 + tid - 64;
+    const bool ok = tid < 128 && idx < K;
+    const double th = ok ? theta[(size_t)s * K + idx] : 0.0;
+    const double tt = (TK != SP_TEMPORAL_NONE && ok) ? t[(size_t)s * K + idx] : 0.0;
+    spline_table_to_lds(ptab + (size_t)s * 4 * np, s_tab, np, tid);
+    if (tid < 128) {
+      s_th[tid] = th;
+      if (TK != SP_TEMPORAL_NONE) s_t[tid] = tt;
+    }
+  }
+  __syncthreads();
+  SplineGen g{s_tab, 2 * np, 6.283185307179586 / covpts, 1.0 / (6.283185307179586 / covpts), covpts};
+  double *ob = out + (size_t)s * strideo;
+  // thread -> columns cl, cl + 16, cl + 32, cl + 48 of rows ri, ri + 16, ri + 32, ri + 48 (the 16 lanes of a row
+  // look up ADJACENT columns: neighbouring table segments on distinct bank groups)
+  const int cl = tid & 15, ri = tid >> 4;
+  double v[16];
+#pragma unroll
+  for (int p0 = 0; p0 < 4; p0 += SP_ASM_BATCH / 4) {
+    double a[SP_ASM_BATCH], b[SP_ASM_BATCH], o[SP_ASM_BATCH];
+#pragma unroll
+    for (int k = 0; k < SP_ASM_BATCH; ++k) {
+      a[k] = s_th[ri + 16 * (p0 + (k >> 2))];
+      b[k] = s_th[64 + cl + 16 * (k & 3)];
+    }
+#if SP_ASM_EXPERIMENT == 2
+    for (int k = 0; k < SP_ASM_BATCH; ++k) o[k] = a[k] - b[k];   // (experiment: no spline evaluation)
+#else
+    g.many<SP_ASM_BATCH>(a, b, o);
+#endif
+#pragma unroll
+    for (int k = 0; k < SP_ASM_BATCH; ++k) v[4 * p0 + k] = o[k];
+  }
+  if (nobs == 1) {
+    const double var1 = meanvar[2 * st.table + 1];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = var1;
+  }
+  if (TK != SP_TEMPORAL_NONE) {
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma clang fp contract(off)
+        v[4 * pass + e] *= temporal_factor(TK, s_t[ri + 16 * pass], s_t[64 + cl + 16 * e], st.tau);
+      }
+  }
+  double csum[4] = {0.0, 0.0, 0.0, 0.0};
+  // (tiles the factorisation forms itself at first touch: sums taken, nothing written -- not the first block
+  //  column: its panel launch has no product to form the tile behind)
+  const bool skip_write = ti > tj && tj > 0 && ti < lazy_nfull;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int li = ri + 16 * pass, i = i0 + li;
+    double w[4];
+    double rsum = 0.0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = j0 + cl + 16 * e;
+      double val = 0.0;
+      if (i < nobs && j < nobs) {
+        val = v[4 * pass + e];
+        rsum += val;
+        csum[e] += val;
+      } else if (i >= K && i < K + M && j < nobs) {
+        val = flux[((size_t)s * M + (i - K)) * K + j] - st.baseline_mean;   // (the GP mean of the normalised process is 0)
+      } else if (i == j) {
+        val = 1.0;
+      }
+      w[e] = val;
+    }
+    // row sum of this tile's 64 columns: the 16 lanes that share the row
+    rsum += __shfl_xor(rsum, 8, 16);
+    rsum += __shfl_xor(rsum, 4, 16);
+    rsum += __shfl_xor(rsum, 2, 16);
+    rsum += __shfl_xor(rsum, 1, 16);
+    if (cl == 0 && i < K) part[((size_t)s * ntr + tj) * K + i] = rsum;
+#if SP_ASM_EXPERIMENT == 1
+    continue;     // (experiment: no tile is written)
+#endif
+    if (i >= Kp || skip_write) continue;
+    double *dst = ob + (size_t)i * ldo + j0 + cl;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (j0 + cl + 16 * e < Kp) dst[16 * e] = w[e];
+  }
+  if (ti > tj) {
+    // column sums = row sums of the mirror tile (tj, ti), which is never formed
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s_col[ri * 64 + cl + 16 * e] = csum[e];
+    __syncthreads();
+    if (tid < 64) {
+      double a = 0.0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a += s_col[r * 64 + tid];
+      const int j = j0 + tid;
+      if (j < K) part[((size_t)s * ntr + ti) * K + j] = a;
+    }
+  }
+}
+
 // Deferred normalisation, second half: one workgroup per star.
 //   rowsum_r = sum over the column tiles of part[s][c][r]            (fixed order: deterministic)
 //   m, z, alpha(z), beta(z), c1 = alpha / mu^2                       (sp.py:705-727, ops/norm/norm.py:26-44)
@@ -513,6 +653,30 @@ int sp_launch_assemble(int S, int K, int M, int Kp, int system,
   else
     SP_ASM(false, false);
 #undef SP_ASM
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}
+
+int sp_launch_assemble_sums(int S, int K, int M, int Kp, const double *theta, const double *t,
+                            const sp_star *stars, int covpts, const double *ptab, const double *meanvar,
+                            int temporal, const double *flux, double *sys, hipStream_t st, double *part,
+                            int lazy_nfull) {
+  const int np = covpts + 4;
+  const size_t lds = sizeof(double) * (4 * (size_t)np + 256 + 16 * 64);
+  if (lds > attr_lds_limit || !ptab || !part) return SP_ERR_INVALID;
+  const int ntr = Kp / 64;
+  dim3 grid(ntr * (ntr + 1) / 2, S);
+#define SP_ASMS(TK)                                                                                     \
+  do {                                                                                                  \
+    allow_big_lds(assemble_sums_kernel<TK>);                                                            \
+    hipLaunchKernelGGL((assemble_sums_kernel<TK>), grid, dim3(256), lds, st, K, M, Kp, theta, t, stars, \
+                       covpts, ptab, meanvar, flux, sys, (long)Kp, (long)Kp * Kp, ntr, part, lazy_nfull); \
+  } while (0)
+  if (temporal == SP_TEMPORAL_NONE) SP_ASMS(SP_TEMPORAL_NONE);
+  else if (temporal == SP_TEMPORAL_MATERN32) SP_ASMS(SP_TEMPORAL_MATERN32);
+  else if (temporal == SP_TEMPORAL_EXPSQUARED) SP_ASMS(SP_TEMPORAL_EXPSQUARED);
+  else return SP_ERR_INVALID;
+#undef SP_ASMS
   SP_LAUNCH_CHECK();
   return SP_OK;
 }

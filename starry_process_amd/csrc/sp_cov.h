@@ -67,8 +67,68 @@ struct SplineGen {
     // to agree to rounding: fused multiply-adds)
     return __builtin_fma(x0, __builtin_fma(x0, __builtin_fma(x0, c23.y, c23.x), c01.y), c01.x);
   }
+  // N entries at once: entry e is operator()(thi[e], thj[e]), the same operations on the same operands
+  // -- the same bits --, but the N index computations, the 2 N gathers and the N Horner chains are
+  // straight-line code on either side of ONE rarely taken branch (some entry's quotient within 1e-9 of
+  // an integer: the diagonal, x = 0, and little else), so that they overlap.  One entry at a time each
+  // evaluation was a dependent chain of ~15 fp64 operations and two LDS round trips behind a branch of
+  // its own, which nothing but other wavefronts could hide (round 4; the assembly ran at 0.65
+  // evaluations per ns, a third of what its instruction count allows).
+  template <int N>
+  __device__ __forceinline__ void many(const double (&thi)[N], const double (&thj)[N], double (&out)[N]) const {
+#pragma clang fp contract(off)
+    double x0[N];
+    int idx[N];
+    bool odd = false;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      const double q = fabs(thi[e] - thj[e]) * inv_dx;
+      idx[e] = (int)q;
+      x0[e] = q - (double)idx[e];
+      odd |= fabs(x0[e] - 0.5) > 0.5 - 1.0e-9;
+    }
+    if (__builtin_expect(odd, 0)) {
+#pragma unroll
+      for (int e = 0; e < N; ++e)
+        if (fabs(x0[e] - 0.5) > 0.5 - 1.0e-9) {
+          const double x = fabs(thi[e] - thj[e]);
+          idx[e] = (int)floor(x / dx);
+          x0[e] = x * inv_dx - (double)idx[e];
+        }
+    }
+    dd2 c01[N], c23[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      const int k = idx[e] < 0 ? 0 : (idx[e] > covpts ? covpts : idx[e]);
+      c01[e] = *reinterpret_cast<const dd2 *>(tab + 2 * k);
+      c23[e] = *reinterpret_cast<const dd2 *>(tab + np2 + 2 * k);
+    }
+#pragma unroll
+    for (int e = 0; e < N; ++e)
+      out[e] = __builtin_fma(x0[e], __builtin_fma(x0[e], __builtin_fma(x0[e], c23[e].y, c23[e].x), c01[e].y), c01[e].x);
+  }
 };
 
+
+// the star's packed table (theta_kernel: [np][2] = {a0, a1}, then [np][2] = {a2, a3}) into LDS, all 256 threads:
+// every load is issued before the first store (a plain copy loop waits out one memory round trip per
+// iteration -- the compiler keeps load, wait, store together)
+__device__ __forceinline__ void spline_table_to_lds(const double *__restrict__ src, double *stage, int np, int tid) {
+  const int n2 = 2 * np;                       // 16-byte entries
+  dd2 v[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int e = tid + 256 * c;
+    v[c] = e < n2 ? *reinterpret_cast<const dd2 *>(src + 2 * e) : dd2{0.0, 0.0};
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int e = tid + 256 * c;
+    if (e < n2) *reinterpret_cast<dd2 *>(stage + 2 * e) = v[c];
+  }
+  for (int e = tid + 1024; e < n2; e += 256)   // (covpts > 508: not a BASELINE configuration)
+    *reinterpret_cast<dd2 *>(stage + 2 * e) = *reinterpret_cast<const dd2 *>(src + 2 * e);
+}
 
 // ---- tiles formed at first touch ---------------------------------------------------------------
 // In the deferred-normalisation marginal path a tile of the system strictly below the diagonal whose
@@ -86,6 +146,9 @@ struct SplineGen {
 // star's packed table is copied there first (one memory round trip, in parallel with the phases';
 // gathering the coefficients from memory instead made the entries wait for two round trips in a
 // row: +3 us per tile).  All 256 threads call this together; two barriers inside.
+#ifndef SP_LAZY_BATCH
+#define SP_LAZY_BATCH 8
+#endif
 template <typename V4>
 __device__ __forceinline__ void lazy_cov_tile(const LazyCov &z, int star, const int (&ri)[4],
                                               const int (&cj)[4], V4 (&out)[4], double *stage) {
@@ -102,25 +165,31 @@ __device__ __forceinline__ void lazy_cov_tile(const LazyCov &z, int star, const 
     ti[k] = (oi && tk) ? tt[ri[k]] : 0.0;
     tj[k] = (oj && tk) ? tt[cj[k]] : 0.0;
   }
-  {
-    const double *src = z.ptab + (size_t)star * 4 * np;
-    for (int e = 2 * threadIdx.x; e < 4 * np; e += 512)
-      *reinterpret_cast<dd2 *>(stage + e) = *reinterpret_cast<const dd2 *>(src + e);
-  }
+  spline_table_to_lds(z.ptab + (size_t)star * 4 * np, stage, np, threadIdx.x);
   __syncthreads();
   SplineGen g{stage, 2 * np, 6.283185307179586 / z.covpts,
               1.0 / (6.283185307179586 / z.covpts), z.covpts};
+  // (eight entries per batch: sixteen take the trailing update from 163 registers -- three workgroups per CU -- to 204)
 #pragma unroll
-  for (int n = 0; n < 4; ++n)
+  for (int n0 = 0; n0 < 4; n0 += SP_LAZY_BATCH / 4) {
+    double a[SP_LAZY_BATCH], b[SP_LAZY_BATCH], v[SP_LAZY_BATCH];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      double v = 0.0;
+    for (int e = 0; e < SP_LAZY_BATCH; ++e) {
+      a[e] = thi[e & 3];
+      b[e] = thj[n0 + (e >> 2)];
+    }
+    g.many<SP_LAZY_BATCH>(a, b, v);
+#pragma unroll
+    for (int e = 0; e < SP_LAZY_BATCH; ++e) {
+      const int n = n0 + (e >> 2), r = e & 3;
+      double w = 0.0;
       if (ri[r] < nobs && cj[n] < nobs) {
 #pragma clang fp contract(off)
-        v = g(thi[r], thj[n]) * temporal_factor(z.temporal, ti[r], tj[n], st.tau);
+        w = v[e] * temporal_factor(z.temporal, ti[r], tj[n], st.tau);
       }
-      out[n][r] = v;
+      out[n][r] = w;
     }
+  }
   __syncthreads();   // the scratch goes back to its owner
 }
 
@@ -129,6 +198,11 @@ __device__ __forceinline__ void lazy_cov_tile(const LazyCov &z, int star, const 
 // c0 + 16 m + r).  No temporal kernel here: tiles are only left to their first touch without one
 // (sp_lnlike_ensemble; the exp per entry, evaluated twice, costs more than the traffic saves), and
 // sixteen inlined copies of exp() would be dead code in the panel kernel.
+#ifndef SP_LAZY_ROW_BATCH
+#define SP_LAZY_ROW_BATCH 0    // entries per SplineGen::many batch in the panel kernel; 0: one at a time -- batches of
+                               // four cost the lazy instantiations 26 (layout) to 180 (pairs) spilled registers
+                               // of their 168: 0.871 against 0.855 ms per step, 104.0k against 106.9k in flight
+#endif
 template <typename V4>
 __device__ __forceinline__ void lazy_cov_row(const LazyCov &z, int star, int ri, int c0, V4 (&out)[4],
                                              double *stage, int tid) {
@@ -138,6 +212,7 @@ __device__ __forceinline__ void lazy_cov_row(const LazyCov &z, int star, int ri,
   const bool oi = ri < nobs;
   const double thi = oi ? th[ri] : 0.0;
   {
+    // (a plain copy loop here: the unrolled form's 16 registers in flight spill the panel kernel's budget)
     const double *src = z.ptab + (size_t)star * 4 * np;
     for (int e = 2 * tid; e < 4 * np; e += 512)
       *reinterpret_cast<dd2 *>(stage + e) = *reinterpret_cast<const dd2 *>(src + e);
@@ -146,6 +221,7 @@ __device__ __forceinline__ void lazy_cov_row(const LazyCov &z, int star, int ri,
   SplineGen g{stage, 2 * np, 6.283185307179586 / z.covpts,
               1.0 / (6.283185307179586 / z.covpts), z.covpts};
   // (unrolled -- a run-time index into the caller's accumulators would send them to scratch memory)
+#if SP_LAZY_ROW_BATCH == 0
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     double thj[4];
@@ -159,6 +235,26 @@ __device__ __forceinline__ void lazy_cov_row(const LazyCov &z, int star, int ri,
     for (int r = 0; r < 4; ++r) o[r] = (oi && c0 + 16 * m + r < nobs) ? g(thi, thj[r]) : 0.0;
     out[m] = o;
   }
+#else
+#pragma unroll
+  for (int m0 = 0; m0 < 4; m0 += SP_LAZY_ROW_BATCH / 4) {
+    double a[SP_LAZY_ROW_BATCH], b[SP_LAZY_ROW_BATCH], v[SP_LAZY_ROW_BATCH];
+#pragma unroll
+    for (int e = 0; e < SP_LAZY_ROW_BATCH; ++e) {
+      const int c = c0 + 16 * (m0 + (e >> 2)) + (e & 3);
+      a[e] = thi;
+      b[e] = c < nobs ? th[c] : 0.0;
+    }
+    g.many<SP_LAZY_ROW_BATCH>(a, b, v);
+#pragma unroll
+    for (int h = 0; h < SP_LAZY_ROW_BATCH / 4; ++h) {
+      V4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (oi && c0 + 16 * (m0 + h) + r < nobs) ? v[4 * h + r] : 0.0;
+      out[m0 + h] = o;
+    }
+  }
+#endif
   __syncthreads();   // the scratch goes back to its owner
 }
 

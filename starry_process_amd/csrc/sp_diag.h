@@ -299,11 +299,17 @@ __device__ __forceinline__ void inverse_block_row(double *sD, const double *sRd,
 // wavefronts that saw a non-positive pivot (callers OR it through global memory).
 __device__ __forceinline__ int diag_block(double *sD, double *sRd, int tid_in = threadIdx.x,
                                           long long *dbg = nullptr) {
-  const int tid = tid_in, lane = tid & 63, wave = tid >> 6;
   const bool inv = true;
   int notpd = 0;
 #pragma unroll 1
   for (int kb = 0; kb < 4; ++kb) {
+    // (a laundered copy of the thread index per block column: the lane-derived predicates of the leaf, the
+    //  substitution and the inverse -- (i == C), (k > i), ... some 60 of them -- are loop invariants, and hoisted
+    //  out of this loop they are 120 scalar registers held across it: 100 of them spilled to vector lanes and
+    //  reloaded inside the loops of the critical chain.  Recomputing a compare costs one instruction.)
+    int tid = tid_in;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
     if (wave == kb) {
       long long ts[5];
       notpd |= factor_panel(sD, sRd, sRd + 64, kb, lane, dbg ? ts : nullptr);
@@ -351,7 +357,12 @@ __device__ __forceinline__ int diag_block(double *sD, double *sRd, int tid_in = 
     if (dbg && wave == (kb < 3 ? kb + 1 : 3) && lane == 0) dbg[8 * kb + 6] = clock64();
   }
   // the last block row of the inverse (nothing left to hide it behind)
-  inverse_block_row(sD, sRd, 3, wave == 3, wave < 3 ? wave : -1, lane);
+  {
+    int tid = tid_in;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    inverse_block_row(sD, sRd, 3, wave == 3, wave < 3 ? wave : -1, lane);
+  }
   __syncthreads();
   return notpd;
 }

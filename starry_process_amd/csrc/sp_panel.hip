@@ -150,7 +150,12 @@ __host__ __device__ __forceinline__ int panel_titems(int ntile, int j, int pair)
 // ---- T item: NR row tiles (64 NR rows) from row tile i0 -----------------------------------------
 // cb: column block of the tiles (the launch's pivot block j; j + 1 for the look-ahead item); the product
 // runs over the column blocks kb0 .. kb1 - 1; la: look-ahead item -- the tile goes back updated, unsolved
-template <int NR>
+// LAZY: the launch may form tiles at first touch (first super-panel of a marginal system, sp_cov.h);
+// RED: the tail that factors the last pivot block reduces its star (sp_reduce.h) -- compile-time, so that an
+// instantiation carries only the state of what its launches contain
+// CHAIN: the call site may be handed the launch's first item (row tile j + 1), which goes on to factor the next
+// pivot block (P_TAILD): only those copies carry the diagonal block's code
+template <int NR, bool LAZY, bool RED, bool CHAIN>
 __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, int mtx, int i0, int cb,
                                                 int kb0, int kb1, bool la, bool may_lazy,
                                                 double *img_star, double *smem, int tid) {
@@ -158,7 +163,7 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
   const long ld = a.ld;
   const int Kd = 64 * (kb1 - kb0);
   const double *img = img_star + sp_img_off(a.j);
-  const bool chain = NR == 1 && !la && i0 == a.j + 1 && (a.mode & P_TAILD);   // this item factors the next block
+  const bool chain = CHAIN && NR == 1 && !la && i0 == a.j + 1 && (a.mode & P_TAILD);   // this item factors the next block
 #ifdef SP_PANEL_TRACE
   const int role = i0 == a.j + 1 ? 1 : (i0 + NR == a.ntile ? 2 : -1);
 #endif
@@ -184,7 +189,7 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
   // (tiles evaluated at first touch: the first operand slices are requested after the evaluation --
   //  48 registers of loads in flight across it made the compiler spill the spline's constants and
   //  reload them for every entry)
-  const bool any_lazy = may_lazy && a.lz.theta && cb > 0 && i0 < a.lz.nfull;
+  const bool any_lazy = LAZY && may_lazy && a.lz.theta && cb > 0 && i0 < a.lz.nfull;
   auto first_loads = [&]() {
 #pragma unroll
     for (int h = 0; h < NR; ++h) stage_load_fast<PK>(Ab, ld, 64 * h, 0, ra[h], tid);
@@ -195,7 +200,7 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
   for (int h = 0; h < NR; ++h) {
     // (first super-panel of a system whose assembly left the tile to its first touch, sp_cov.h:
     //  evaluated while the first operand slices are on their way)
-    const bool lazy = may_lazy && a.lz.theta && cb > 0 && i0 + h < a.lz.nfull;
+    const bool lazy = LAZY && may_lazy && a.lz.theta && cb > 0 && i0 + h < a.lz.nfull;
     if (!lazy) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
@@ -388,13 +393,13 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
         }
     }
     P2_STAMP(role, 6);
-    if (NR == 1 && (a.mode & P_TAILD) && i == a.j + 1 && a.next_nact > 0) {
+    if (CHAIN && NR == 1 && (a.mode & P_TAILD) && i == a.j + 1 && a.next_nact > 0) {
       // the next pivot block, complete now and still in registers: factored here, in the shadow of
       // the launch's other items (its image goes to the other slot: this launch still reads its own)
       __syncthreads();
       double *sD = smem;
       const int nact = a.next_nact;
-      const int nlive = a.red.live_rows > 0 ? a.red.live_rows - 64 * (a.j + 1) : 64;
+      const int nlive = (RED && a.red.live_rows > 0) ? a.red.live_rows - 64 * (a.j + 1) : 64;
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -416,7 +421,7 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
       panel_diag_core(Dt, ld, nact, img_star + sp_img_off(a.j + 1),
                       a.info ? a.info + mtx : nullptr, smem, tid, nullptr, nlive);
 #endif
-      if (a.red.lnlike) {
+      if (RED && a.red.lnlike) {
         // the last pivot block of the system: everything the reduction reads is final (the earlier
         // columns by earlier launches, the last ones by this workgroup just now)
         // (same workgroup, same CU: the barrier's workgroup-scope ordering is all the visibility it takes -- an
@@ -459,6 +464,14 @@ __device__ __forceinline__ unsigned long long *chain_words(double *img_star) {
   return reinterpret_cast<unsigned long long *>(img_star + SP_IMG_WORDS);   // [0] seq << 32 | CU key, [1] seq when done
 }
 
+// One instantiation per kind of launch (round 4; round 3's single kernel carried every role behind run-time
+// flags: 363 spilled SGPRs, the reloads in the diagonal block's loops -- on the critical chain):
+//   PK_D      D items only (pivot block 0)
+//   PK_LAY    the chain-aware layout: T items of 64 rows, the chain's tail, sleepers, look-ahead items
+//   PK_PLAIN  T items dealt by workgroup index, 128-row pairs where the launcher asks for them
+enum { PK_D = 0, PK_LAY = 1, PK_PLAIN = 2 };
+
+template <int KIND, bool LAZY, bool RED>
 __global__ __launch_bounds__(256, P_WGS) void panel_kernel(PanelArgs a) {
   __shared__ __attribute__((aligned(16))) double smem[P_LDS];
   const int tid = threadIdx.x;
@@ -466,7 +479,7 @@ __global__ __launch_bounds__(256, P_WGS) void panel_kernel(PanelArgs a) {
   if (tid == 0 && a.j < 16 && blockIdx.x < 1024 && (a.mode & P_TITEMS)) g_p2cu[a.j * 1024 + blockIdx.x] = (int)cu_key() + 1;
   P2WgStamp wg_stamp(a.j, (a.mode & P_TITEMS) != 0);
 #endif
-  if (a.lay) {
+  if constexpr (KIND == PK_LAY) {
     const int x = blockIdx.x & 7, k = blockIdx.x >> 3, spx = a.S >> 3;
     const int c = k & 31, rnd = k >> 5, nb = 32 - spx;
     const int nsingle = a.ntile - a.j - 2;                      // row tiles below the chain's: one item each
@@ -485,8 +498,8 @@ __global__ __launch_bounds__(256, P_WGS) void panel_kernel(PanelArgs a) {
           __hip_atomic_store(F, ((unsigned long long)(unsigned)a.seq << 32) | (unsigned long long)cu_key(),
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool fla = a.mode & P_FIRSTLA;
-        panel_tile_item<1>(a, a.sys + (size_t)mtx * a.stride, mtx, a.j + 1, a.j, fla ? a.j - 1 : a.s0, a.j, false,
-                           !fla, img_star, smem, tid);
+        panel_tile_item<1, LAZY, RED, true>(a, a.sys + (size_t)mtx * a.stride, mtx, a.j + 1, a.j, fla ? a.j - 1 : a.s0,
+                                            a.j, false, !fla, img_star, smem, tid);
         if (tid == 0) __hip_atomic_store(F + 1, (unsigned long long)(unsigned)a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
       }
@@ -516,20 +529,21 @@ __global__ __launch_bounds__(256, P_WGS) void panel_kernel(PanelArgs a) {
     const int mtx = x * spx + sl;
     double *M = a.sys + (size_t)mtx * a.stride;
     double *img_star = a.img + (size_t)mtx * a.lts;
-    if (idx < nsingle)
-      panel_tile_item<1>(a, M, mtx, a.j + 2 + idx, a.j, a.s0, a.j, false, true, img_star, smem, tid);
-    else
-      panel_tile_item<1>(a, M, mtx, a.j + 2, a.j + 1, a.s0, a.j, true, true, img_star, smem, tid);
+    // (one call site for the launch's other items: what differs between a row tile's item and the look-ahead
+    //  item is data -- three inlined copies of the item cost the instantiation its registers)
+    const bool la = idx >= nsingle;
+    panel_tile_item<1, LAZY, false, false>(a, M, mtx, la ? a.j + 2 : a.j + 2 + idx, la ? a.j + 1 : a.j, a.s0, a.j, la,
+                                           true, img_star, smem, tid);
     return;
   }
-  const int nd = (a.mode & P_DITEMS) ? 1 : 0;                                      // D items per star
-  const int nt = (a.mode & P_TITEMS) ? panel_titems(a.ntile, a.j, a.pair) : 0;   // T items per star
-  const int nl = (a.mode & P_LOOKAHEAD) ? 1 : 0;                                   // look-ahead items per star
+  constexpr int nd = KIND == PK_D ? 1 : 0;                                         // D items per star
+  const int nt = KIND == PK_D ? 0 : panel_titems(a.ntile, a.j, a.pair);          // T items per star
+  const int nl = (KIND != PK_D && (a.mode & P_LOOKAHEAD)) ? 1 : 0;                 // look-ahead items per star
   int mtx, strip;
   if (!sp_xcd_decode(blockIdx.x, a.S, nd + nt + nl, mtx, strip)) return;
   double *M = a.sys + (size_t)mtx * a.stride;
   double *img_star = a.img + (size_t)mtx * a.lts;
-  if (strip < nd) {
+  if constexpr (KIND == PK_D) {
     P2_STAMP(0, 0);
     double *img = img_star + sp_img_off(a.j);
 #ifdef SP_PANEL_TRACE
@@ -539,22 +553,25 @@ __global__ __launch_bounds__(256, P_WGS) void panel_kernel(PanelArgs a) {
     panel_diag_item(M, a.ld, a.j, a.nact, img, a.info ? a.info + mtx : nullptr, smem, tid);
 #endif
     P2_STAMP(0, 2);
-  } else if (strip < nd + nt) {
+  } else if (strip < nt) {
     // T item t: row tile j + 1 + t; with pairs: 0 = row tile j + 1 alone (it is on the critical path),
     // t >= 1 = row tiles j + 2 t, j + 2 t + 1 (the last one may be single)
-    const int t = strip - nd;
+    const int t = strip;
     const int i0 = a.pair ? (t == 0 ? a.j + 1 : a.j + 2 * t) : a.j + 1 + t;
     // (the first tile after a look-ahead: all but the last column block of its product is in it already)
     const bool fla = t == 0 && (a.mode & P_FIRSTLA);
 #if P_PAIRS
     if (a.pair && t > 0 && i0 + 1 < a.ntile)
-      panel_tile_item<2>(a, M, mtx, i0, a.j, a.s0, a.j, false, true, img_star, smem, tid);
+      panel_tile_item<2, LAZY, false, false>(a, M, mtx, i0, a.j, a.s0, a.j, false, true, img_star, smem, tid);
     else
 #endif
-      panel_tile_item<1>(a, M, mtx, i0, a.j, fla ? a.j - 1 : a.s0, a.j, false, !fla, img_star, smem, tid);
+    if (t == 0)
+      panel_tile_item<1, LAZY, RED, true>(a, M, mtx, i0, a.j, fla ? a.j - 1 : a.s0, a.j, false, !fla, img_star, smem, tid);
+    else
+      panel_tile_item<1, LAZY, false, false>(a, M, mtx, i0, a.j, a.s0, a.j, false, true, img_star, smem, tid);
   } else {
     // look-ahead: tile (j + 2, j + 1) with the column blocks s0 .. j - 1
-    panel_tile_item<1>(a, M, mtx, a.j + 2, a.j + 1, a.s0, a.j, true, true, img_star, smem, tid);
+    panel_tile_item<1, LAZY, false, false>(a, M, mtx, a.j + 2, a.j + 1, a.s0, a.j, true, true, img_star, smem, tid);
   }
 }
 
@@ -614,7 +631,21 @@ int sp_launch_panel2(int layout, const SpReduceArgs *red, double *sys, long ld, 
     }
   }
   if (nblk > 0x7fffffffL) return SP_ERR_INVALID;
-  hipLaunchKernelGGL(panel_kernel, dim3((unsigned)nblk), dim3(256), 0, st, a);
+  const bool lz = a.lz.theta != nullptr, rd = a.red.lnlike != nullptr;
+#define SP_PANEL_GO(KIND)                                                                                    \
+  do {                                                                                                       \
+    if (lz && rd) hipLaunchKernelGGL((panel_kernel<KIND, true, true>), dim3((unsigned)nblk), dim3(256), 0, st, a);        \
+    else if (lz) hipLaunchKernelGGL((panel_kernel<KIND, true, false>), dim3((unsigned)nblk), dim3(256), 0, st, a);        \
+    else if (rd) hipLaunchKernelGGL((panel_kernel<KIND, false, true>), dim3((unsigned)nblk), dim3(256), 0, st, a);        \
+    else hipLaunchKernelGGL((panel_kernel<KIND, false, false>), dim3((unsigned)nblk), dim3(256), 0, st, a);               \
+  } while (0)
+  if (a.mode & P_DITEMS)
+    hipLaunchKernelGGL((panel_kernel<PK_D, false, false>), dim3((unsigned)nblk), dim3(256), 0, st, a);
+  else if (a.lay)
+    SP_PANEL_GO(PK_LAY);
+  else
+    SP_PANEL_GO(PK_PLAIN);
+#undef SP_PANEL_GO
   SP_LAUNCH_CHECK();
   return SP_OK;
 }

@@ -217,7 +217,7 @@ def test_likelihood_over_the_prior_box(branch):
 # (what the reference's rounding noise in the l >= 9 rows of Sigma_y -- up to 1e-2 of max|Sigma_y| at the
 #  corners of the box, tests/test_upstream_grid.py -- moves its own log-likelihood by; at the three
 #  hyperparameter sets with an extended-precision arbiter the device moments are the accurate ones)
-LNLIKE_BOX_TOL = 2e-4
+LNLIKE_BOX_TOL = 5e-5     # measured: 1.6e-5 (marginal, normalised), 1.3e-6 (conditional)
 
 
 def test_ensemble_log_prob_is_finite_at_high_b():
@@ -236,9 +236,18 @@ def test_ensemble_log_prob_is_finite_at_high_b():
                         [20.0, 0.5, 0.74, 0.10, 10.0], [20.0, 1.0, 0.0, 0.10, 10.0], [20.0, 0.0, 0.0, 0.10, 10.0]])
     with warnings.catch_warnings():
         warnings.simplefilter("error")
-        one = get_log_prob_ensemble(t, flux, ferr=1e-3, p=p, upstream="device")
-        many = EnsembleLogProb(t, flux, ferr=1e-3, p=p, depth=3)
+        # (without the Jacobian of (a, b) -> (mu, sigma): latitude.py:281-316 is NaN / -inf ON the box's edges
+        #  a = 1 / b = 0, in the reference too -- the likelihood itself is what must be finite there)
+        one = get_log_prob_ensemble(t, flux, ferr=1e-3, p=p, upstream="device", apply_jac=False)
+        many = EnsembleLogProb(t, flux, ferr=1e-3, p=p, depth=3, apply_jac=False)
         ref = np.array([one(*s) for s in samples])
         got = many(samples)
+        assert np.all(np.isfinite(got)) and np.all(np.isfinite(ref)), (got, ref)
+        assert np.abs(got - ref).max() < 1e-8 * np.abs(ref).max()
+        # ... and with it inside the box
+        one = get_log_prob_ensemble(t, flux, ferr=1e-3, p=p, upstream="device")
+        many = EnsembleLogProb(t, flux, ferr=1e-3, p=p, depth=3)
+        ref = np.array([one(*s) for s in samples[:4]])
+        got = many(samples[:4])
     assert np.all(np.isfinite(got)) and np.all(np.isfinite(ref))
     assert np.abs(got - ref).max() < 1e-8 * np.abs(ref).max()
