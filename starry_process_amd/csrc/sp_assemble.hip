@@ -15,6 +15,8 @@
 //
 // Compiled with -ffp-contract=off: the int64 interpolation index
 // floor(x / dx) must agree bit for bit with the reference (flux.py:262-265).
+#include <cstdlib>
+
 #include "sp_internal.h"
 #include "sp_cov.h"
 
@@ -302,10 +304,11 @@ __global__ __launch_bounds__(256) void assemble_kernel(
     }
     if (DEFER) {
       // row sum of this tile's 64 columns: the 16 lanes that share the row
-      rsum += __shfl_xor(rsum, 8, 16);
-      rsum += __shfl_xor(rsum, 4, 16);
-      rsum += __shfl_xor(rsum, 2, 16);
-      rsum += __shfl_xor(rsum, 1, 16);
+      {
+        double one[1] = {rsum};
+        row16_sum(one);
+        rsum = one[0];
+      }
       if ((threadIdx.x & 15) == 0 && i < K) part[((size_t)s * ntr + tj) * K + i] = rsum;
       if (i >= lim) continue;
     }
@@ -333,141 +336,223 @@ __global__ __launch_bounds__(256) void assemble_kernel(
 }
 
 // The hot form of the assembly -- marginal branch, deferred normalisation (what assemble_kernel<false, true,
-// true> did until round 4): the RAW lower tiles of the padded system and their row / column sums, one 64 x 64
-// tile per workgroup.  Differences from the general kernel, all of them about latency (the kernel issues a
-// third of the instructions its duration has room for):
-//   * the star's table arrives packed (theta_kernel) and every load of the prologue -- table, phases, times --
-//     is in flight before the first wait (the general kernel's transposing copy loop waits out five memory round
-//     trips in a row);
-//   * the 16 entries of a thread are evaluated as ONE batch (SplineGen::many): index computations, gathers
-//     and Horner chains of different entries overlap;
-//   * the temporal kernel is a template parameter: no run-time switch (and no inlined exp) between entries.
-// Same operations per entry as the general kernel and as the tiles formed at first touch: same bits.
-#ifndef SP_ASM_EXPERIMENT
-#define SP_ASM_EXPERIMENT 0
-#endif
+// true> did until round 4): the RAW lower tiles of the padded system and their row / column sums.
+//
+// Round 3's kernel spent one workgroup per 64 x 64 tile (8 704 per 64-star step): timed with the spline
+// evaluation compiled out it still took 33 of its 55 us -- tile decode, a transposing copy of the table that
+// waits out five memory round trips in a row, two barriers, a column reduction through LDS per tile.  Here a
+// workgroup is long-lived: it takes a CHUNK of its star's lower tiles in column-strip order (tiles (tj, tj),
+// (tj + 1, tj), ... (ntr - 1, tj), then the next strip), so that
+//   * the star's table (packed by theta_kernel) is copied to LDS once per workgroup, every load of the
+//     prologue in flight before the first wait;
+//   * the phases of a strip's 64 columns stay in four registers per thread, the column sums accumulate in
+//     four more over the strip and go through LDS once per strip, not once per tile;
+//   * the phases of a tile's rows are fetched one tile ahead; the tile loop has no barrier at all;
+//   * the 16 entries of a thread are evaluated as ONE batch (SplineGen::many) and the temporal kernel is a
+//     template parameter: no run-time switch (and no inlined exp) between entries.
+// Same operations per entry as the general kernel and as the tiles formed at first touch: same bits; the sums
+// land in the slots defer_finish_kernel adds up (the column sums of a strip segment in the segment's first
+// slot, zeros in its others).
 #ifndef SP_ASM_BATCH
 #define SP_ASM_BATCH 16      // entries per SplineGen::many batch (4, 8 or 16)
 #endif
+#ifndef SP_ASM_OCC
+#define SP_ASM_OCC 2         // workgroups per CU the register budget is cut for
+#endif
 template <int TK>
-__global__ __launch_bounds__(256) void assemble_sums_kernel(
+__global__ __launch_bounds__(256, SP_ASM_OCC) void assemble_sums_kernel(
     int K, int M, int Kp, const double *__restrict__ theta, const double *__restrict__ t,
     const sp_star *__restrict__ stars, int covpts, const double *__restrict__ ptab,
     const double *__restrict__ meanvar, const double *__restrict__ flux, double *__restrict__ out, long ldo,
-    long strideo, int ntr, double *__restrict__ part, int lazy_nfull) {
+    long strideo, int ntr, double *__restrict__ part, int lazy_nfull, int nchunk) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int s = blockIdx.y, np = covpts + 4, tid = threadIdx.x;
   const sp_star st = stars[s];
-  const int tile = blockIdx.x;
-  int ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
-  while (ti * (ti + 1) / 2 > tile) --ti;
-  while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
-  const int tj = tile - ti * (ti + 1) / 2;
-  const int i0 = ti * 64, j0 = tj * 64;
-  double *s_tab = lds;                       // 4 np
-  double *s_th = s_tab + 4 * np;             // phases: rows 0 .. 63, columns 64 .. 127
-  double *s_t = s_th + 128;                  // times, the same (TK != 0)
-  double *s_col = s_t + 128;                 // [16][64] column-sum partials
-  const int nobs = star_nobs(st, K);
+  const int ntiles = ntr * (ntr + 1) / 2;
+  const int per = (ntiles + nchunk - 1) / nchunk;
+  const int t0 = per * blockIdx.x, t1 = t0 + per < ntiles ? t0 + per : ntiles;
+  if (t0 >= t1) return;
+  // strip-major tile order: strip tj holds the tiles ti = tj .. ntr - 1
+  int tj = 0, ti;
   {
-    // thread l < 128: the phase (and time) of row i0 + l or column j0 + l - 64
-    const int idx = tid < 64 ? i0 + tid : j0 + tid - 64;
-    const bool ok = tid < 128 && idx < K;
-    const double th = ok ? theta[(size_t)s * K + idx] : 0.0;
-    const double tt = (TK != SP_TEMPORAL_NONE && ok) ? t[(size_t)s * K + idx] : 0.0;
-    spline_table_to_lds(ptab + (size_t)s * 4 * np, s_tab, np, tid);
-    if (tid < 128) {
-      s_th[tid] = th;
-      if (TK != SP_TEMPORAL_NONE) s_t[tid] = tt;
+    int rem = t0;
+    while (rem >= ntr - tj) {
+      rem -= ntr - tj;
+      ++tj;
     }
+    ti = tj + rem;
   }
-  __syncthreads();
-  SplineGen g{s_tab, 2 * np, 6.283185307179586 / covpts, 1.0 / (6.283185307179586 / covpts), covpts};
-  double *ob = out + (size_t)s * strideo;
-  // thread -> columns cl, cl + 16, cl + 32, cl + 48 of rows ri, ri + 16, ri + 32, ri + 48 (the 16 lanes of a row
-  // look up ADJACENT columns: neighbouring table segments on distinct bank groups)
+  double *s_tab = lds;                       // 4 np
+  double *s_col = s_tab + 4 * np;            // [16][64] column-sum partials
+  const int nobs = star_nobs(st, K);
+  const double *th = theta + (size_t)s * K, *tt = t + (size_t)s * K;
+  // thread -> columns cl, cl + 16, cl + 32, cl + 48 of rows ri, ri + 16, ri + 32, ri + 48 of a tile (the 16 lanes of
+  // a row look up ADJACENT columns: neighbouring table segments on distinct bank groups)
   const int cl = tid & 15, ri = tid >> 4;
-  double v[16];
-#pragma unroll
-  for (int p0 = 0; p0 < 4; p0 += SP_ASM_BATCH / 4) {
-    double a[SP_ASM_BATCH], b[SP_ASM_BATCH], o[SP_ASM_BATCH];
-#pragma unroll
-    for (int k = 0; k < SP_ASM_BATCH; ++k) {
-      a[k] = s_th[ri + 16 * (p0 + (k >> 2))];
-      b[k] = s_th[64 + cl + 16 * (k & 3)];
-    }
-#if SP_ASM_EXPERIMENT == 2
-    for (int k = 0; k < SP_ASM_BATCH; ++k) o[k] = a[k] - b[k];   // (experiment: no spline evaluation)
-#else
-    g.many<SP_ASM_BATCH>(a, b, o);
-#endif
-#pragma unroll
-    for (int k = 0; k < SP_ASM_BATCH; ++k) v[4 * p0 + k] = o[k];
-  }
-  if (nobs == 1) {
-    const double var1 = meanvar[2 * st.table + 1];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = var1;
-  }
-  if (TK != SP_TEMPORAL_NONE) {
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-#pragma clang fp contract(off)
-        v[4 * pass + e] *= temporal_factor(TK, s_t[ri + 16 * pass], s_t[64 + cl + 16 * e], st.tau);
-      }
-  }
-  double csum[4] = {0.0, 0.0, 0.0, 0.0};
-  // (tiles the factorisation forms itself at first touch: sums taken, nothing written -- not the first block
-  //  column: its panel launch has no product to form the tile behind)
-  const bool skip_write = ti > tj && tj > 0 && ti < lazy_nfull;
-#pragma unroll
-  for (int pass = 0; pass < 4; ++pass) {
-    const int li = ri + 16 * pass, i = i0 + li;
-    double w[4];
-    double rsum = 0.0;
+  double thj[4], tmj[4], thi[4], tmi[4];
+  auto load_cols = [&](int tjj) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int j = j0 + cl + 16 * e;
-      double val = 0.0;
-      if (i < nobs && j < nobs) {
-        val = v[4 * pass + e];
-        rsum += val;
-        csum[e] += val;
-      } else if (i >= K && i < K + M && j < nobs) {
-        val = flux[((size_t)s * M + (i - K)) * K + j] - st.baseline_mean;   // (the GP mean of the normalised process is 0)
-      } else if (i == j) {
-        val = 1.0;
-      }
-      w[e] = val;
+      const int j = 64 * tjj + cl + 16 * e;
+      thj[e] = j < K ? th[j] : 0.0;
+      tmj[e] = (TK != SP_TEMPORAL_NONE && j < K) ? tt[j] : 0.0;
     }
-    // row sum of this tile's 64 columns: the 16 lanes that share the row
-    rsum += __shfl_xor(rsum, 8, 16);
-    rsum += __shfl_xor(rsum, 4, 16);
-    rsum += __shfl_xor(rsum, 2, 16);
-    rsum += __shfl_xor(rsum, 1, 16);
-    if (cl == 0 && i < K) part[((size_t)s * ntr + tj) * K + i] = rsum;
-#if SP_ASM_EXPERIMENT == 1
-    continue;     // (experiment: no tile is written)
-#endif
-    if (i >= Kp || skip_write) continue;
-    double *dst = ob + (size_t)i * ldo + j0 + cl;
+  };
+  auto load_rows = [&](int tii, double (&a)[4], double (&b)[4]) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (j0 + cl + 16 * e < Kp) dst[16 * e] = w[e];
-  }
-  if (ti > tj) {
-    // column sums = row sums of the mirror tile (tj, ti), which is never formed
+    for (int pass = 0; pass < 4; ++pass) {
+      const int i = 64 * tii + ri + 16 * pass;
+      a[pass] = i < K ? th[i] : 0.0;
+      b[pass] = (TK != SP_TEMPORAL_NONE && i < K) ? tt[i] : 0.0;
+    }
+  };
+  load_cols(tj);
+  load_rows(ti, thi, tmi);
+  spline_table_to_lds(ptab + (size_t)s * 4 * np, s_tab, np, tid);
+  __syncthreads();
+  SplineGen g{s_tab, 2 * np, 6.283185307179586 / covpts, 1.0 / (6.283185307179586 / covpts), covpts};
+  const double var1 = nobs == 1 ? meanvar[2 * st.table + 1] : 0.0;
+  double *ob = out + (size_t)s * strideo;
+  double *ps = part + (size_t)s * ntr * K;
+  double csum[4] = {0.0, 0.0, 0.0, 0.0};
+  int seg0 = -1;                             // first row tile below the diagonal of this strip segment
+  for (int tile = t0; tile < t1; ++tile) {
+    const int i0 = 64 * ti, j0 = 64 * tj;
+    const bool strip_ends = ti == ntr - 1 || tile == t1 - 1;
+    // the next tile's rows (and, behind a strip's last tile, the next strip's columns) are on their way
+    // while this tile is evaluated
+    const int nti = ti == ntr - 1 ? tj + 1 : ti + 1;
+    double nthi[4], ntmi[4];
+    if (tile + 1 < t1) load_rows(nti, nthi, ntmi);
+    double v[16];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) s_col[ri * 64 + cl + 16 * e] = csum[e];
-    __syncthreads();
-    if (tid < 64) {
-      double a = 0.0;
+    for (int p0 = 0; p0 < 4; p0 += SP_ASM_BATCH / 4) {
+      double a[SP_ASM_BATCH], b[SP_ASM_BATCH], o[SP_ASM_BATCH];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) a += s_col[r * 64 + tid];
-      const int j = j0 + tid;
-      if (j < K) part[((size_t)s * ntr + ti) * K + j] = a;
+      for (int k = 0; k < SP_ASM_BATCH; ++k) {
+        a[k] = thi[p0 + (k >> 2)];
+        b[k] = thj[k & 3];
+      }
+      g.many<SP_ASM_BATCH>(a, b, o);
+#pragma unroll
+      for (int k = 0; k < SP_ASM_BATCH; ++k) v[4 * p0 + k] = o[k];
+    }
+    if (nobs == 1) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = var1;
+    }
+    if (TK != SP_TEMPORAL_NONE) {
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma clang fp contract(off)
+          v[4 * pass + e] *= temporal_factor(TK, tmi[pass], tmj[e], st.tau);
+        }
+    }
+    // the next tile's rows are taken over HERE, ahead of this tile's stores: the counter of outstanding memory
+    // operations is one for loads and stores, so a wait for loads that sits behind the stores waits for the
+    // stores' acknowledgements too (1-2 us per tile: the first form of this loop ran at 4 us per tile)
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      thi[pass] = nthi[pass];
+      tmi[pass] = ntmi[pass];
+    }
+    asm volatile("" : "+v"(thi[0]), "+v"(thi[1]), "+v"(thi[2]), "+v"(thi[3]));
+    // (tiles the factorisation forms itself at first touch: sums taken, nothing written -- not the first block
+    //  column: its panel launch has no product to form the tile behind)
+    const bool skip_write = ti > tj && tj > 0 && ti < lazy_nfull;
+    if (ti > tj && seg0 < 0) seg0 = ti;
+    if (i0 + 64 <= nobs && j0 + 64 <= nobs) {
+      // a tile of valid cadences only (all but the last row / column tile of a system): no masks -- the general
+      // form below spends five instructions on predicates and selects for every one of the evaluation
+      double rs[4];
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        rs[pass] = (v[4 * pass] + v[4 * pass + 1]) + (v[4 * pass + 2] + v[4 * pass + 3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) csum[e] += v[4 * pass + e];
+      }
+      row16_sum(rs);      // the 16 lanes that share a row
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int i = i0 + ri + 16 * pass;
+        if (cl == 0) ps[(size_t)tj * K + i] = rs[pass];
+        if (!skip_write) {
+          double *dst = ob + (size_t)i * ldo + j0 + cl;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dst[16 * e] = v[4 * pass + e];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int i = i0 + ri + 16 * pass;
+        double w[4];
+        double rsum = 0.0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int j = j0 + cl + 16 * e;
+          double val = 0.0;
+          if (i < nobs && j < nobs) {
+            val = v[4 * pass + e];
+            rsum += val;
+            csum[e] += val;
+          } else if (i >= K && i < K + M && j < nobs) {
+            val = flux[((size_t)s * M + (i - K)) * K + j] - st.baseline_mean;   // (the GP mean of the normalised process is 0)
+          } else if (i == j) {
+            val = 1.0;
+          }
+          w[e] = val;
+        }
+        // row sum of this tile's 64 columns: the 16 lanes that share the row
+        {
+          double one[1] = {rsum};
+          row16_sum(one);
+          rsum = one[0];
+        }
+        if (cl == 0 && i < K) ps[(size_t)tj * K + i] = rsum;
+        if (i >= Kp || skip_write) continue;
+        double *dst = ob + (size_t)i * ldo + j0 + cl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (j0 + cl + 16 * e < Kp) dst[16 * e] = w[e];
+      }
+    }
+    if (ti == tj) {
+      // (the diagonal tile has no mirror: its entries are not column sums of anything)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) csum[e] = 0.0;
+    }
+    if (strip_ends) {
+      if (seg0 >= 0) {
+        // column sums of the segment's tiles below the diagonal = row sums of their mirror tiles (tj, ti), which are
+        // never formed: the whole segment's in the slot of its first tile, zeros in the slots of the others
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s_col[ri * 64 + cl + 16 * e] = csum[e];
+        __syncthreads();
+        if (tid < 64) {
+          double a = 0.0;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) a += s_col[r * 64 + tid];
+          const int j = j0 + tid;
+          if (j < K) {
+            ps[(size_t)seg0 * K + j] = a;
+            for (int c = seg0 + 1; c <= ti; ++c) ps[(size_t)c * K + j] = 0.0;
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) csum[e] = 0.0;
+        seg0 = -1;
+      }
+      if (tile + 1 < t1) load_cols(tj + 1);
+    }
+    if (ti == ntr - 1) {
+      ++tj;
+      ti = tj;
+    } else {
+      ++ti;
     }
   }
 }
@@ -662,15 +747,23 @@ int sp_launch_assemble_sums(int S, int K, int M, int Kp, const double *theta, co
                             int temporal, const double *flux, double *sys, hipStream_t st, double *part,
                             int lazy_nfull) {
   const int np = covpts + 4;
-  const size_t lds = sizeof(double) * (4 * (size_t)np + 256 + 16 * 64);
+  const size_t lds = sizeof(double) * (4 * (size_t)np + 16 * 64);
   if (lds > attr_lds_limit || !ptab || !part) return SP_ERR_INVALID;
-  const int ntr = Kp / 64;
-  dim3 grid(ntr * (ntr + 1) / 2, S);
+  const int ntr = Kp / 64, ntiles = ntr * (ntr + 1) / 2;
+  // tiles per workgroup: a function of nothing but the build -- the column sums of a strip segment are added
+  // in the segment's order, and a star's value must not depend on how many stars share its launch
+  static const int per = [] {
+    const char *e = getenv("SP_ASM_TILES");
+    const int v = e ? atoi(e) : 8;
+    return v < 1 ? 1 : v;
+  }();
+  const int nchunk = (ntiles + per - 1) / per;
+  dim3 grid(nchunk, S);
 #define SP_ASMS(TK)                                                                                     \
   do {                                                                                                  \
     allow_big_lds(assemble_sums_kernel<TK>);                                                            \
     hipLaunchKernelGGL((assemble_sums_kernel<TK>), grid, dim3(256), lds, st, K, M, Kp, theta, t, stars, \
-                       covpts, ptab, meanvar, flux, sys, (long)Kp, (long)Kp * Kp, ntr, part, lazy_nfull); \
+                       covpts, ptab, meanvar, flux, sys, (long)Kp, (long)Kp * Kp, ntr, part, lazy_nfull, nchunk); \
   } while (0)
   if (temporal == SP_TEMPORAL_NONE) SP_ASMS(SP_TEMPORAL_NONE);
   else if (temporal == SP_TEMPORAL_MATERN32) SP_ASMS(SP_TEMPORAL_MATERN32);

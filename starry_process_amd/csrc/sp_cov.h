@@ -24,6 +24,28 @@ __device__ __forceinline__ double temporal_factor(int kind, double ti, double tj
   return exp(-(dt * dt) / (2.0 * tau));
 }
 
+// sums over the 16 lanes of a DPP row, N values at once, result in every lane: four exchange-and-add steps on the
+// cross-lane data path (quad_perm xor 1, xor 2, row_half_mirror, row_mirror; two 32-bit moves per double).
+// __shfl_xor(double, k, 16) compiles to ds_bpermute_b32 pairs -- a round trip through the LDS crossbar per step
+// with a full lgkmcnt wait behind each: 16 dependent round trips per assembled tile (round 4).
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <int N>
+__device__ __forceinline__ void row16_sum(double (&x)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) x[k] += dpp_move<0xB1>(x[k]);    // quad_perm [1, 0, 3, 2]
+#pragma unroll
+  for (int k = 0; k < N; ++k) x[k] += dpp_move<0x4E>(x[k]);    // quad_perm [2, 3, 0, 1]
+#pragma unroll
+  for (int k = 0; k < N; ++k) x[k] += dpp_move<0x141>(x[k]);   // row_half_mirror
+#pragma unroll
+  for (int k = 0; k < N; ++k) x[k] += dpp_move<0x140>(x[k]);   // row_mirror
+}
+
 // spline lookup (flux.py:262-272)
 //
 // The segment index is integer work and must equal floor(fl(x / dx)) bit for
