@@ -22,7 +22,7 @@ One "step" = one hyperparameter sample of an MCMC / nested-sampling loop:
                                             (sp_lnlike_ensemble)
   -> N > 1: RCCL all-gather of the per-star log-likelihoods (torch.distributed).
 Consecutive steps are independent samples (the walkers / live points a sampler
-evaluates per iteration), so --in-flight F of them (default 3) are kept in flight:
+evaluates per iteration), so --in-flight F of them (default 4) are kept in flight:
 step i runs on stream i mod F with its own library handle, workspace and outputs.
 The latency-bound phases of one step (diagonal blocks, panel solves) then overlap
 the throughput-bound phases of its neighbours (assembly, trailing updates); every
@@ -42,8 +42,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# one hardware queue per stream in flight (starry_process_amd/__init__.py does the same; here before
-# anything can have touched the GPU)
+# one hardware queue per stream in flight (engine._want_hw_queues would do the same when the slots are asked
+# for; here before anything can have touched the GPU, and visible in the file the driver runs)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 YDEG, UDEG, K, STARS_PER_GPU, COVPTS = 15, 2, 1000, int(os.environ.get("SP_BENCH_STARS", "64")), 300
@@ -157,6 +157,7 @@ def timed_steps(h, steps, warmup, prewarm_ms=0.0, before_timed=None):
         h.slots[i % F].run()
     host_enqueue = time.perf_counter() - t0
     h.sync()
+    h.local_elapsed = time.perf_counter() - t0      # this rank's own clock to its own last step (N > 1: reported per rank)
     h.barrier()
     elapsed = h.max_over_ranks(time.perf_counter() - t0)
     return elapsed, host_enqueue, prewarm_steps
@@ -312,21 +313,57 @@ def launch_ranks(n, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    def stop_all(grace=5.0):
+        """terminate every rank still running; kill what ignores it after `grace` seconds"""
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + grace
+        for p in procs:
+            while p.poll() is None and time.time() < t_end:
+                time.sleep(0.05)
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+
+    import signal
+
+    def on_signal(signum, frame):
+        # (a `timeout`, Ctrl-C or the driver's SIGTERM on the parent must not leave N ranks holding their GPUs and
+        #  the rendezvous)
+        raise KeyboardInterrupt("signal %d" % signum)
+
+    old = {sig: signal.signal(sig, on_signal) for sig in (signal.SIGTERM, signal.SIGINT)}
     rc = 0
-    live = set(range(n))
-    while live:
-        for r in sorted(live):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            live.discard(r)
-            if code != 0 and rc == 0:
-                rc = code if code > 0 else 1
-                print("bench.py: rank %d exited with %d; stopping the other ranks" % (r, code), file=sys.stderr)
+    try:
+        live = set(range(n))
+        deadline = None                   # set once a rank has failed: the others get a few seconds to leave
+        while live:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0 and rc == 0:
+                    # (a rank killed by signal k reports -k: 128 + k, as a shell would)
+                    rc = code if code > 0 else 128 - code
+                    print("bench.py: rank %d exited with %d; stopping the other ranks" % (r, code), file=sys.stderr)
+                    for o in live:
+                        procs[o].terminate()
+                    deadline = time.time() + 10.0
+            if live and deadline is not None and time.time() > deadline:
                 for o in live:
-                    procs[o].terminate()
-        if live:
-            time.sleep(0.05)
+                    procs[o].kill()       # a survivor stuck in a collective ignores SIGTERM
+                deadline = time.time() + 1e9
+            if live:
+                time.sleep(0.05)
+    except KeyboardInterrupt as e:
+        print("bench.py: interrupted (%s); stopping the ranks" % e, file=sys.stderr)
+        rc = rc or 130
+    finally:
+        stop_all()
+        for sig, h in old.items():
+            signal.signal(sig, h)
     return rc
 
 
@@ -361,6 +398,20 @@ class StubSlot(object):
         self.calls += 1
 
 
+def per_rank_ms(torch, dist, world, local_elapsed, steps, device):
+    """{"min", "max", "all"}: every rank's own ms_per_step over the timed region (its clock from the common
+    barrier to the completion of ITS last step; `ms_per_step` of the line is the job's: to the barrier behind
+    the slowest rank)."""
+    mine = 1e3 * local_elapsed / steps
+    if world == 1:
+        return {"min": mine, "max": mine, "all": [mine]}
+    tt = torch.tensor([mine], dtype=torch.float64, device=device)
+    every = [torch.zeros_like(tt) for _ in range(world)]
+    dist.all_gather(every, tt)
+    vals = [float(x.item()) for x in every]
+    return {"min": min(vals), "max": max(vals), "all": vals}
+
+
 def main_stub(args, rank, world):
     """The control flow of main() on gloo with StubSlot evaluators (no GPU, no library)."""
     import torch
@@ -368,6 +419,8 @@ def main_stub(args, rank, world):
 
     if os.environ.get("SP_BENCH_STUB_FAIL_RANK") == str(rank):   # (test hook: a rank that dies at start-up)
         return 7
+    if os.environ.get("SP_BENCH_STUB_SLEEP"):                    # (test hook: ranks that outlive their parent's patience)
+        time.sleep(float(os.environ["SP_BENCH_STUB_SLEEP"]))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -386,6 +439,7 @@ def main_stub(args, rank, world):
     sid, g = slots[(args.steps - 1) % F].history[-1]
     ref = np.array([_stub_lnlike(s, sid) for s in range(world * S)])
     ok = bool(np.array_equal(g.numpy(), ref))
+    per_rank = per_rank_ms(torch, dist, world, h.local_elapsed, args.steps, None)
     if rank == 0:
         print(json.dumps({
             "metric": "log_likelihood evals/sec (ydeg=15, K=1000)", "value": world * S * args.steps / elapsed,
@@ -396,6 +450,7 @@ def main_stub(args, rank, world):
                                    "measurement", "stars_per_gpu": S, "parallelism": "stars sharded %d-way" % world,
                        "steps_in_flight": F},
             "backend": "gloo-stub", "parity_ok": ok, "gathered_values": int(g.numel()),
+            "per_rank_ms_per_step": per_rank, "cpu_baseline": "N = 1 only" if world > 1 else None,
             "prewarm": {"steps": prewarm_steps, "timed": False}}))
     if world > 1:
         dist.barrier()
@@ -507,6 +562,30 @@ def main():
 
     elapsed, host_enqueue, prewarm_steps = timed_steps(harness, args.steps, args.warmup, args.prewarm_ms, arm)
     timed_prof = prof_summary([sl.e for sl in slots], timed_kinds)
+    per_rank = per_rank_ms(torch, dist, world, harness.local_elapsed, args.steps, e.device) if use_dist else None
+    # N > 1: what the all-gather costs a step (untimed repeat, the collective of every step between two events on
+    # the step's own stream: its span there, the wait for the slowest rank's shard included)
+    allgather = None
+    if use_dist:
+        nag = min(args.steps, 4 * F)
+        evs = []
+        dist.barrier()
+        for i in range(nag):
+            sl = slots[i % F]
+            with torch.cuda.stream(sl.stream):
+                sl.use_dist = False
+                sl.step()
+                sl.use_dist = True
+                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a0.record(sl.stream)
+                dist.all_gather_into_tensor(sl.gathered, sl.out)
+                a1.record(sl.stream)
+                evs.append((a0, a1))
+        torch.cuda.synchronize()
+        ag = [a0.elapsed_time(a1) for a0, a1 in evs]
+        allgather = {"launches": nag, "avg_ms": float(np.mean(ag)), "max_ms": float(np.max(ag)),
+                     "bytes_per_rank": 8 * S, "note": "span of ncclAllGather (RCCL) on the step's stream, " 
+                     "untimed repeat with %d steps in flight; includes the wait for the slowest rank" % F}
     # Untimed repeat of the same steps in flight with EVERY panel kernel under its own pair of
     # events (the pairs cost a few per cent of a step, hence not in the timed region)
     launch_prof = None
@@ -732,6 +811,14 @@ def main():
             "other_shapes": extras,
             "roofline": roof,
         }
+        if world > 1:
+            line["per_rank_ms_per_step"] = per_rank
+            if allgather:
+                allgather["share_of_step"] = allgather["avg_ms"] / ms_per_step
+            line["allgather"] = allgather
+            line["cpu_baseline"] = "N = 1 only (rank 0 would hold the other ranks up; see the N = 1 line)"
+            roof["measured"] += "; N > 1: no one-at-a-time leg (`alone` figures are the N = 1 line's), " \
+                                "whole_step is per GPU over the job's ms_per_step"
         if not args.no_cpu and world == 1:   # reported at N = 1 only (rank 0 would hold the others up)
             base, ref_vals = cpu_baseline(args.cpu_stars, engine="c")
             line["cpu_baseline"] = base

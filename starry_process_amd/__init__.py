@@ -1,17 +1,8 @@
 """MI355X-native log-likelihood hot path of starry_process."""
 __version__ = "0.1.0"
 
-import os as _os
-
-# Several independent evaluations are kept in flight on separate HIP streams (engine.engine_slots,
-# calibrate.EnsembleLogProb, bench.py).  The runtime maps streams onto 4 hardware queues by default: a
-# fifth stream shares a queue with another and the two serialise (measured: four steps in flight
-# LOSE 10 % with 4 queues and gain 3 % with 8).  Takes effect only if no HIP call has been made yet
-# in this process; an explicit setting of the caller wins.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
-from .defaults import defaults  # noqa: E402,F401
-from .temporal import ExpSquaredKernel, Matern32Kernel  # noqa: E402,F401
+from .defaults import defaults  # noqa: F401
+from .temporal import ExpSquaredKernel, Matern32Kernel  # noqa: F401
 
 
 def __getattr__(name):

@@ -22,16 +22,7 @@
 
 namespace {
 
-struct Coef {   // per-star normalisation coefficients, 8 doubles
-  double c1;    // alpha / mu^2          (1 when not normalised)
-  double zab;   // alpha + beta
-  double za;    // alpha
-  double z;     // m / mu^2
-  double gpmean;  // mean of the flux GP (0 when normalised, sp.py:669-670)
-  double m;     // mean(Sigma)
-  double mu;    // 1 + flux mean
-  double pad;
-};
+typedef SpCoef Coef;   // per-star normalisation coefficients (sp_internal.h)
 
 __global__ __launch_bounds__(256) void theta_kernel(
     int K, const double *__restrict__ t, const sp_star *__restrict__ stars,
@@ -154,7 +145,7 @@ __global__ __launch_bounds__(256) void norm_coef_kernel(
   c.gpmean = normalized ? 0.0 : fmean;
   c.m = 0.0;
   c.mu = 1.0 + fmean;
-  c.pad = 0.0;
+  c.d1 = 0.0;
   const int nobs = star_nobs(stars[s], K);
   if (normalized) {
     double part = 0.0;
@@ -212,7 +203,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(
   const sp_star st = stars[s];
   Coef c;
   if (DEFER) {
-    c.c1 = 1.0; c.zab = 0.0; c.za = 0.0; c.z = 0.0; c.gpmean = 0.0; c.m = 0.0; c.mu = 1.0; c.pad = 0.0;
+    c.c1 = 1.0; c.zab = 0.0; c.za = 0.0; c.z = 0.0; c.gpmean = 0.0; c.m = 0.0; c.mu = 1.0; c.d1 = 0.0;
   } else {
     c = coef[s];
   }
@@ -629,7 +620,7 @@ __global__ __launch_bounds__(1024) void defer_finish_kernel(
     c.gpmean = 0.0;
     c.m = m;
     c.mu = mu;
-    c.pad = st.baseline_var / c1;      // d_1
+    c.d1 = st.baseline_var / c1;       // d_1
     coef[s] = c;
     if (status && z > zmax) atomicOr(&status[s], SP_STAR_ZMAX);
   }

@@ -21,9 +21,7 @@
 
 namespace {
 
-struct CondCoef {   // = Coef of sp_assemble.hip
-  double c1, zab, za, z, gpmean, m, mu, pad;
-};
+typedef SpCoef CondCoef;
 
 using CondCore = MM2<64, 64, 8, 6, 4>;
 

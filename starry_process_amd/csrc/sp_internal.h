@@ -169,6 +169,22 @@ struct LazyCov {
   int tr0, tc0;            // system tile coordinates of the launch's tile (0, 0)
 };
 
+// Per-star normalisation coefficients: 8 doubles per star in the workspace (`coef`), written by
+// norm_coef_kernel (direct form) or defer_finish_kernel (deferred form) of sp_assemble.hip, read
+// by the assembly kernels, cond_system_kernel (sp_cond.hip) and the reduction (sp_reduce.h).  ONE definition:
+// rounds 2-3 carried three hand-made mirrors of it with different field names for the same slots.
+struct SpCoef {
+  double c1;       // alpha / mu^2                       (1 when not normalised)
+  double zab;      // direct: alpha + beta               deferred: d_p = z (alpha + beta) / c1
+  double za;       // direct: alpha                      deferred: d_q = -z alpha / c1
+  double z;        // m / mu^2
+  double gpmean;   // mean of the flux GP (0 when normalised, sp.py:669-670)
+  double m;        // mean(Sigma)
+  double mu;       // 1 + flux mean
+  double d1;       // direct: unused                     deferred: d_1 = baseline_var / c1
+};
+static_assert(sizeof(SpCoef) == 64, "8 doubles per star (Layout::coef, sub_layout)");
+
 // What the workgroup that factors a group's LAST pivot block does behind it (sp_panel.hip): the
 // log-likelihood reduction of its star (sp_reduce.h), when the residual / normalisation rows live in
 // that block's row tile and the block is factored in a panel launch's tail (sp_panel_fuses_reduce).
@@ -176,7 +192,7 @@ struct SpReduceArgs {
   double *lnlike;               // null: no reduction (plain factorisations)
   uint32_t *status, *status_out;
   const sp_star *stars;
-  const void *coef;             // RedCoef per star (deferred normalisation) or null
+  const void *coef;             // SpCoef per star (deferred normalisation) or null
   int K, M;
   int live_rows;                // rows of the padded system that carry data (0: all): the rest is identity padding
 };

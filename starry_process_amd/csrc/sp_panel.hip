@@ -83,8 +83,9 @@ struct P2WgStamp {
 #endif
 
 #ifndef P_WGS
-#define P_WGS 3             // workgroups per CU the register budget is cut for (168 registers: no spills --
-                            // with 128, the scratch traffic of the D items cost them 20 us per launch)
+#define P_WGS 3             // workgroups per CU the register budget is cut for (168 registers; per instantiation
+                            // 124-168 are used and nothing spills, vector or scalar: DESIGN.md 4.3 -- with a
+                            // budget of 128 the scratch traffic of the D items cost them 20 us per launch)
 #endif
 
 namespace {
@@ -121,7 +122,7 @@ struct PanelArgs {
   int pair;            // row tiles below the next pivot row tile are dealt in pairs (128-row items)
   int lay;             // 1: chain-aware layout of the launch (see panel_kernel)
   int seq;             // launch number (tags the chain workgroups' words in the stars' scratch)
-  double *img;         // per star `lts` doubles: two image slots (sp_tile.h)
+  double *img;         // per star `lts` doubles: three image slots + the chain words (sp_tile.h)
   long lts;
   int32_t *info;
   LazyCov lz;

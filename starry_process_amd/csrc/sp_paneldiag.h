@@ -36,7 +36,7 @@ struct DiagFuse {
   double *sys;       // systems (null: nothing to factor)
   long ld, stride;
   int j, nact;       // pivot block, its active columns
-  double *img;       // per-star scratch (lts doubles apart); slot (j & 1) receives the image
+  double *img;       // per-star scratch (lts doubles apart); slot j mod 3 receives the image (sp_tile.h)
   long lts;
   int32_t *info;
 };

@@ -17,9 +17,7 @@
 // terms first), give log det C and r^T C^-1 r from the Gram matrix of those rows and the
 // residuals'; a rank-1 step whose pivot 1 + d u^T B^-1 u is not positive means C is not positive
 // definite: the same -inf the reference's failed Cholesky gives (math.py:82-91, sp.py:1186-1188).
-struct RedCoef {   // = Coef of sp_assemble.hip
-  double c1, dp, dq, z, gpmean, m, mu, d1;
-};
+typedef SpCoef RedCoef;   // (deferred form: zab = d_p, za = d_q)
 
 // COHERENT: read past the L1 (agent-scope loads) -- for a caller whose inputs were written by ANOTHER workgroup of
 // the same launch.  (The panel kernel's tail does not need it: what it reads was written by earlier launches or
@@ -99,7 +97,7 @@ __device__ __forceinline__ void lnlike_reduce_body(
     const RedCoef rc = *coef_s;
     c1 = rc.c1;
     double H[3][3] = {{v[1], v[3], v[2]}, {v[3], v[6], v[5]}, {v[2], v[5], v[4]}};
-    const double d[3] = {rc.dp, rc.d1, rc.dq};
+    const double d[3] = {rc.zab, rc.d1, rc.za};
     for (int k = 0; k < 3; ++k) {
       for (int a = 0; a < 3; ++a) col[k][a] = H[a][k];
       if (d[k] == 0.0) continue;

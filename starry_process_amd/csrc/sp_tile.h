@@ -31,5 +31,8 @@ static inline long sp_xcd_grid(long batch, long ntiles) { return 8L * ((batch * 
 #define SP_IMG_SLOT 2688
 #define SP_IMG_WORDS (3 * SP_IMG_SLOT)
 __host__ __device__ __forceinline__ size_t sp_img_off(int j) { return (size_t)(j % 3) * SP_IMG_SLOT; }
+// (sp_lt_stride, sp_internal.h, gives a star at least 2 x 4096 doubles: the three slots and the two chain words
+//  must fit, or a star's words land in its neighbour's first image)
+static_assert(SP_IMG_WORDS + 2 <= 2 * 4096, "per-star scratch: three image slots + the chain words");
 
 #endif

@@ -496,6 +496,27 @@ class Engine(object):
 _engines = {}
 
 
+def _want_hw_queues(streams):
+    """Several independent evaluations in flight on separate HIP streams need a hardware queue each: the
+    runtime maps streams onto 4 queues by default, a fifth stream shares a queue with another and the two
+    serialise (measured: four steps in flight plus the copy stream LOSE 10 % with 4 queues and gain 3 % with
+    8).  ``GPU_MAX_HW_QUEUES`` is read when the HIP runtime initialises: it is set here -- where the streams
+    are asked for, not at package import -- if the process has not touched the GPU yet; if it has, the
+    setting cannot take effect any more and a warning says what to export.  A value set by the caller wins."""
+    import os
+    import warnings
+
+    if streams <= 3 or "GPU_MAX_HW_QUEUES" in os.environ:
+        return
+    torch = _torch()
+    if torch.cuda.is_initialized():
+        warnings.warn("starry_process_amd: %d streams in flight but the HIP runtime is already initialised with "
+                      "its default of 4 hardware queues; export GPU_MAX_HW_QUEUES=8 before the first GPU call "
+                      "(streams that share a queue serialise)" % streams, RuntimeWarning, stacklevel=3)
+    else:
+        os.environ["GPU_MAX_HW_QUEUES"] = "8"
+
+
 def engine_slots(ydeg=15, udeg=2, device=None, depth=3):
     """``depth`` independent (Engine, torch.cuda.Stream) pairs on one GPU, for keeping several
     INDEPENDENT evaluations in flight (the walkers / live points a sampler evaluates per
@@ -506,8 +527,9 @@ def engine_slots(ydeg=15, udeg=2, device=None, depth=3):
     (bench.py).  A handle is not re-entrant, hence one per slot (fresh handles; the
     process-wide engine of ``get_engine`` is left as it is, and is what depth = 1 returns)."""
     torch = _torch()
-    first = get_engine(ydeg, udeg, device)
     depth = max(1, int(depth))
+    _want_hw_queues(depth)
+    first = get_engine(ydeg, udeg, device)
     if depth == 1:
         return [(first, torch.cuda.Stream(device=first.device))]
     out = []

@@ -178,3 +178,46 @@ def test_bench_py_reports_a_dead_rank():
     """A rank that fails takes the job down with a non-zero code (no hang on the survivor's collective)."""
     r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1"], {"SP_BENCH_STUB_FAIL_RANK": "1"}, timeout=120)
     assert r.returncode != 0 and "rank 1 exited" in r.stderr
+
+
+def test_bench_py_eight_ranks_gathers_512_values_in_star_order():
+    """cfg4's shape on CPU: `python bench.py --gpus 8` (gloo stub) -- eight ranks, 64 stars each, and rank 0's
+    line reports 512 gathered values that equal the per-star reference IN STAR ORDER (contiguous shards:
+    rank r owns stars 64 r .. 64 r + 63), every rank's own ms_per_step, and says where the CPU baseline is."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, SP_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "6", "--warmup", "2",
+                        "--in-flight", "3"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["gathered_values"] == 512 and line["parity_ok"] is True
+    assert line["scaling"] == "weak" and line["config"]["stars_per_gpu"] == 64
+    pr = line["per_rank_ms_per_step"]
+    assert len(pr["all"]) == 8 and pr["min"] <= pr["max"] <= line["ms_per_step"] * 1.5
+    assert "N = 1" in line["cpu_baseline"]
+
+
+def test_bench_py_parent_killed_takes_its_ranks_down():
+    """SIGTERM on the parent of `bench.py --gpus 2` (a `timeout`, the driver) must end both ranks."""
+    import signal
+    import subprocess
+    import time
+
+    env = dict(os.environ, SP_BENCH_BACKEND="gloo", SP_BENCH_STUB_SLEEP="60")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    time.sleep(6.0)                       # the ranks are up (and asleep: SP_BENCH_STUB_SLEEP)
+    kids = subprocess.run(["pgrep", "-P", str(p.pid)], capture_output=True, text=True).stdout.split()
+    assert len(kids) == 2, kids
+    p.send_signal(signal.SIGTERM)
+    out, err = p.communicate(timeout=60)
+    assert p.returncode != 0 and "interrupted" in err
+    time.sleep(0.5)
+    for k in kids:
+        assert not os.path.exists("/proc/%s" % k) or open("/proc/%s/stat" % k).read().split()[2] == "Z"
