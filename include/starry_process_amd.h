@@ -283,6 +283,37 @@ int sp_cholesky_lnlike_batched(sp_handle *h, int S, int K, int M,
                                void *workspace_dev, double *lnlike_dev,
                                uint32_t *status_dev, void *stream);
 
+/* ---- batched inverse and log-determinant of SPD matrices (round 4; what the reverse sweep of the
+ * likelihood needs: d lnL / dC = (alpha alpha^T - C^-1) / 2, math.py:40-72 composed) ------------------------
+ * C_dev [S] K x K (leading dimension ldc, stride strideC; symmetric positive definite, the lower triangle is
+ * read) -> Cinv_dev [S, Kr, Kr], Kr = roundup(K, 64): the LOWER 64 x 64 tiles of C^-1 (rows / columns >= K zero;
+ * the tiles above the diagonal are not written), logdet_dev [S] = log det C (NaN: not positive definite),
+ * info_dev [S] (may be NULL).  The identity rides through the blocked factorisation as rows below the matrix
+ *  and comes out as L^-T; C^-1 = L^-T L^-1 is one product on the matrix cores.
+ * workspace_dev: sp_spd_inverse_workspace_bytes(h, S, K) bytes.                                            */
+size_t sp_spd_inverse_workspace_bytes(sp_handle *h, int S, int K);
+int sp_spd_inverse_batched(sp_handle *h, int S, int K, const double *C_dev, long ldc, long strideC,
+                           double *Cinv_dev, double *logdet_dev, int32_t *info_dev, void *workspace_dev,
+                           void *stream);
+
+/* ---- the ensemble gradient's device half (round 4; tests/test_lnlike.py:100-136 for a whole batch) ------------
+ * Marginal branch, one light curve per star (M = 1), every cadence valid (sp_star.nobs = 0).  For every star:
+ *   lnlike_dev [S]            the log-likelihood (sp.py:1129-1188; -inf as sp_lnlike_ensemble)
+ *   ybar_dev [S, covpts + 4]  d lnL_s / d yp, yp = the star's kernel table (tab_dev[table_s][0, :], the second
+ *                             moment on the lag grid minus mean^2, flux.py:310-320), everything else held fixed
+ *   meanbar_dev [S]           d lnL_s / d (flux mean, meanvar_dev[2 table_s]) at fixed table
+ * by one reverse sweep: C assembled, C^-1 by sp_spd_inverse_batched, d lnL / dC = (alpha alpha^T - C^-1) / 2
+ * pulled back through the normalisation (sp.py:705-727) and the cubic interpolation (flux.py:256-276; the spline
+ * is linear in yp).  The caller chains (ybar, meanbar) to the hyperparameters: d lnL / d theta = sum_s ybar_s .
+ * d yp / d theta + meanbar_s d mean / d theta (starry_process_amd/grad.py: ensemble_gradient).
+ * workspace_dev: sp_lnlike_grad_workspace_bytes(h, S, K, covpts) bytes.                                      */
+size_t sp_lnlike_grad_workspace_bytes(sp_handle *h, int S, int K, int covpts);
+int sp_lnlike_grad_marginal(sp_handle *h, int S, int K, const double *t_dev, const double *flux_dev,
+                            const double *diag_dev, const sp_star *stars_dev, int covpts, const double *tab_dev,
+                            const double *meanvar_dev, int temporal, int normalized, int norm_order, double zmax,
+                            void *workspace_dev, double *lnlike_dev, double *ybar_dev, double *meanbar_dev,
+                            uint32_t *status_dev, void *stream);
+
 /* ---- fp64 NT product on the matrix cores (the kernel behind a13 / a17, exposed) -------
  *   C[b] = beta * C[b] + alpha * A[b] . B[b]^T,   beta in {0, 1}
  * A: M x K (lda), B: N x K (ldb), C: M x N (ldc), row-major, `batch` matrices strideA /

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void pad_in_kernel(const double *__restrict__ 
                                                      int K, long lda, long strideA,
                                                      double *__restrict__ sys, int Kp,
                                                      long strideS, int M,
-                                                     const double *__restrict__ resid) {
+                                                     const double *__restrict__ resid, int ident) {
   const int s = blockIdx.z, i = blockIdx.y;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= Kp) return;
@@ -54,6 +54,10 @@ __global__ __launch_bounds__(256) void pad_in_kernel(const double *__restrict__ 
     v = A[(size_t)s * strideA + (size_t)i * lda + j];
   else if (i >= K && i < K + M && j < K && resid)
     v = resid[((size_t)s * M + (i - K)) * K + j];
+  else if (ident && i >= K + M)
+    v = (j == i - (K + M) && j < K) ? 1.0 : 0.0;   // the identity riding along below the M residual rows (no unit diagonal
+                                             // of their own: those rows are never pivots, and their columns beyond K
+                                             // must stay zero for the product that forms the inverse)
   else if (i == j)
     v = 1.0;
   sys[(size_t)s * strideS + (size_t)i * Kp + j] = v;
@@ -221,8 +225,15 @@ __global__ __launch_bounds__(256) void chol_rev_finish_kernel(const double *__re
 // behind it runs under the products of the launch's other items.
 static int cholesky_panel2(sp_handle *h, int ngroups, const sp_chol_group *grp, int K, int Kp, int w) {
   const long ld = Kp, stride = (long)Kp * Kp, lts = sp_lt_stride(Kp);
-  const int nsteps = (K + SP_NB - 1) / SP_NB, ntile = Kp / SP_NB;
+  const int nsteps = (K + SP_NB - 1) / SP_NB, ntile_all = Kp / SP_NB;
   const bool la_on = h->look_ahead != 0;
+  // row tiles a launch of pivot block j has to take (all of them, unless an identity rides along: tri0)
+  const int tri0 = grp[0].tri0;
+  auto ntile_of = [&](int j) {
+    if (tri0 < 0) return ntile_all;
+    const int need = (tri0 + SP_NB * (j + 1) + SP_NB - 1) / SP_NB;
+    return need < ntile_all ? need : ntile_all;
+  };
   const bool fuse_reduce = sp_panel_fuses_reduce(h, K, Kp);
   auto nact_of = [&](int j) { return K - j * SP_NB < SP_NB ? K - j * SP_NB : SP_NB; };
   for (int s0 = 0; s0 < nsteps; s0 += w) {
@@ -230,6 +241,7 @@ static int cholesky_panel2(sp_handle *h, int ngroups, const sp_chol_group *grp, 
       SpProfScope sp_scope(ngroups == 1 ? h : nullptr, grp[0].st, SP_PROF_PANELS, 0.0, 0);
       for (int q = 0; q < w && s0 + q < nsteps; ++q) {
         const int j = s0 + q;
+        const int ntile = ntile_of(j);
         int last = s0 + w;
         if (last > nsteps - 1) last = nsteps - 1;
         const int neager = last > j ? last - j : 0;
@@ -273,7 +285,9 @@ static int cholesky_panel2(sp_handle *h, int ngroups, const sp_chol_group *grp, 
     }   // (sp_scope ends here: the trailing update has its own pair)
     const int jE = s0 + w, cE = jE * SP_NB;
     if (cE < K) {
-      const int n = Kp - cE, kd = w * SP_NB, cS = s0 * SP_NB;
+      // (an identity riding along: rows up to what column block jE - 1 has reached, pivot columns only)
+      const int n = ntile_of(jE - 1) * SP_NB - cE, kd = w * SP_NB, cS = s0 * SP_NB;
+      const int tj_limit = tri0 >= 0 ? nsteps - jE : 0;
       for (int g = 0; g < ngroups; ++g) {
         const sp_chol_group &G = grp[g];
         LazyCov lzv = G.lazy;
@@ -281,7 +295,7 @@ static int cholesky_panel2(sp_handle *h, int ngroups, const sp_chol_group *grp, 
         DiagFuse df{G.sys, ld, stride, jE, nact_of(jE), G.invL, lts, G.info};
         SpProfScope prof(h, G.st, SP_PROF_SYRK, (double)G.S * (double)n * (n + 1) * kd);
         int rc = sp_launch_syrk_diag(G.sys + (size_t)cE * ld + cS, ld, stride, G.sys + (size_t)cE * ld + cE,
-                                     n, kd, G.S, G.st, (G.lazy.theta && s0 == 0) ? &lzv : nullptr, &df);
+                                     n, kd, G.S, G.st, (G.lazy.theta && s0 == 0) ? &lzv : nullptr, &df, tj_limit);
         if (rc != SP_OK) return rc;
       }
     }
@@ -338,9 +352,9 @@ int sp_launch_lnlike_reduce(const double *sys, int S, int K, int M, int Kp,
 }
 
 int sp_launch_pad_in(const double *A, int K, long lda, long strideA, double *sys,
-                     int Kp, int M, const double *resid, int S, hipStream_t st) {
+                     int Kp, int M, const double *resid, int S, hipStream_t st, int ident) {
   hipLaunchKernelGGL(pad_in_kernel, dim3((Kp + 255) / 256, Kp, S), dim3(256), 0,
-                     st, A, K, lda, strideA, sys, Kp, (long)Kp * Kp, M, resid);
+                     st, A, K, lda, strideA, sys, Kp, (long)Kp * Kp, M, resid, ident);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }

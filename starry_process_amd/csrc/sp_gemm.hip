@@ -137,7 +137,13 @@ __global__ __launch_bounds__(256) void mm_nt_kernel(
     ti = tile / ntn;
     tj = tile % ntn;
   }
-  if (skip00 && lower_only && ti == 0 && tj == 0) {
+  // skip00: bit 0 -- tile (0, 0) is not this launch's; bit 1 -- B = A is UPPER triangular by 64 x 64 blocks (an
+  // inverse factor, sp_spd_inverse_batched): the product of tile (ti, tj), ti >= tj, starts at column TM ti;
+  // bits 8.. -- tile columns from this one on are not wanted (the rows below a factorisation that carry no
+  // pivot: their columns are never read)
+  const int tj_limit = skip00 >> 8, k_first = (skip00 & 2) ? ti * TM : 0;
+  if (tj_limit && tj >= tj_limit) return;
+  if ((skip00 & 1) && lower_only && ti == 0 && tj == 0) {
     // tile (0, 0) -- the next pivot block -- carries every update already (the panel kernels keep it
     // up to date); its workgroup factors it beside the products of this launch (sp_paneldiag.h)
     if (df.sys) {
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(256) void mm_nt_kernel(
   const bool lazy = CAN_LAZY && beta && lz.theta && lz.tr0 + ti > lz.tc0 + tj && lz.tc0 + tj > 0 &&
                     lz.tr0 + ti < lz.nfull;
   mm_d4 cz[4];
-  if (!lazy) mm.prologue(lds, 0, Kd);   // the first slices are on their way while the C tile is fetched
+  if (!lazy) mm.prologue(lds, k_first, Kd);   // the first slices are on their way while the C tile is fetched
   if (lazy) {
     int ri[4], cj[4];
 #pragma unroll
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(256) void mm_nt_kernel(
       cj[k] = 64 * (lz.tc0 + tj) + mm.acc_col(k < Core::NA ? k : 0);
     }
     lazy_cov_tile(lz, mtx, ri, cj, cz, lds);
-    mm.prologue(lds, 0, Kd);
+    mm.prologue(lds, k_first, Kd);
   }
 #pragma unroll
   for (int m = 0; m < Core::MA; ++m)
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(256) void mm_nt_kernel(
         cin[m][n] = c;
       }
     }
-  mm.loop(lds, 0, Kd, acc);
+  mm.loop(lds, k_first, Kd, acc);
 #pragma unroll
   for (int m = 0; m < Core::MA; ++m)
 #pragma unroll
@@ -260,7 +266,7 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
     return mm_launch<MM2<64, 64, 8, 6, 4>>(A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows,
                                            Kd, alpha, beta, lower_only, batch, st, skip00);
   }
-  if (skip00) return SP_ERR_INVALID;   // (only the pipelined kernel leaves a tile out)
+  if (skip00) return SP_ERR_INVALID;   // (only the pipelined kernel leaves tiles out)
   hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)nblk), dim3(256), 0, st, A, lda, strideA, B, ldb,
                      strideB, C, ldc, strideC, Mrows, Nrows, Kd, alpha, beta, lower_only, batch, ntn, ntiles);
   SP_LAUNCH_CHECK();
@@ -270,13 +276,14 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
 // C -= X X^T on the lower 64 x 64 tiles of an n x n block, tile (0, 0) skipped -- its workgroup
 // factors the pivot block `df` describes instead (sp_cholesky.hip)
 int sp_launch_syrk_diag(const double *X, long ld, long stride, double *T, int n, int kd, int batch,
-                        hipStream_t st, const LazyCov *lazy, const DiagFuse *df) {
+                        hipStream_t st, const LazyCov *lazy, const DiagFuse *df, int tj_limit) {
   if (n <= 0 || batch <= 0) return SP_OK;
   if ((n % GT) || (kd % 16) || kd <= 0 || (ld & 1) || (stride & 1) ||
       ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(T)) & 15))
     return SP_ERR_INVALID;
   return mm_launch<MM2<64, 64, 8, 6, 4>>(X, ld, stride, X, ld, stride, T, ld, stride, n, n, kd, -1.0, 1, 1,
-                                         batch, st, 1, (lazy && lazy->theta) ? lazy : nullptr, df);
+                                         batch, st, 1 | (tj_limit > 0 ? tj_limit << 8 : 0),
+                                         (lazy && lazy->theta) ? lazy : nullptr, df);
 }
 
 int sp_launch_gemm_nt(const double *A, long lda, long strideA, const double *B, long ldb,

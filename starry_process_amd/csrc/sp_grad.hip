@@ -1,0 +1,259 @@
+// Reverse sweep of the marginal-branch log-likelihood for an ENSEMBLE of stars (round 4; the counterpart of
+// theano.grad(sp.log_likelihood(...), [r, a, b, c, n]) for the whole batch, tests/test_lnlike.py:100-136).
+//
+//   lnL_s = -1/2 r^T C^-1 r - 1/2 log det C - K/2 log 2 pi,      C = C(table_s, flux mean)      (sp.py:1129-1188)
+//   d lnL / dC = G = (alpha alpha^T - C^-1) / 2,  alpha = C^-1 r
+//
+// C^-1 comes from sp_spd_inverse_batched (the identity riding through the blocked factorisation, sp_api.hip).
+// C depends on the hyperparameters only through the star's kernel TABLE yp[covpts + 4] (the second moment on the
+// lag grid, flux.py:310-320) and the scalar flux mean:  Sigma_ij = spline(|theta_i - theta_j|; yp) T_ij is LINEAR
+// in yp, and the normalisation (sp.py:705-727)
+//     C = c1 Sigma + s1 p p^T - s2 q q^T + D + b 1 1^T,   q = Sigma 1 / (K m),  p = 1 - q,  m = mean(Sigma),
+//     z = m / mu^2,  c1 = alpha_n(z) / mu^2,  s1 = z (alpha_n + beta_n),  s2 = z alpha_n,  mu = 1 + flux mean
+// adds a rank-2 term whose adjoint needs nothing but products of C^-1 with r, p, q, 1:
+//     <G, dC> = <H, dSigma> + kappa_mu d mu,      H_ij = c1 G_ij + w_i + w_j
+// (the scalars of grad_scalars_kernel).  The sweep therefore ends in ONE pass over the K^2 entries per star that
+// scatters H_ij T_ij times the four cubic weights of entry (i, j) into the table's adjoint ybar[covpts + 4]; the
+// chain from (r, a, b, c, n) to the table is five numbers long and taken by the caller (grad.py).
+#include "sp_internal.h"
+#include "sp_cov.h"
+
+namespace {
+
+__device__ __forceinline__ double wsum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// upper 64 x 64 tiles <- transposes of the lower ones ([S, Kr, Kr]; grid (ntr (ntr - 1) / 2, S))
+__global__ __launch_bounds__(256) void mirror_lower_kernel(double *__restrict__ A, int Kr) {
+  __shared__ double tile[64][65];
+  const int t = blockIdx.x;
+  int ti = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f) + 1;   // strictly-lower tile index t -> (ti > tj)
+  while (ti * (ti - 1) / 2 > t) --ti;
+  while ((ti + 1) * ti / 2 <= t) ++ti;
+  const int tj = t - ti * (ti - 1) / 2;
+  double *M = A + (size_t)blockIdx.y * Kr * Kr;
+  const int c = threadIdx.x & 63, r4 = threadIdx.x >> 6;
+  for (int r = r4; r < 64; r += 4) tile[r][c] = M[(size_t)(64 * ti + r) * Kr + 64 * tj + c];
+  __syncthreads();
+  for (int r = r4; r < 64; r += 4) M[(size_t)(64 * tj + r) * Kr + 64 * ti + c] = tile[c][r];
+}
+
+// C^-1 [r, p, q, 1] per star (C^-1 symmetric: thread i sums over the ROWS j of its column, coalesced).
+// vec[s][0..3][K].  grid (Kr / 64, S)
+__global__ __launch_bounds__(256) void grad_matvec_kernel(
+    int K, int Kr, const double *__restrict__ Cinv, const double *__restrict__ flux,
+    const sp_star *__restrict__ stars, const SpCoef *__restrict__ coef, const double *__restrict__ qv,
+    int normalized, double *__restrict__ vec) {
+  __shared__ double red[4][4][64];
+  const int s = blockIdx.y, i = blockIdx.x * 64 + (threadIdx.x & 63), jq = threadIdx.x >> 6;
+  const double *Ci = Cinv + (size_t)s * Kr * Kr;
+  const double shift = coef[s].gpmean + stars[s].baseline_mean;
+  double a[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int j = jq; j < K; j += 4) {
+    const double c = Ci[(size_t)j * Kr + i];
+    const double q = normalized ? qv[(size_t)s * K + j] : 0.0;
+    a[0] += c * (flux[(size_t)s * K + j] - shift);
+    a[1] += c * (1.0 - q);
+    a[2] += c * q;
+    a[3] += c;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[k][jq][threadIdx.x & 63] = a[k];
+  __syncthreads();
+  if (jq == 0 && i < K) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      vec[((size_t)s * 4 + k) * K + i] = (red[k][0][threadIdx.x] + red[k][1][threadIdx.x]) +
+                                        (red[k][2][threadIdx.x] + red[k][3][threadIdx.x]);
+  }
+}
+
+// one workgroup per star: the dot products, lnL, the scalar adjoints and the vector w (into vec[s][1]); alpha
+// stays in vec[s][0]
+__global__ __launch_bounds__(256) void grad_scalars_kernel(
+    int K, int Kr, const double *__restrict__ Cinv, const double *__restrict__ flux,
+    const sp_star *__restrict__ stars, const SpCoef *__restrict__ coef, const double *__restrict__ qv,
+    const double *__restrict__ diag, const double *__restrict__ logdet, const int32_t *__restrict__ info,
+    int normalized, int order, double zmax, double *__restrict__ vec, double *__restrict__ lnlike,
+    double *__restrict__ meanbar, double *__restrict__ hcoef, uint32_t *__restrict__ status) {
+  __shared__ double red[12][4];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const sp_star st = stars[s];
+  const SpCoef c = coef[s];
+  const double shift = c.gpmean + st.baseline_mean;
+  double *V = vec + (size_t)s * 4 * K;
+  const double *Ci = Cinv + (size_t)s * Kr * Kr;
+  // 0 r.a  1 a.p  2 a.q  3 a.1  4 p.Cp  5 q.Cq  6 q.Cp  7 1.C1  8 a.D.a  9 tr(Cinv D)
+  double d[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = tid; i < K; i += 256) {
+    const double al = V[i], cp = V[K + i], cq = V[2 * K + i], c1v = V[3 * K + i];
+    const double q = normalized ? qv[(size_t)s * K + i] : 0.0, p = 1.0 - q;
+    const double r = flux[(size_t)s * K + i] - shift;
+    const double D = diag ? diag[(size_t)s * K + i] : st.data_var;
+    d[0] += r * al;
+    d[1] += al * p;
+    d[2] += al * q;
+    d[3] += al;
+    d[4] += p * cp;
+    d[5] += q * cq;
+    d[6] += q * cp;
+    d[7] += c1v;
+    d[8] += al * al * D;
+    d[9] += Ci[(size_t)i * Kr + i] * D;
+  }
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    const double v = wsum(d[k]);
+    if ((tid & 63) == 0) red[k][tid >> 6] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 10; ++k) d[k] = (red[k][0] + red[k][1]) + (red[k][2] + red[k][3]);
+  const double Kd = (double)K;
+  const bool bad = (info && info[s] != 0) || (normalized && c.z > zmax);
+  double c1 = 1.0, wconst = 0.0, gscale_u = 0.0, gscale_v = 0.0, mbar = d[3];
+  if (normalized) {
+    const double z = c.z, mu = c.mu, m = c.m;
+    // alpha_n(z), beta_n(z) and their derivatives (ops/norm/norm.py:26-44): f_0 = 1, f_{n+1} = f_n z (2 n + 3)
+    double f = 1.0, fp = 0.0, an = 0.0, bn = 0.0, dan = 0.0, dbn = 0.0;
+    for (int n = 0; n <= order; ++n) {
+      an += f;
+      bn += 2 * n * f;
+      dan += fp;
+      dbn += 2 * n * fp;
+      const double fn = f * z * (2 * n + 3), fpn = (2 * n + 3) * (f + z * fp);
+      f = fn;
+      fp = fpn;
+    }
+    c1 = an / (mu * mu);
+    const double ab = an + bn, s1 = z * ab, s2 = z * an, b = st.baseline_var;
+    const double A1 = 0.5 * (d[1] * d[1] - d[4]), A2 = 0.5 * (d[2] * d[2] - d[5]);
+    const double aSa = (d[0] - s1 * d[1] * d[1] + s2 * d[2] * d[2] - d[8] - b * d[3] * d[3]) / c1;
+    const double CiS = (Kd - s1 * d[4] + s2 * d[5] - d[9] - b * d[7]) / c1;
+    const double A0 = 0.5 * (aSa - CiS);
+    const double uq = 0.5 * (d[1] * d[2] - d[6]);
+    const double gq = -2.0 * (s1 * uq + s2 * A2);
+    const double kz = A0 * dan / (mu * mu) + A1 * (ab + z * (dan + dbn)) - A2 * (an + z * dan);
+    const double km = kz / (mu * mu) - gq / m;
+    mbar = -2.0 * z * kz / mu - 2.0 * A0 * an / (mu * mu * mu);
+    wconst = km / (2.0 * Kd * Kd);
+    gscale_u = -2.0 * s1 / (2.0 * Kd * m);
+    gscale_v = -2.0 * s2 / (2.0 * Kd * m);
+  }
+  // w_i = g_i / (2 K m) + kappa_m / (2 K^2),  g = -2 (s1 u + s2 v),  u = (alpha (a.p) - C^-1 p) / 2,  v likewise
+  for (int i = tid; i < K; i += 256) {
+    const double al = V[i], cp = V[K + i], cq = V[2 * K + i];
+    const double u = 0.5 * (al * d[1] - cp), v = 0.5 * (al * d[2] - cq);
+    V[K + i] = bad ? 0.0 : gscale_u * u + gscale_v * v + wconst;
+  }
+  if (tid == 0) {
+    const double ll = -0.5 * d[0] - 0.5 * logdet[s] - 0.5 * Kd * 1.8378770664093453;   // log(2 pi)
+    const bool dead = bad || !(ll == ll);
+    lnlike[s] = dead ? -INFINITY : ll;
+    meanbar[s] = dead ? 0.0 : mbar;
+    hcoef[s] = dead ? 0.0 : c1;           // (0: the scatter adds nothing for a star the likelihood rejects)
+    if (status) status[s] = ((info && info[s]) ? SP_STAR_NOT_PD : 0u) | ((normalized && c.z > zmax) ? SP_STAR_ZMAX : 0u) |
+                            ((!(ll == ll) && !bad) ? SP_STAR_NAN : 0u);
+  }
+}
+
+// scatter of H_ij T_ij c_m(x0_ij) into the table's adjoint: workgroup = (star, 64 rows), every column; the bins in
+// LDS (ds_add_f64), one partial table per workgroup (grad_bins_reduce_kernel adds them in a fixed order)
+template <int TK>
+__global__ __launch_bounds__(256) void grad_scatter_kernel(
+    int K, int Kr, const double *__restrict__ Cinv, const double *__restrict__ theta, const double *__restrict__ t,
+    const sp_star *__restrict__ stars, int covpts, const double *__restrict__ vec, const double *__restrict__ hcoef,
+    double *__restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) double bins[];   // covpts + 4
+  const int s = blockIdx.y, np = covpts + 4, tid = threadIdx.x;
+  for (int k = tid; k < np; k += 256) bins[k] = 0.0;
+  __syncthreads();
+  const int i = blockIdx.x * 64 + (tid & 63), cq = tid >> 6;
+  const double c1 = hcoef[s];
+  const sp_star st = stars[s];
+  if (i < K && c1 != 0.0) {
+    const double *V = vec + (size_t)s * 4 * K;
+    const double *Ci = Cinv + (size_t)s * Kr * Kr;
+    const double thi = theta[(size_t)s * K + i], ai = V[i], wi = V[K + i];
+    const double ti = TK != SP_TEMPORAL_NONE ? t[(size_t)s * K + i] : 0.0;
+    const double dx = 6.283185307179586 / covpts, inv_dx = 1.0 / dx;
+    for (int j = cq; j < K; j += 4) {
+      const double H = c1 * 0.5 * (ai * V[j] - Ci[(size_t)j * Kr + i]) + wi + V[K + j];
+      const double T = temporal_factor(TK, ti, TK != SP_TEMPORAL_NONE ? t[(size_t)s * K + j] : 0.0, st.tau);
+      // the segment of the lag and the position inside it: SplineGen's index (flux.py:262-265)
+      int idx;
+      double x;
+      {
+#pragma clang fp contract(off)
+        const double lag = fabs(thi - theta[(size_t)s * K + j]);
+        const double qd = lag * inv_dx;
+        idx = (int)qd;
+        x = qd - (double)idx;
+        if (fabs(x - 0.5) > 0.5 - 1.0e-9) {
+          idx = (int)floor(lag / dx);
+          x = qd - (double)idx;
+        }
+        idx = idx < 0 ? 0 : (idx > covpts ? covpts : idx);
+      }
+      // value = sum_m yp[idx + m] c_m(x):  a0 = y1, a1 = -y0/3 - y1/2 + y2 - y3/6, a2 = (y0 + y2)/2 - y1,
+      // a3 = ((y1 - y2) + (y3 - y0)/3)/2   (flux.py:322-330)
+      const double x2 = x * x, x3 = x2 * x, HT = H * T;
+      atomicAdd(&bins[idx], HT * (-x / 3.0 + 0.5 * x2 - x3 / 6.0));
+      atomicAdd(&bins[idx + 1], HT * (1.0 - 0.5 * x - x2 + 0.5 * x3));
+      atomicAdd(&bins[idx + 2], HT * (x + 0.5 * x2 - 0.5 * x3));
+      atomicAdd(&bins[idx + 3], HT * (-x / 6.0 + x3 / 6.0));
+    }
+  }
+  __syncthreads();
+  double *P = partial + ((size_t)s * gridDim.x + blockIdx.x) * np;
+  for (int k = tid; k < np; k += 256) P[k] = bins[k];
+}
+
+__global__ __launch_bounds__(256) void grad_bins_reduce_kernel(int np, int nwg, const double *__restrict__ partial,
+                                                               double *__restrict__ ybar) {
+  const int s = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= np) return;
+  double a = 0.0;
+  for (int w = 0; w < nwg; ++w) a += partial[((size_t)s * nwg + w) * np + k];
+  ybar[(size_t)s * np + k] = a;
+}
+
+}  // namespace
+
+int sp_launch_grad_sweep(int S, int K, int Kr, double *Cinv, const double *theta, const double *t,
+                         const double *flux, const sp_star *stars, const void *coef, const double *qv,
+                         const double *diag, const double *logdet, const int32_t *info, int covpts, int temporal,
+                         int normalized, int order, double zmax, double *vec, double *hcoef, double *partial,
+                         double *lnlike, double *ybar, double *meanbar, uint32_t *status, hipStream_t st) {
+  const int ntr = Kr / 64, np = covpts + 4;
+  if (ntr > 1) {
+    hipLaunchKernelGGL(mirror_lower_kernel, dim3(ntr * (ntr - 1) / 2, S), dim3(256), 0, st, Cinv, Kr);
+    SP_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(grad_matvec_kernel, dim3(ntr, S), dim3(256), 0, st, K, Kr, Cinv, flux, stars,
+                     (const SpCoef *)coef, qv, normalized, vec);
+  SP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(grad_scalars_kernel, dim3(S), dim3(256), 0, st, K, Kr, Cinv, flux, stars, (const SpCoef *)coef,
+                     qv, diag, logdet, info, normalized, order, zmax, vec, lnlike, meanbar, hcoef, status);
+  SP_LAUNCH_CHECK();
+  const size_t lds = sizeof(double) * np;
+  if (lds > 60 * 1024) return SP_ERR_INVALID;
+  dim3 grid(ntr, S);
+  if (temporal == SP_TEMPORAL_NONE)
+    hipLaunchKernelGGL((grad_scatter_kernel<SP_TEMPORAL_NONE>), grid, dim3(256), lds, st, K, Kr, Cinv, theta, t, stars,
+                       covpts, vec, hcoef, partial);
+  else if (temporal == SP_TEMPORAL_MATERN32)
+    hipLaunchKernelGGL((grad_scatter_kernel<SP_TEMPORAL_MATERN32>), grid, dim3(256), lds, st, K, Kr, Cinv, theta, t,
+                       stars, covpts, vec, hcoef, partial);
+  else if (temporal == SP_TEMPORAL_EXPSQUARED)
+    hipLaunchKernelGGL((grad_scatter_kernel<SP_TEMPORAL_EXPSQUARED>), grid, dim3(256), lds, st, K, Kr, Cinv, theta, t,
+                       stars, covpts, vec, hcoef, partial);
+  else
+    return SP_ERR_INVALID;
+  SP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(grad_bins_reduce_kernel, dim3((np + 255) / 256, S), dim3(256), 0, st, np, ntr, partial, ybar);
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}

@@ -206,6 +206,9 @@ struct sp_chol_group {
   hipStream_t st;
   LazyCov lazy;
   SpReduceArgs red;
+  int tri0 = -1;     // >= 0: the rows from this one on are an IDENTITY riding along (sp_spd_inverse_batched): row
+                     // tri0 + m is zero left of column m until the factorisation reaches it, so a launch only
+                     // takes the row tiles that hold something, and the columns beyond the matrix are never formed
 };
 
 // does the factorisation of a (K, Kp) system by this handle end in a panel launch's tail (which can carry the reduction)?
@@ -255,7 +258,15 @@ int sp_launch_panel2(int layout, const SpReduceArgs *red, double *sys, long ld, 
 // symmetric trailing update C -= X X^T (lower 64 x 64 tiles, tile (0, 0) skipped) whose tile-(0, 0)
 // workgroup factors the pivot block described by `df` (sp_paneldiag.h)
 int sp_launch_syrk_diag(const double *X, long ld, long stride, double *T, int n, int kd, int batch,
-                        hipStream_t st, const LazyCov *lazy, const DiagFuse *df);
+                        hipStream_t st, const LazyCov *lazy, const DiagFuse *df, int tj_limit = 0);
+
+// reverse sweep of the marginal-branch likelihood (sp_grad.hip): C^-1 (lower tiles in, full out) -> lnL, the table's
+// adjoint ybar [S, covpts + 4], the flux mean's adjoint [S]
+int sp_launch_grad_sweep(int S, int K, int Kr, double *Cinv, const double *theta, const double *t,
+                         const double *flux, const sp_star *stars, const void *coef, const double *qv,
+                         const double *diag, const double *logdet, const int32_t *info, int covpts, int temporal,
+                         int normalized, int order, double zmax, double *vec, double *hcoef, double *partial,
+                         double *lnlike, double *ybar, double *meanbar, uint32_t *status, hipStream_t st);
 
 // per-star scratch of the factorisation: three image slots + the chain words (sp_tile.h).  Doubles.
 static inline long sp_lt_stride(int) { return 2 * 4096L; }

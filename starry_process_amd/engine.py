@@ -347,6 +347,31 @@ class Engine(object):
         check(self._L.sp_cho_factor(self._h, self._p(Ab), K, K, K * K, B, self._p(info), self._stream()))
         return (Ab if A.dim() == 3 else Ab[0]), info
 
+    def spd_inverse(self, C, workspace=None, full=True):
+        """(C^-1, log det C, info) of symmetric positive definite C [K, K] or [B, K, K] by the factorisation's own
+        machinery (sp_spd_inverse_batched: the identity rides through the blocked Cholesky, C^-1 = L^-T L^-1 on
+        the matrix cores).  full=False returns the library's raw output: [B, Kr, Kr] (Kr = K rounded up to 64)
+        with the LOWER 64 x 64 tiles valid -- what the reverse sweep of the likelihood reads (grad.py)."""
+        torch = _torch()
+        C = self.f64(C)
+        Cb = (C if C.dim() == 3 else C.unsqueeze(0)).contiguous()
+        B, K, _ = Cb.shape
+        Kr = (K + 63) // 64 * 64
+        nbytes = int(self._L.sp_spd_inverse_workspace_bytes(self._h, B, K))
+        ws = workspace
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        out = torch.zeros(B, Kr, Kr, dtype=torch.float64, device=self.device)
+        logdet = self.empty(B)
+        info = torch.zeros(B, dtype=torch.int32, device=self.device)
+        check(self._L.sp_spd_inverse_batched(self._h, B, K, self._p(Cb), K, K * K, self._p(out), self._p(logdet),
+                                             self._p(info), self._p(ws), self._stream()))
+        if not full:
+            return out, logdet, info
+        low = torch.tril(out[:, :K, :K])
+        inv = low + torch.tril(low, -1).transpose(1, 2)
+        return (inv if C.dim() == 3 else inv[0]), (logdet if C.dim() == 3 else logdet[0]), info
+
     def cho_solve(self, L, b):
         """(L L^T)^-1 b; L [K, K] or [B, K, K]; b [K], [K, M] or [B, K, M]."""
         L = self.f64(L)
@@ -477,6 +502,31 @@ class Engine(object):
             self._p(rta1), TEMPORAL[temporal], int(bool(normalized)), int(norm_order),
             float(zmax), self._p(ws), self._p(out), self._p(status), self._stream()))
         return out, status
+
+    def lnlike_grad_marginal(self, t, flux, stars_dev, tab, meanvar, diag=None, covpts=300, temporal=None,
+                             normalized=True, norm_order=20, zmax=0.023, workspace=None):
+        """Device half of the ensemble gradient (sp_lnlike_grad_marginal): t [S, K], flux [S, K] or [S, 1, K] ->
+        (lnlike [S], ybar [S, covpts + 4], meanbar [S], status [S]): the log-likelihoods and their derivatives with
+        respect to each star's kernel table and flux mean (grad.py chains them to the hyperparameters)."""
+        torch = _torch()
+        S, K = t.shape
+        flux = flux.reshape(S, K)
+        nbytes = int(self._L.sp_lnlike_grad_workspace_bytes(self._h, S, K, int(covpts)))
+        ws = workspace
+        if ws is None or ws.numel() < nbytes:
+            ws = self._grad_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        out, ybar, mbar = self.empty(S), self.empty(S, covpts + 4), self.empty(S)
+        status = torch.zeros(S, dtype=torch.int32, device=self.device)
+        check(self._L.sp_lnlike_grad_marginal(
+            self._h, S, K, self._p(t), self._p(flux), self._p(diag), self._p(stars_dev), int(covpts), self._p(tab),
+            self._p(meanvar), TEMPORAL[temporal], int(bool(normalized)), int(norm_order), float(zmax), self._p(ws),
+            self._p(out), self._p(ybar), self._p(mbar), self._p(status), self._stream()))
+        return out, ybar, mbar, status
+
+    def grad_workspace(self, S, K, covpts):
+        torch = _torch()
+        nbytes = int(self._L.sp_lnlike_grad_workspace_bytes(self._h, S, K, int(covpts)))
+        return torch.empty(nbytes, dtype=torch.uint8, device=self.device)
 
     def cholesky_lnlike(self, cov, resid):
         """cov [S,K,K] (noise included), resid [S,M,K] -> (lnlike [S], status [S])."""

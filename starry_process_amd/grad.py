@@ -33,8 +33,9 @@ import numpy as np
 
 from .defaults import defaults
 from .engine import get_engine
+from .temporal import kernel_id
 
-__all__ = ["log_likelihood_with_grad", "hyper_gradient"]
+__all__ = ["EnsembleGradient", "ensemble_gradient", "log_likelihood_with_grad", "hyper_gradient"]
 
 _cache = {}
 
@@ -307,3 +308,147 @@ def hyper_gradient(t, flux, data_var, r=defaults["r"], dr=defaults["dr"], a=defa
         m1, S1_ = (mu, Sig) if xh == x else moments(hi["r"], hi["dr"], hi["a"], hi["b"])
         out[name] = float(gmu @ ((m1 - m0) / (xh - xl)) + np.sum(gSig * ((S1_ - S0_) / (xh - xl))))
     return lnl, out
+
+
+class EnsembleGradient(object):
+    """Log-likelihood of an ENSEMBLE of light curves and its gradient with respect to the spot hyperparameters
+    (r, a, b, c, n[, dr]) in ONE device sweep per evaluation -- what ``theano.grad`` of the summed
+    ``sp.log_likelihood`` is in the reference (tests/test_lnlike.py:100-136, calibrate/log_prob.py:53-91), for every
+    star of the batch at once.  Marginal branch, one light curve per star, scalar or per-cadence data variance.
+
+        eg = EnsembleGradient(t, flux, ferr=1e-3, p=periods)       # data -> GPU, once
+        lnl, grad = eg(r=20., a=.4, b=.27, c=.1, n=10.)             # lnl: sum over stars; grad: dict
+        eg.lnlike                                                   # per-star values of the last call
+
+    How: d lnL / dC = (alpha alpha^T - C^-1) / 2 with C^-1 from the factorisation's own machinery
+    (sp_spd_inverse_batched: the identity rides through the blocked Cholesky), pulled back on the device through the
+    normalisation and the cubic interpolation to the adjoint of each star's kernel TABLE (304 numbers) and flux mean
+    (sp_lnlike_grad_marginal).  The chain from the hyperparameters to the table is short and cheap -- moments by the
+    device quadrature, then the table kernels -- and is differentiated there: exactly in c and n (the moments are
+    mu_y = c n m, Sigma_y = c^2 n S + eps, contrast.py:21-33, and the table is linear in Sigma_y + mu_y mu_y^T), by
+    central differences of the table in r, a, b (and dr), evaluated on a second stream while the sweep runs."""
+
+    def __init__(self, t, flux, ferr=1.0e-3, p=1.0, u=None, ydeg=15, baseline_var=0.0, baseline_mean=0.0,
+                 normalized=True, covpts=None, tau=None, temporal_kernel="matern32", device=None, h=1.0e-4,
+                 upstream_kwargs=None):
+        import torch
+
+        from .engine import engine_slots, make_stars
+
+        flux = np.asarray(flux, dtype=np.float64)
+        if flux.ndim != 2:
+            raise ValueError("flux must be (S, K)")
+        S, K = flux.shape
+        if K < 2:
+            raise ValueError("at least two cadences")
+        t = np.asarray(t, dtype=np.float64)
+        t = np.broadcast_to(t, (S, K)) if t.ndim == 1 else t
+        udeg = defaults["udeg"]
+        per = lambda x: np.broadcast_to(np.asarray(x, dtype=np.float64), (S,))
+        uu = np.asarray(defaults["u"][:udeg] if u is None else u, dtype=np.float64)
+        if uu.ndim == 1:
+            utab, table = uu[None, :udeg], np.zeros(S, dtype=np.int32)
+        else:
+            utab, table = np.unique(uu[:, :udeg], axis=0, return_inverse=True)
+            table = table.astype(np.int32).reshape(-1)
+        if np.any(per(p) < -1e-6):
+            raise ValueError("p out of bounds")
+        var = np.asarray(ferr, dtype=np.float64) ** 2
+        stars = make_stars(S, period=per(p), tau=float(tau) if tau else 0.0, baseline_var=per(baseline_var),
+                           baseline_mean=per(baseline_mean), data_var=per(var) if var.ndim < 2 else 0.0, table=table)
+        (self._e, self._stream), (self._eu, self._su) = engine_slots(ydeg, udeg, device, 2)
+        e = self._e
+        self.S, self.K, self._ntab = S, K, utab.shape[0]
+        self._t, self._flux = e.f64(np.ascontiguousarray(t)), e.f64(np.ascontiguousarray(flux))
+        self._diag = e.f64(np.ascontiguousarray(np.broadcast_to(var, (S, K)))) if var.ndim == 2 else None
+        self._stars = e.stars_to_device(stars)
+        self._rta1 = e.f64(e.rTA1L(utab))
+        self._table = torch.as_tensor(table.astype(np.int64), device=e.device)
+        self._covpts = int(defaults["covpts"] if covpts is None else covpts)
+        self._temporal = (temporal_kernel if isinstance(temporal_kernel, str) else kernel_id(temporal_kernel)) if tau else None
+        self._normalized, self._h, self._ukw = bool(normalized), float(h), dict(upstream_kwargs or {})
+        self._ws = e.grad_workspace(S, K, self._covpts)
+        self.lnlike = None
+        torch.cuda.synchronize(e.device)
+
+    def _tables(self, eng, **hp):
+        """(yp [ntab, np], mean [ntab]) of the kernel tables at the given hyperparameters, on eng's stream."""
+        from .upstream_device import ylm_moments_device
+
+        mu, Sig = ylm_moments_device(eng, **hp, **self._ukw)
+        eng.set_moments_dev(mu, Sig)
+        tab, mv = eng.kernel_table(self._rta1, self._covpts)
+        return tab[:, 0, :], mv[:, 0], (mu, Sig, tab, mv)
+
+    def __call__(self, r=defaults["r"], a=defaults["a"], b=defaults["b"], c=defaults["c"], n=defaults["n"], dr=None):
+        import torch
+
+        e, eu = self._e, self._eu
+        x0 = {"r": float(r), "dr": dr, "a": float(a), "b": float(b)}
+        hp0 = dict(x0, c=float(c), n=float(n))
+        torch.cuda.synchronize(e.device)
+        # main stream: the tables at the point, then the sweep
+        with torch.cuda.stream(self._stream):
+            yp0, mean0, (mu, Sig, tab, mv) = self._tables(e, **hp0)
+            lnl, ybar, mbar, status = e.lnlike_grad_marginal(
+                self._t, self._flux, self._stars, tab, mv, diag=self._diag, covpts=self._covpts,
+                temporal=self._temporal, normalized=self._normalized, workspace=self._ws)
+        # second stream, meanwhile: the tables' derivatives
+        bounds = {"r": (0.0, 90.0), "dr": (0.0, 90.0), "a": (0.0, 1.0), "b": (0.0, 1.0)}
+        dy, dm = {}, {}
+        with torch.cuda.stream(self._su):
+            for name in ("r", "dr", "a", "b"):
+                if x0[name] is None:
+                    continue
+                x = float(x0[name])
+                step = self._h * max(abs(x), 0.1)
+                lo_b, hi_b = bounds[name]
+                xl, xh = max(x - step, lo_b), min(x + step, hi_b)        # one-sided within a step of a bound
+                yl, ml, _ = self._tables(eu, **dict(hp0, **{name: xl}))
+                yh, mh, _ = self._tables(eu, **dict(hp0, **{name: xh}))
+                dy[name], dm[name] = (yh - yl) / (xh - xl), (mh - ml) / (xh - xl)
+            # c and n, exactly: mu_y = c n m, Sigma_y = c^2 n S + eps; the second moment f = yp + mean^2 is linear in
+            # Sigma_y + mu_y mu_y^T:  f = c^2 n f_S + c^2 n^2 f_mm + f_eps,  mean = c n m1
+            ypA, meanA, (muA, SigA, _, _) = self._tables(eu, **hp0)
+            N = muA.shape[0]
+            eps = torch.full((N,), float(self._ukw.get("epsy", defaults["epsy"])), dtype=torch.float64, device=eu.device)
+            eps[15 ** 2:] = float(self._ukw.get("epsy15", defaults["epsy15"]))
+            zero_mu = torch.zeros_like(muA)
+            eu.set_moments_dev(muA, torch.zeros_like(SigA))
+            t_mm, _ = eu.kernel_table(self._rta1, self._covpts)             # f_mm part: yp = c^2 n^2 f_mm - mean^2
+            eu.set_moments_dev(zero_mu, torch.diag(eps))
+            t_eps, _ = eu.kernel_table(self._rta1, self._covpts)            # f_eps (mean 0)
+            f = ypA + meanA[:, None] ** 2
+            f_mm = t_mm[:, 0, :] + meanA[:, None] ** 2
+            f_eps = t_eps[:, 0, :]
+            f_S = f - f_mm - f_eps
+            if c != 0 and n != 0:
+                dy["c"] = 2.0 * (f - f_eps) / c - 2.0 * meanA[:, None] ** 2 / c
+                dm["c"] = meanA / c
+                dy["n"] = (f_S + 2.0 * f_mm) / n - 2.0 * meanA[:, None] ** 2 / n
+                dm["n"] = meanA / n
+            done = torch.cuda.Event()
+            done.record(self._su)
+        with torch.cuda.stream(self._stream):
+            self._stream.wait_event(done)
+            # adjoints per table: the stars that share a flux operator add up
+            Yb = torch.zeros(self._ntab, ybar.shape[1], dtype=torch.float64, device=e.device).index_add_(0, self._table, ybar)
+            Mb = torch.zeros(self._ntab, dtype=torch.float64, device=e.device).index_add_(0, self._table, mbar)
+            names = [k for k in ("r", "dr", "a", "b", "c", "n") if k in dy]
+            g = torch.stack([(Yb * dy[k]).sum() + (Mb * dm[k]).sum() for k in names]) if names else None
+            total = lnl.sum()
+        torch.cuda.synchronize(e.device)
+        self.lnlike = lnl.cpu().numpy()
+        self.status = status.cpu().numpy()
+        gv = g.cpu().numpy() if g is not None else np.zeros(0)
+        grad = {k: float(v) for k, v in zip(names, gv)}
+        if c == 0 or n == 0:
+            grad.setdefault("c", float("nan"))
+            grad.setdefault("n", float("nan"))
+        return float(total.item()), grad
+
+
+def ensemble_gradient(t, flux, ferr=1.0e-3, p=1.0, r=defaults["r"], a=defaults["a"], b=defaults["b"],
+                      c=defaults["c"], n=defaults["n"], dr=None, **kwargs):
+    """One-shot form of ``EnsembleGradient``: (sum of log-likelihoods, {"r": ., "a": ., "b": ., "c": ., "n": .})."""
+    return EnsembleGradient(t, flux, ferr=ferr, p=p, **kwargs)(r=r, a=a, b=b, c=c, n=n, dr=dr)

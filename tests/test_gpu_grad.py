@@ -206,3 +206,104 @@ def test_facade_log_likelihood_grad():
     ref = float(both.log_likelihood(st["t"], st["flux"], st["data_cov"], p=st["p"]).eval())
     assert abs(float(lnl.eval()) - ref) < 1e-9 * abs(ref)
     assert g["mean_ylm"].shape == (256,) and g["cov_ylm"].shape == (256, 256)
+
+
+# ---- the ensemble gradient (round 4): one device sweep for a batch of stars -------------------------------------
+def _ensemble(S, K, seed0=0):
+    sts = [synthetic_star(seed0 + s, K) for s in range(S)]
+    return (np.array([s["t"] for s in sts]), np.array([s["flux"] for s in sts]),
+            np.array([s["p"] for s in sts]), sts)
+
+
+@pytest.mark.parametrize("normalized", [True, False])
+def test_ensemble_gradient_equals_the_sum_of_single_star_gradients(normalized):
+    """EnsembleGradient (C^-1 by the factorisation's machinery, adjoint of the kernel table on the device) against
+    hyper_gradient star by star (the reverse-mode kernels of round 3, pinned on the oracle above): same value,
+    same gradient -- two independent routes through the chain rule."""
+    from starry_process_amd.grad import EnsembleGradient, hyper_gradient
+
+    S, K = 5, 120
+    t, flux, p, sts = _ensemble(S, K)
+    hp = dict(r=18.0, a=0.45, b=0.3, c=0.12, n=6.0)
+    eg = EnsembleGradient(t, flux, ferr=1e-3, p=p, normalized=normalized)
+    total, g = eg(**hp)
+    ref_l, ref_g = 0.0, {k: 0.0 for k in hp}
+    for s in range(S):
+        l1, g1 = hyper_gradient(t[s], flux[s], 1e-6, p=float(p[s]), normalized=normalized, **hp)
+        assert abs(eg.lnlike[s] - l1) < 1e-9 * abs(l1)
+        ref_l += l1
+        for k in hp:
+            ref_g[k] += g1[k]
+    assert abs(total - ref_l) < 1e-9 * abs(ref_l)
+    scale = max(abs(v) for v in ref_g.values())
+    for k in hp:
+        assert abs(g[k] - ref_g[k]) < 2e-6 * max(abs(ref_g[k]), 1e-3 * scale), (k, g[k], ref_g[k])
+
+
+def test_ensemble_gradient_against_finite_differences_of_the_oracle():
+    """The reference's test_lnlike_grad for a batch (tests/test_lnlike.py:100-136): d sum_s lnL_s / d(r, a, b, c, n)
+    against central differences of the ORACLE's log-likelihood on the oracle's own upstream quadrature."""
+    from starry_process_amd.grad import EnsembleGradient
+
+    S, K = 3, 100
+    t, flux, p, sts = _ensemble(S, K, seed0=7)
+    hp = dict(r=20.0, a=0.40, b=0.27, c=0.10, n=10.0)
+    eg = EnsembleGradient(t, flux, ferr=1e-3, p=p)
+    total, g = eg(**hp)
+
+    def f_of(name):
+        def f(d):
+            q = dict(hp)
+            q[name] = hp[name] + d
+            mu, Sig = _oracle_moments(q["r"], q["a"], q["b"], q["c"], q["n"])
+            return sum(_oracle_lnlike(mu, Sig, t[s], flux[s], 1e-6, p=float(p[s])) for s in range(S))
+        return f
+
+    ref0 = f_of("r")(0.0)
+    assert abs(total - ref0) < 1e-8 * abs(ref0)
+    for name, h in (("r", 1e-3), ("a", 1e-4), ("b", 1e-4), ("c", 1e-5), ("n", 1e-3)):
+        fd = _central(f_of(name), h)
+        assert abs(g[name] - fd) < 2e-5 * max(abs(fd), 1.0), (name, g[name], fd)
+
+
+def test_ensemble_gradient_cfg3_shape_and_options():
+    """cfg3's shape (64 stars, K = 1000): values equal sp_lnlike_ensemble's to 1e-9, the gradient is finite; per-
+    cadence variances, a baseline variance, two limb-darkening tables and a temporal kernel take the same path."""
+    from starry_process_amd.engine import get_engine, make_stars
+    from starry_process_amd.grad import EnsembleGradient
+    from starry_process_amd.upstream_device import ylm_moments_device
+
+    S, K = 64, 1000
+    t, flux, p, sts = _ensemble(S, K)
+    eg = EnsembleGradient(t, flux, ferr=1e-3, p=p)
+    total, g = eg()
+    e = get_engine(15, 2)
+    mu, Sig = ylm_moments_device(e)
+    e.set_moments_dev(mu, Sig)
+    rta1 = e.f64(e.rTA1L([0.0, 0.0]))
+    tab, mv = e.kernel_table(rta1, 300)
+    stars = e.stars_to_device(make_stars(S, period=p, data_var=1e-6))
+    ref, status = e.lnlike_ensemble(e.f64(t), e.f64(flux[:, None, :]), stars, tab=tab, meanvar=mv)
+    ref = ref.cpu().numpy()
+    assert not status.cpu().numpy().any() and not eg.status.any()
+    assert np.abs(eg.lnlike / ref - 1).max() < 1e-9
+    assert set(g) == {"r", "a", "b", "c", "n"} and all(np.isfinite(v) for v in g.values())
+    # options: small batch against hyper_gradient
+    from starry_process_amd.grad import hyper_gradient
+
+    S2, K2 = 3, 90
+    t2, f2, p2, _ = _ensemble(S2, K2, seed0=3)
+    var = np.linspace(1e-6, 3e-6, K2)[None, :] * np.ones((S2, 1))
+    u = np.array([[0.0, 0.0], [0.4, 0.2], [0.4, 0.2]])
+    eg2 = EnsembleGradient(t2, f2, ferr=np.sqrt(var), p=p2, u=u, baseline_var=1e-5, tau=2.0)
+    tot2, g2 = eg2(r=22.0, a=0.3, b=0.5, c=0.08, n=4.0)
+    ref_g = {k: 0.0 for k in g2}
+    for s in range(S2):
+        l1, g1 = hyper_gradient(t2[s], f2[s], var[s], p=float(p2[s]), u=u[s], baseline_var=1e-5, tau=2.0,
+                                r=22.0, a=0.3, b=0.5, c=0.08, n=4.0)
+        assert abs(eg2.lnlike[s] - l1) < 1e-9 * abs(l1)
+        for k in ref_g:
+            ref_g[k] += g1[k]
+    scale = max(abs(v) for v in ref_g.values())
+    for k in ref_g:
+        assert abs(g2[k] - ref_g[k]) < 5e-6 * max(abs(ref_g[k]), 1e-3 * scale), (k, g2[k], ref_g[k])
