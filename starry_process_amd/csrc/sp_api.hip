@@ -437,6 +437,28 @@ __global__ __launch_bounds__(256) void logdet_kernel(const double *__restrict__ 
   if (threadIdx.x == 0)
     out[blockIdx.x] = (info && info[blockIdx.x]) ? __builtin_nan("") : 2.0 * ((red[0] + red[1]) + (red[2] + red[3]));
 }
+// what sp_spd_inverse_batched needs around a K x K matrix already in the system's top-left corner: the identity in
+// the rows K .. K + Kr - 1 (columns < Kr: row K + m has its one at column m < K) and zeros in the columns K .. Kr - 1
+// of the matrix rows -- nothing else of the Kp x Kp system is ever read.  grid (ceil(Kr / 256), K + Kr, S)
+__global__ __launch_bounds__(256) void ident_rows_kernel(double *__restrict__ sys, long ld, long stride, int K, int Kr) {
+  const int i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= Kr) return;
+  double *row = sys + (size_t)blockIdx.z * stride + (size_t)i * ld;
+  if (i >= K) {
+    // (the zeros LEFT of a row's one are read too: they are the operands of the left-looking products and of the
+    //  trailing updates of the launches that take the row's tile later)
+    row[j] = (j == i - K && j < K) ? 1.0 : 0.0;
+  } else if (j >= K) {
+    row[j] = 0.0;
+  }
+}
+// K x K matrices into the top-left corners of the systems.  grid (ceil(K / 256), K, S)
+__global__ __launch_bounds__(256) void corner_copy_kernel(const double *__restrict__ A, long lda, long strideA,
+                                                          double *__restrict__ sys, long ld, long stride, int K) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j < K)
+    sys[(size_t)blockIdx.z * stride + (size_t)blockIdx.y * ld + j] = A[(size_t)blockIdx.z * strideA + (size_t)blockIdx.y * lda + j];
+}
 // columns c0 .. c1 - 1 of `rows` rows from row r0 on: zero (the columns of the last, partial pivot block beyond
 // the matrix, which the panel solve leaves undefined in the rows below)
 __global__ __launch_bounds__(256) void zero_cols_kernel(double *__restrict__ sys, long ld, long stride, int r0,
@@ -1207,22 +1229,17 @@ size_t sp_spd_inverse_workspace_bytes(sp_handle *h, int S, int K) {
 // a launch of the factorisation only takes the identity's row tiles that hold something yet, the trailing updates
 // leave the columns without pivots alone, and the product of tile (ti, tj) starts at column 64 ti --
 // K^3 (1/3 + 1/2 + 1/3) flops, against K^3 (1/3 + 1 + 1) without the structure.
-int sp_spd_inverse_batched(sp_handle *h, int S, int K, const double *C_dev, long ldc, long strideC,
-                           double *Cinv_dev, double *logdet_dev, int32_t *info_dev, void *workspace_dev,
-                           void *stream) {
-  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
-  if (!h || !C_dev || !Cinv_dev || !workspace_dev || S < 0 || K < 1 || ldc < K) return SP_ERR_INVALID;
-  if (S == 0) return SP_OK;
-  hipStream_t st = (hipStream_t)stream;
+// the inverse of the matrices ALREADY in the top-left K x K corners of the systems of `ws` (lower triangles)
+static int spd_inverse_in_place(sp_handle *h, int S, int K, const Layout &L, void *ws, double *Cinv_dev,
+                                double *logdet_dev, hipStream_t st) {
   const int Kr = sp_roundup(K, SP_NB);
-  Layout L = make_layout(h, S, K, Kr, true);
-  void *ws = workspace_dev;
   double *sys = at<double>(ws, L.sys);
   int32_t *info = at<int32_t>(ws, L.info);
   const long ld = L.Kp, stride = (long)L.Kp * L.Kp;
   int rc;
   SP_HIP(hipMemsetAsync(info, 0, sizeof(int32_t) * S, st));
-  if ((rc = sp_launch_pad_in(C_dev, K, ldc, strideC, sys, L.Kp, 0, nullptr, S, st, 1))) return rc;
+  hipLaunchKernelGGL(ident_rows_kernel, dim3((Kr + 255) / 256, K + Kr, S), dim3(256), 0, st, sys, ld, stride, K, Kr);
+  SP_LAUNCH_CHECK();
   sp_chol_group g{sys, info, at<double>(ws, L.invL), S, st, LazyCov{}, SpReduceArgs{}, K};
   if ((rc = sp_launch_cholesky_groups(h, 1, &g, K, L.Kp))) return rc;
   if (logdet_dev) {
@@ -1237,10 +1254,28 @@ int sp_spd_inverse_batched(sp_handle *h, int S, int K, const double *C_dev, long
   }
   // C^-1 = Y Y^T, lower 64 x 64 tiles, into [S, Kr, Kr]
   const double *Y = sys + (size_t)K * ld;
-  if ((rc = sp_launch_gemm_nt(Y, ld, stride, Y, ld, stride, Cinv_dev, Kr, (long)Kr * Kr, Kr, Kr, Kr, 1.0, 0, 1, S, st,
-                              2, nullptr)))
-    return rc;
-  if (info_dev) SP_HIP(hipMemcpyAsync(info_dev, info, sizeof(int32_t) * S, hipMemcpyDeviceToDevice, st));
+  return sp_launch_gemm_nt(Y, ld, stride, Y, ld, stride, Cinv_dev, Kr, (long)Kr * Kr, Kr, Kr, Kr, 1.0, 0, 1, S, st, 2,
+                           nullptr);
+}
+
+int sp_spd_inverse_batched(sp_handle *h, int S, int K, const double *C_dev, long ldc, long strideC,
+                           double *Cinv_dev, double *logdet_dev, int32_t *info_dev, void *workspace_dev,
+                           void *stream) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || !C_dev || !Cinv_dev || !workspace_dev || S < 0 || K < 1 || ldc < K) return SP_ERR_INVALID;
+  if (S == 0) return SP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int Kr = sp_roundup(K, SP_NB);
+  Layout L = make_layout(h, S, K, Kr, true);
+  void *ws = workspace_dev;
+  // the matrices into the systems' corners (nothing else of the systems is touched here)
+  hipLaunchKernelGGL(corner_copy_kernel, dim3((K + 255) / 256, K, S), dim3(256), 0, st, C_dev, ldc, strideC,
+                     at<double>(ws, L.sys), (long)L.Kp, (long)L.Kp * L.Kp, K);
+  SP_LAUNCH_CHECK();
+  int rc = spd_inverse_in_place(h, S, K, L, ws, Cinv_dev, logdet_dev, st);
+  if (rc) return rc;
+  if (info_dev)
+    SP_HIP(hipMemcpyAsync(info_dev, at<int32_t>(ws, L.info), sizeof(int32_t) * S, hipMemcpyDeviceToDevice, st));
   return SP_OK;
 }
 
@@ -1264,7 +1299,7 @@ GradLayout grad_layout(sp_handle *h, int S, int K, int covpts) {
   G.vec = take(d * (size_t)S * 4 * K);
   G.hcoef = take(d * S);
   G.logdet = take(d * S);
-  G.partial = take(d * (size_t)S * (Kr / SP_NB) * (covpts + 4));
+  G.partial = take(d * (size_t)S * ((Kr / SP_NB) * (Kr / SP_NB + 1) / 2) * (covpts + 4));
   G.total = off;
   return G;
 }
@@ -1293,7 +1328,7 @@ int sp_lnlike_grad_marginal(sp_handle *h, int S, int K, const double *t_dev, con
   void *ws = base + G.inv;
   Layout L = make_layout(h, S, K, Kr, true);
   double *theta = at<double>(ws, L.theta), *rowsum = at<double>(ws, L.rowsum), *qv = at<double>(ws, L.qv);
-  double *coef = at<double>(ws, L.coef), *Cbuf = at<double>(ws, L.raw);
+  double *coef = at<double>(ws, L.coef), *sys = at<double>(ws, L.sys);
   int32_t *info = at<int32_t>(ws, L.info);
   double *Cinv = reinterpret_cast<double *>(base + G.cinv), *vec = reinterpret_cast<double *>(base + G.vec);
   double *hcoef = reinterpret_cast<double *>(base + G.hcoef), *logdet = reinterpret_cast<double *>(base + G.logdet);
@@ -1308,10 +1343,12 @@ int sp_lnlike_grad_marginal(sp_handle *h, int S, int K, const double *t_dev, con
   if ((rc = sp_launch_norm_coef(S, K, stars_dev, meanvar_dev, nullptr, normalized, norm_order, zmax, rowsum, qv, coef,
                                 nullptr, st)))
     return rc;
-  if ((rc = sp_launch_assemble(S, K, 0, K, 0, theta, t_dev, stars_dev, covpts, tab_dev, meanvar_dev, h->d_xp, temporal,
-                               nullptr, normalized, qv, coef, diag_dev, 1, nullptr, Cbuf, K, (long)K * K, st)))
+  // (straight into the corner of the system the inverse factors: leading dimension Kp)
+  // (the LOWER tiles of the Kr x Kr corner: the system form of the assembly with no rows below the matrix)
+  if ((rc = sp_launch_assemble(S, K, 0, Kr, 1, theta, t_dev, stars_dev, covpts, tab_dev, meanvar_dev, h->d_xp, temporal,
+                               nullptr, normalized, qv, coef, diag_dev, 1, nullptr, sys, L.Kp, (long)L.Kp * L.Kp, st)))
     return rc;
-  if ((rc = sp_spd_inverse_batched(h, S, K, Cbuf, K, (long)K * K, Cinv, logdet, nullptr, ws, stream))) return rc;
+  if ((rc = spd_inverse_in_place(h, S, K, L, ws, Cinv, logdet, st))) return rc;
   return sp_launch_grad_sweep(S, K, Kr, Cinv, theta, t_dev, flux_dev, stars_dev, coef, qv, diag_dev, logdet, info,
                               covpts, temporal, normalized, norm_order, zmax, vec, hcoef, partial, lnlike_dev, ybar_dev,
                               meanbar_dev, status_dev, st);

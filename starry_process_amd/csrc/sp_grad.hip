@@ -159,8 +159,9 @@ __global__ __launch_bounds__(256) void grad_scalars_kernel(
   }
 }
 
-// scatter of H_ij T_ij c_m(x0_ij) into the table's adjoint: workgroup = (star, 64 rows), every column; the bins in
-// LDS (ds_add_f64), one partial table per workgroup (grad_bins_reduce_kernel adds them in a fixed order)
+// scatter of H_ij T_ij c_m(x0_ij) into the table's adjoint: one workgroup per LOWER 64 x 64 tile (C^-1 and H are
+// symmetric: the tiles below the diagonal count twice; the lower storage is read along its rows: coalesced), the
+// bins in LDS (ds_add_f64), one partial table per workgroup (grad_bins_reduce_kernel adds them in a fixed order)
 template <int TK>
 __global__ __launch_bounds__(256) void grad_scatter_kernel(
     int K, int Kr, const double *__restrict__ Cinv, const double *__restrict__ theta, const double *__restrict__ t,
@@ -170,7 +171,12 @@ __global__ __launch_bounds__(256) void grad_scatter_kernel(
   const int s = blockIdx.y, np = covpts + 4, tid = threadIdx.x;
   for (int k = tid; k < np; k += 256) bins[k] = 0.0;
   __syncthreads();
-  const int i = blockIdx.x * 64 + (tid & 63), cq = tid >> 6;
+  const int tile = blockIdx.x;
+  int ta = (int)((sqrtf(8.0f * tile + 1.0f) - 1.0f) * 0.5f);     // row tile (ta >= tb)
+  while (ta * (ta + 1) / 2 > tile) --ta;
+  while ((ta + 1) * (ta + 2) / 2 <= tile) ++ta;
+  const int tb = tile - ta * (ta + 1) / 2;
+  const int i = tb * 64 + (tid & 63), rq = tid >> 6;
   const double c1 = hcoef[s];
   const sp_star st = stars[s];
   if (i < K && c1 != 0.0) {
@@ -179,8 +185,10 @@ __global__ __launch_bounds__(256) void grad_scatter_kernel(
     const double thi = theta[(size_t)s * K + i], ai = V[i], wi = V[K + i];
     const double ti = TK != SP_TEMPORAL_NONE ? t[(size_t)s * K + i] : 0.0;
     const double dx = 6.283185307179586 / covpts, inv_dx = 1.0 / dx;
-    for (int j = cq; j < K; j += 4) {
-      const double H = c1 * 0.5 * (ai * V[j] - Ci[(size_t)j * Kr + i]) + wi + V[K + j];
+    const double mult = ta > tb ? 2.0 : 1.0;
+    const int jend = ta * 64 + 64 < K ? ta * 64 + 64 : K;
+    for (int j = ta * 64 + rq; j < jend; j += 4) {
+      const double H = mult * (c1 * 0.5 * (ai * V[j] - Ci[(size_t)j * Kr + i]) + wi + V[K + j]);
       const double T = temporal_factor(TK, ti, TK != SP_TEMPORAL_NONE ? t[(size_t)s * K + j] : 0.0, st.tau);
       // the segment of the lag and the position inside it: SplineGen's index (flux.py:262-265)
       int idx;
@@ -240,7 +248,7 @@ int sp_launch_grad_sweep(int S, int K, int Kr, double *Cinv, const double *theta
   SP_LAUNCH_CHECK();
   const size_t lds = sizeof(double) * np;
   if (lds > 60 * 1024) return SP_ERR_INVALID;
-  dim3 grid(ntr, S);
+  dim3 grid(ntr * (ntr + 1) / 2, S);
   if (temporal == SP_TEMPORAL_NONE)
     hipLaunchKernelGGL((grad_scatter_kernel<SP_TEMPORAL_NONE>), grid, dim3(256), lds, st, K, Kr, Cinv, theta, t, stars,
                        covpts, vec, hcoef, partial);
@@ -253,7 +261,7 @@ int sp_launch_grad_sweep(int S, int K, int Kr, double *Cinv, const double *theta
   else
     return SP_ERR_INVALID;
   SP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(grad_bins_reduce_kernel, dim3((np + 255) / 256, S), dim3(256), 0, st, np, ntr, partial, ybar);
+  hipLaunchKernelGGL(grad_bins_reduce_kernel, dim3((np + 255) / 256, S), dim3(256), 0, st, np, ntr * (ntr + 1) / 2, partial, ybar);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }

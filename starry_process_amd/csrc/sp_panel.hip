@@ -609,7 +609,9 @@ int sp_launch_panel2(int layout, const SpReduceArgs *red, double *sys, long ld, 
   {
     const long n64 = (long)S * ((ntile - j - 1) + ((a.mode & P_LOOKAHEAD) ? 1 : 0));
     // (up to an eighth over: the stragglers of a short second round cost less than the pairs' slower products)
-    a.pair = P_PAIRS && (a.mode & P_TITEMS) && 8 * n64 > 9L * P_WGS * ncu;
+    // (layout bit 1: never -- the identity riding along in sp_spd_inverse_batched keeps every launch at 17 row tiles
+    //  per star, 1.4 rounds of 64-row items, where pairs measured 114 us against 83-90)
+    a.pair = P_PAIRS && !(layout & 2) && (a.mode & P_TITEMS) && 8 * n64 > 9L * P_WGS * ncu;
   }
   const int per_star = ((a.mode & P_DITEMS) ? 1 : 0) + ((a.mode & P_TITEMS) ? panel_titems(ntile, j, a.pair) : 0) +
                        ((a.mode & P_LOOKAHEAD) ? 1 : 0);
@@ -618,7 +620,7 @@ int sp_launch_panel2(int layout, const SpReduceArgs *red, double *sys, long ld, 
   // chain-aware layout (panel_kernel): launches with a diagonal block in their tail, whole stars per XCD
   a.lay = 0; a.seq = 0;
   {
-    const int lay_on = layout;
+    const int lay_on = layout & 1;
     static std::atomic<int> seq{0};
     const int spx = S / 8;
     if (lay_on && P_PAIRS && (a.mode & P_TAILD) && S % 8 == 0 && spx >= 1 && spx <= 16 && ntile - j - 2 >= 0) {

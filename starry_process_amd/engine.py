@@ -556,7 +556,7 @@ def _want_hw_queues(streams):
     import os
     import warnings
 
-    if streams <= 3 or "GPU_MAX_HW_QUEUES" in os.environ:
+    if streams <= 4 or "GPU_MAX_HW_QUEUES" in os.environ:      # (the runtime's default is 4 queues)
         return
     torch = _torch()
     if torch.cuda.is_initialized():
