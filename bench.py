@@ -221,20 +221,26 @@ KERNEL_OF_KIND = {
 
 def rocprof_average_us(kernel_prefix):
     """Average duration of a kernel in the committed rocprofv3 kernel-trace summary of THIS round's
-    one-step-at-a-time run (profiles/r03_one_kernel_stats.csv), or None: printed beside the event
-    average so that the two can be compared; it is a file of the repository, not of this run."""
+    one-step-at-a-time run (profiles/r04_one_kernel_stats.csv), over all its template instantiations
+    (the panel kernel is one per kind of launch), or None: printed beside the event average so that the
+    two can be compared; it is a file of the repository, not of this run."""
     import csv
 
-    path = os.path.join(ROOT, "profiles", "r03_one_kernel_stats.csv")
-    if not os.path.exists(path):
-        return None, None
-    try:
-        for r in csv.DictReader(open(path)):
-            name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
-            if name.startswith(kernel_prefix):
-                return float(r["AverageNs"]) / 1e3, "profiles/r03_one_kernel_stats.csv"
-    except Exception:
-        pass
+    for name in ("r04_one_kernel_stats.csv", "r03_one_kernel_stats.csv"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        try:
+            calls = total = 0.0
+            for r in csv.DictReader(open(path)):
+                kn = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+                if kn.startswith(kernel_prefix):
+                    calls += float(r["Calls"])
+                    total += float(r["TotalDurationNs"])
+            if calls:
+                return total / calls / 1e3, "profiles/" + name
+        except Exception:
+            pass
     return None, None
 
 
@@ -286,6 +292,48 @@ def bench_shape(torch, dist, ydeg, Kc, S, tspan, tau, u, conditional, F, steps, 
            "whole_step_frac": fl / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
            "finite": bool(torch.isfinite(slots[0].out).all().item())}
     return res
+
+
+def bench_grad(torch, S, Kc, device, forward_ms):
+    """The ensemble gradient d sum_s lnL_s / d(r, a, b, c, n) at cfg3's shape (grad.EnsembleGradient: one device
+    sweep for the whole batch -- C^-1 by the factorisation's machinery, the kernel table's adjoint on the device),
+    never in `value`.  Algorithmic work of the sweep: S K^3 flop (factorisation K^3/3 + triangular inverse K^3/3 +
+    L^-T L^-1 K^3/3)."""
+    from starry_process_amd.grad import EnsembleGradient
+    from starry_process_amd.synthetic import synthetic_star
+    from starry_process_amd.upstream_device import ylm_moments_device
+
+    sts = [synthetic_star(s, Kc) for s in range(S)]
+    eg = EnsembleGradient(np.array([s["t"] for s in sts]), np.array([s["flux"] for s in sts]), ferr=1e-3,
+                          p=np.array([s["p"] for s in sts]), device=device)
+    for k in range(3):
+        total, g = eg()
+    n = 10
+    t1 = time.perf_counter()
+    for k in range(n):
+        total, g = eg(r=20.0 + 0.01 * k)
+    ms_call = 1e3 * (time.perf_counter() - t1) / n
+    e = eg._e
+    mu, Sig = ylm_moments_device(e)
+    e.set_moments_dev(mu, Sig)
+    tab, mv = e.kernel_table(eg._rta1, COVPTS)
+    for _ in range(3):
+        e.lnlike_grad_marginal(eg._t, eg._flux, eg._stars, tab, mv, workspace=eg._ws)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(n):
+        e.lnlike_grad_marginal(eg._t, eg._flux, eg._stars, tab, mv, workspace=eg._ws)
+    torch.cuda.synchronize()
+    ms_sweep = 1e3 * (time.perf_counter() - t1) / n
+    fl = S * float(Kc) ** 3
+    return {"stars": S, "K": Kc, "ms_per_gradient": ms_call, "device_sweep_ms": ms_sweep,
+            "gradients_per_s": 1e3 / ms_call, "star_gradients_per_s": S * 1e3 / ms_call,
+            "sweep_over_forward": ms_sweep / forward_ms if forward_ms else None,
+            "call_over_forward": ms_call / forward_ms if forward_ms else None,
+            "sweep_TFLOPs": fl / (ms_sweep * 1e-3) / 1e12, "sweep_frac": fl / (ms_sweep * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+            "lnlike_sum": total, "gradient": g,
+            "note": "d sum lnL / d(r, a, b, c, n), one call for the batch; forward = one step at a time "
+                    "(one_step_at_a_time.ms_per_step); sweep flops S K^3 (factor + triangular inverse + L^-T L^-1)"}
 
 
 def _free_port():
@@ -692,6 +740,7 @@ def main():
             extras["cfg3_conditional"] = bench_shape(torch, dist, ydeg=15, Kc=1000, S=64, tspan=4.0, tau=None,
                                                      u=(0.0, 0.0), conditional=True, F=F, steps=24,
                                                      device=local_rank)
+            extras["cfg3_grad"] = bench_grad(torch, S, K, local_rank, one["ms_per_step"] if one else None)
         except Exception as exc:   # (never lose the headline over an extra)
             extras["error"] = repr(exc)
 
@@ -722,7 +771,7 @@ def main():
         cand = {k: v for k, v in timed_prof.items() if v["launches"] > 0}
         dom = max(cand, key=lambda k: cand[k]["ms"]) if cand else "syrk"
         traffic = traffic_source = None
-        for name in ("r03_step_traffic.json", "r02_step_traffic.json"):
+        for name in ("r04_step_traffic.json", "r03_step_traffic.json", "r02_step_traffic.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 try:
