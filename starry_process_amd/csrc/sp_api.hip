@@ -441,15 +441,19 @@ __global__ __launch_bounds__(256) void logdet_kernel(const double *__restrict__ 
 // the rows K .. K + Kr - 1 (columns < Kr: row K + m has its one at column m < K) and zeros in the columns K .. Kr - 1
 // of the matrix rows -- nothing else of the Kp x Kp system is ever read.  grid (ceil(Kr / 256), K + Kr, S)
 __global__ __launch_bounds__(256) void ident_rows_kernel(double *__restrict__ sys, long ld, long stride, int K, int Kr) {
-  const int i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= Kr) return;
-  double *row = sys + (size_t)blockIdx.z * stride + (size_t)i * ld;
+  // one wavefront per row, 16 bytes per lane and pass (Kr is a multiple of 64, the rows 16-byte aligned: ld even)
+  typedef double v2 __attribute__((ext_vector_type(2)));
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= K + Kr) return;
+  double *row = sys + (size_t)blockIdx.y * stride + (size_t)i * ld;
   if (i >= K) {
     // (the zeros LEFT of a row's one are read too: they are the operands of the left-looking products and of the
     //  trailing updates of the launches that take the row's tile later)
-    row[j] = (j == i - K && j < K) ? 1.0 : 0.0;
-  } else if (j >= K) {
-    row[j] = 0.0;
+    const int one = i - K < K ? i - K : -1;
+    for (int j = 2 * lane; j < Kr; j += 128)
+      *reinterpret_cast<v2 *>(row + j) = v2{j == one ? 1.0 : 0.0, j + 1 == one ? 1.0 : 0.0};
+  } else {
+    for (int j = K + lane; j < Kr; j += 64) row[j] = 0.0;
   }
 }
 // K x K matrices into the top-left corners of the systems.  grid (ceil(K / 256), K, S)
@@ -1238,7 +1242,7 @@ static int spd_inverse_in_place(sp_handle *h, int S, int K, const Layout &L, voi
   const long ld = L.Kp, stride = (long)L.Kp * L.Kp;
   int rc;
   SP_HIP(hipMemsetAsync(info, 0, sizeof(int32_t) * S, st));
-  hipLaunchKernelGGL(ident_rows_kernel, dim3((Kr + 255) / 256, K + Kr, S), dim3(256), 0, st, sys, ld, stride, K, Kr);
+  hipLaunchKernelGGL(ident_rows_kernel, dim3((K + Kr + 3) / 4, S), dim3(256), 0, st, sys, ld, stride, K, Kr);
   SP_LAUNCH_CHECK();
   sp_chol_group g{sys, info, at<double>(ws, L.invL), S, st, LazyCov{}, SpReduceArgs{}, K};
   if ((rc = sp_launch_cholesky_groups(h, 1, &g, K, L.Kp))) return rc;
@@ -1299,7 +1303,11 @@ GradLayout grad_layout(sp_handle *h, int S, int K, int covpts) {
   G.vec = take(d * (size_t)S * 4 * K);
   G.hcoef = take(d * S);
   G.logdet = take(d * S);
-  G.partial = take(d * (size_t)S * ((Kr / SP_NB) * (Kr / SP_NB + 1) / 2) * (covpts + 4));
+  {
+    // the scatter's bins per lower tile; before that, the row parts of the products with C^-1 ([S][ntr][4][K])
+    const size_t ntr = Kr / SP_NB, bins = ntr * (ntr + 1) / 2 * (covpts + 4), rows = ntr * 4 * (size_t)K;
+    G.partial = take(d * (size_t)S * (bins > rows ? bins : rows));
+  }
   G.total = off;
   return G;
 }
