@@ -219,13 +219,21 @@ __global__ __launch_bounds__(256) void grad_scatter_kernel(
   for (int k = tid; k < np; k += 256) P[k] = bins[k];
 }
 
+// ybar[s][k] = sum over the tiles' partial tables, in a fixed order: thread (k, g) adds the partials w = g, g + 4, ...,
+// the four groups are added in order.  grid (ceil(np / 64), S)
 __global__ __launch_bounds__(256) void grad_bins_reduce_kernel(int np, int nwg, const double *__restrict__ partial,
                                                                double *__restrict__ ybar) {
-  const int s = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= np) return;
+  __shared__ double red[4][64];
+  const int s = blockIdx.y, k = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
   double a = 0.0;
-  for (int w = 0; w < nwg; ++w) a += partial[((size_t)s * nwg + w) * np + k];
-  ybar[(size_t)s * np + k] = a;
+  if (k < np) {
+#pragma unroll 4
+    for (int w = g; w < nwg; w += 4) a += partial[((size_t)s * nwg + w) * np + k];
+  }
+  red[g][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (g == 0 && k < np)
+    ybar[(size_t)s * np + k] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 }  // namespace
@@ -261,7 +269,7 @@ int sp_launch_grad_sweep(int S, int K, int Kr, double *Cinv, const double *theta
   else
     return SP_ERR_INVALID;
   SP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(grad_bins_reduce_kernel, dim3((np + 255) / 256, S), dim3(256), 0, st, np, ntr * (ntr + 1) / 2, partial, ybar);
+  hipLaunchKernelGGL(grad_bins_reduce_kernel, dim3((np + 63) / 64, S), dim3(256), 0, st, np, ntr * (ntr + 1) / 2, partial, ybar);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }
