@@ -307,3 +307,30 @@ def test_ensemble_gradient_cfg3_shape_and_options():
     scale = max(abs(v) for v in ref_g.values())
     for k in ref_g:
         assert abs(g2[k] - ref_g[k]) < 5e-6 * max(abs(ref_g[k]), 1e-3 * scale), (k, g2[k], ref_g[k])
+
+
+def test_ensemble_gradient_spread_of_radii_and_rejected_stars():
+    """dr joins the gradient when a spread of radii is given (against hyper_gradient); an evaluation the likelihood
+    rejects (z > normalization_zmax, sp.py:1178-1183) returns -inf for those stars, flags them, and they add nothing
+    to the gradient -- no NaN reaches the caller."""
+    from starry_process_amd.grad import EnsembleGradient, hyper_gradient
+
+    S, K = 3, 100
+    t, flux, p, _ = _ensemble(S, K, seed0=11)
+    eg = EnsembleGradient(t, flux, ferr=1e-3, p=p)
+    hp = dict(r=22.0, dr=4.0, a=0.35, b=0.4, c=0.1, n=8.0)
+    total, g = eg(**hp)
+    assert set(g) == {"r", "dr", "a", "b", "c", "n"}
+    ref = {k: 0.0 for k in g}
+    for s in range(S):
+        l1, g1 = hyper_gradient(t[s], flux[s], 1e-6, p=float(p[s]), **hp)
+        assert abs(eg.lnlike[s] - l1) < 1e-9 * abs(l1)
+        for k in ref:
+            ref[k] += g1[k]
+    scale = max(abs(v) for v in ref.values())
+    for k in ref:
+        assert abs(g[k] - ref[k]) < 5e-6 * max(abs(ref[k]), 1e-3 * scale), (k, g[k], ref[k])
+    # a contrast for which the normalisation's expansion parameter is out of range: every star is rejected
+    total, g = eg(r=20.0, a=0.4, b=0.27, c=0.9, n=20.0)
+    assert total == -np.inf and np.all(eg.lnlike == -np.inf) and np.all(eg.status & 2)
+    assert all(v == 0.0 for v in g.values())
