@@ -326,7 +326,7 @@ class EnsembleGradient(object):
     (sp_lnlike_grad_marginal).  The chain from the hyperparameters to the table is short and cheap -- moments by the
     device quadrature, then the table kernels -- and is differentiated there: exactly in c and n (the moments are
     mu_y = c n m, Sigma_y = c^2 n S + eps, contrast.py:21-33, and the table is linear in Sigma_y + mu_y mu_y^T), by
-    central differences of the table in r, a, b (and dr), evaluated on a second stream while the sweep runs."""
+    central differences of the table in r, a, b (and dr), evaluated on three more streams while the sweep runs."""
 
     def __init__(self, t, flux, ferr=1.0e-3, p=1.0, u=None, ydeg=15, baseline_var=0.0, baseline_mean=0.0,
                  normalized=True, covpts=None, tau=None, temporal_kernel="matern32", device=None, h=1.0e-4,
@@ -356,7 +356,11 @@ class EnsembleGradient(object):
         var = np.asarray(ferr, dtype=np.float64) ** 2
         stars = make_stars(S, period=per(p), tau=float(tau) if tau else 0.0, baseline_var=per(baseline_var),
                            baseline_mean=per(baseline_mean), data_var=per(var) if var.ndim < 2 else 0.0, table=table)
-        (self._e, self._stream), (self._eu, self._su) = engine_slots(ydeg, udeg, device, 2)
+        # the sweep's handle + three more for the tables' finite differences: a table evaluation is a latency chain
+        # of a dozen small kernels (0.3 ms); nine of them in a row on ONE stream outlast the sweep they should hide
+        # behind (3.2 against 2.5 ms), three streams of three do not
+        slots = engine_slots(ydeg, udeg, device, 4)
+        (self._e, self._stream), self._side = slots[0], slots[1:]
         e = self._e
         self.S, self.K, self._ntab = S, K, utab.shape[0]
         self._t, self._flux = e.f64(np.ascontiguousarray(t)), e.f64(np.ascontiguousarray(flux))
@@ -383,7 +387,7 @@ class EnsembleGradient(object):
     def __call__(self, r=defaults["r"], a=defaults["a"], b=defaults["b"], c=defaults["c"], n=defaults["n"], dr=None):
         import torch
 
-        e, eu = self._e, self._eu
+        e = self._e
         x0 = {"r": float(r), "dr": dr, "a": float(a), "b": float(b)}
         hp0 = dict(x0, c=float(c), n=float(n))
         torch.cuda.synchronize(e.device)
@@ -393,20 +397,33 @@ class EnsembleGradient(object):
             lnl, ybar, mbar, status = e.lnlike_grad_marginal(
                 self._t, self._flux, self._stars, tab, mv, diag=self._diag, covpts=self._covpts,
                 temporal=self._temporal, normalized=self._normalized, workspace=self._ws)
-        # second stream, meanwhile: the tables' derivatives
+        # three more streams, meanwhile: the tables' derivatives
         bounds = {"r": (0.0, 90.0), "dr": (0.0, 90.0), "a": (0.0, 1.0), "b": (0.0, 1.0)}
-        dy, dm = {}, {}
-        with torch.cuda.stream(self._su):
-            for name in ("r", "dr", "a", "b"):
-                if x0[name] is None:
-                    continue
-                x = float(x0[name])
-                step = self._h * max(abs(x), 0.1)
-                lo_b, hi_b = bounds[name]
-                xl, xh = max(x - step, lo_b), min(x + step, hi_b)        # one-sided within a step of a bound
-                yl, ml, _ = self._tables(eu, **dict(hp0, **{name: xl}))
-                yh, mh, _ = self._tables(eu, **dict(hp0, **{name: xh}))
-                dy[name], dm[name] = (yh - yl) / (xh - xl), (mh - ml) / (xh - xl)
+        dy, dm, events = {}, {}, []
+
+        def central(eng, name):
+            x = float(x0[name])
+            step = self._h * max(abs(x), 0.1)
+            lo_b, hi_b = bounds[name]
+            xl, xh = max(x - step, lo_b), min(x + step, hi_b)        # one-sided within a step of a bound
+            yl, ml, _ = self._tables(eng, **dict(hp0, **{name: xl}))
+            yh, mh, _ = self._tables(eng, **dict(hp0, **{name: xh}))
+            dy[name], dm[name] = (yh - yl) / (xh - xl), (mh - ml) / (xh - xl)
+
+        (e1, s1), (e2, s2), (e3, s3) = self._side
+        with torch.cuda.stream(s1):
+            central(e1, "r")
+            if x0["dr"] is not None:
+                central(e1, "dr")
+            events.append(torch.cuda.Event())
+            events[-1].record(s1)
+        with torch.cuda.stream(s2):
+            central(e2, "a")
+            central(e2, "b")
+            events.append(torch.cuda.Event())
+            events[-1].record(s2)
+        with torch.cuda.stream(s3):
+            eu = e3
             # c and n, exactly: mu_y = c n m, Sigma_y = c^2 n S + eps; the second moment f = yp + mean^2 is linear in
             # Sigma_y + mu_y mu_y^T:  f = c^2 n f_S + c^2 n^2 f_mm + f_eps,  mean = c n m1
             ypA, meanA, (muA, SigA, _, _) = self._tables(eu, **hp0)
@@ -427,10 +444,11 @@ class EnsembleGradient(object):
                 dm["c"] = meanA / c
                 dy["n"] = (f_S + 2.0 * f_mm) / n - 2.0 * meanA[:, None] ** 2 / n
                 dm["n"] = meanA / n
-            done = torch.cuda.Event()
-            done.record(self._su)
+            events.append(torch.cuda.Event())
+            events[-1].record(s3)
         with torch.cuda.stream(self._stream):
-            self._stream.wait_event(done)
+            for ev in events:
+                self._stream.wait_event(ev)
             # adjoints per table: the stars that share a flux operator add up
             Yb = torch.zeros(self._ntab, ybar.shape[1], dtype=torch.float64, device=e.device).index_add_(0, self._table, ybar)
             Mb = torch.zeros(self._ntab, dtype=torch.float64, device=e.device).index_add_(0, self._table, mbar)

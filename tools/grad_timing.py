@@ -65,7 +65,7 @@ print("forward step (moments -> table -> lnL of %d stars), one at a time:   %.3f
 print("ensemble gradient, device sweep alone (C, C^-1, adjoints):           %.3f ms  = %.2f x forward; "
       "%.1f TFLOP/s of the 3.5 K^3/3 flops of factor + triangular inverse + L^-T L^-1" %
       (ms_sweep, ms_sweep / ms_fwd, 3.5 * fl / (ms_sweep * 1e-3) / 1e12))
-print("ensemble gradient, whole call (tables, 6 finite-difference tables on a second stream, sweep): %.3f ms = %.2f x forward"
+print("ensemble gradient, whole call (tables, nine table evaluations on three more streams, sweep): %.3f ms = %.2f x forward"
       % (ms_grad, ms_grad / ms_fwd))
 print("round 3: hyper_gradient, ONE star per call:                          %.3f ms  (x %d stars = %.0f ms)" % (ms_one, S, ms_one * S))
 print("gradient:", {k: float("%.6g" % v) for k, v in g.items()}, " lnL = %.6f" % total)
