@@ -860,11 +860,12 @@ def main():
             "other_shapes": extras,
             "roofline": roof,
         }
-        if world > 1:
+        if use_dist:      # (N > 1, or SP_BENCH_FORCE_DIST=1: the same code path with one RCCL rank)
             line["per_rank_ms_per_step"] = per_rank
             if allgather:
                 allgather["share_of_step"] = allgather["avg_ms"] / ms_per_step
             line["allgather"] = allgather
+        if world > 1:
             line["cpu_baseline"] = "N = 1 only (rank 0 would hold the other ranks up; see the N = 1 line)"
             roof["measured"] += "; N > 1: no one-at-a-time leg (`alone` figures are the N = 1 line's), " \
                                 "whole_step is per GPU over the job's ms_per_step"
