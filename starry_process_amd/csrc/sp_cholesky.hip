@@ -269,7 +269,7 @@ static int cholesky_panel2(sp_handle *h, int ngroups, const sp_chol_group *grp, 
           sp_scope.add(fl, nl);
           int rc = SP_OK;
           if (d_alone)
-            rc = sp_launch_panel2(h->panel_layout | (tri0 >= 0 ? 2 : 0), nullptr, G.sys, ld, stride, G.S, ntile, j, s0, nact_of(j), 0, last, SP_PANEL_D,
+            rc = sp_launch_panel2(h->panel_layout | (tri0 >= 0 ? (2 | (tri0 << 8)) : 0), nullptr, G.sys, ld, stride, G.S, ntile, j, s0, nact_of(j), 0, last, SP_PANEL_D,
                                   h->ncu, G.invL, lts, G.info, G.st, nullptr);
           const int what = rows > 0 ? (SP_PANEL_T | (tail ? SP_PANEL_TAILD : 0) | (la ? SP_PANEL_LA : 0) |
                                        (first_la ? SP_PANEL_FIRSTLA : 0))
@@ -277,7 +277,7 @@ static int cholesky_panel2(sp_handle *h, int ngroups, const sp_chol_group *grp, 
           // (the launch whose tail factors the LAST pivot block carries the reduction, if there is one)
           const SpReduceArgs *red = (tail && j + 1 == nsteps - 1 && fuse_reduce) ? &G.red : nullptr;
           if (rc == SP_OK && what)
-            rc = sp_launch_panel2(h->panel_layout | (tri0 >= 0 ? 2 : 0), red, G.sys, ld, stride, G.S, ntile, j, s0, nact_of(j), tail ? nact_of(j + 1) : 0,
+            rc = sp_launch_panel2(h->panel_layout | (tri0 >= 0 ? (2 | (tri0 << 8)) : 0), red, G.sys, ld, stride, G.S, ntile, j, s0, nact_of(j), tail ? nact_of(j + 1) : 0,
                                   last, what, h->ncu, G.invL, lts, G.info, G.st, lzp);
           if (rc != SP_OK) return rc;
         }
@@ -292,7 +292,7 @@ static int cholesky_panel2(sp_handle *h, int ngroups, const sp_chol_group *grp, 
         const sp_chol_group &G = grp[g];
         LazyCov lzv = G.lazy;
         lzv.tr0 = lzv.tc0 = jE;
-        DiagFuse df{G.sys, ld, stride, jE, nact_of(jE), G.invL, lts, G.info};
+        DiagFuse df{G.sys, ld, stride, jE, nact_of(jE), G.invL, lts, G.info, tri0, s0};
         SpProfScope prof(h, G.st, SP_PROF_SYRK, (double)G.S * (double)n * (n + 1) * kd);
         int rc = sp_launch_syrk_diag(G.sys + (size_t)cE * ld + cS, ld, stride, G.sys + (size_t)cE * ld + cE,
                                      n, kd, G.S, G.st, (G.lazy.theta && s0 == 0) ? &lzv : nullptr, &df, tj_limit);

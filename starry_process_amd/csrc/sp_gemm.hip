@@ -141,7 +141,14 @@ __global__ __launch_bounds__(256) void mm_nt_kernel(
   // inverse factor, sp_spd_inverse_batched): the product of tile (ti, tj), ti >= tj, starts at column TM ti;
   // bits 8.. -- tile columns from this one on are not wanted (the rows below a factorisation that carry no
   // pivot: their columns are never read)
-  const int tj_limit = skip00 >> 8, k_first = (skip00 & 2) ? ti * TM : 0;
+  const int tj_limit = skip00 >> 8;
+  int k_first = (skip00 & 2) ? ti * TM : 0;
+  if (df.tri0 >= 0 && TM == 64) {
+    // the trailing update with an identity riding along: the rows of tile df.j + ti are zero left of column block
+    // (64 (df.j + ti) - tri0) / 64 -- the product over the super-panel's blocks s0 .. starts there
+    const int r = 64 * (df.j + ti) - df.tri0, first = r > 0 ? r / 64 - df.s0 : 0;
+    if (first > 0) k_first = 64 * first < Kd ? 64 * first : Kd;
+  }
   if (tj_limit && tj >= tj_limit) return;
   if ((skip00 & 1) && lower_only && ti == 0 && tj == 0) {
     // tile (0, 0) -- the next pivot block -- carries every update already (the panel kernels keep it
@@ -219,7 +226,7 @@ int mm_launch(const double *A, long lda, long strideA, const double *B, long ldb
               int lower_only, int batch, hipStream_t st, int skip00, const LazyCov *lazy = nullptr,
               const DiagFuse *dfp = nullptr) {
   const LazyCov lz = lazy ? *lazy : LazyCov{};
-  const DiagFuse df = dfp ? *dfp : DiagFuse{nullptr, 0, 0, 0, 0, nullptr, 0, nullptr};
+  const DiagFuse df = dfp ? *dfp : DiagFuse{nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, -1, 0};
   const int ntm = Mrows / Core::TM_, ntn = Nrows / Core::TN_;
   const int ntiles = lower_only ? ntm * (ntm + 1) / 2 : ntm * ntn;
   const long nblk = sp_xcd_grid(batch, ntiles);

@@ -122,6 +122,8 @@ struct PanelArgs {
   int pair;            // row tiles below the next pivot row tile are dealt in pairs (128-row items)
   int lay;             // 1: chain-aware layout of the launch (see panel_kernel)
   int seq;             // launch number (tags the chain workgroups' words in the stars' scratch)
+  int tri0;            // >= 0: the rows from this one on are an identity riding along (sp_spd_inverse_batched): row tile T
+                       // is zero left of column block (64 T - tri0) / 64, and the product of its item starts there
   double *img;         // per star `lts` doubles: three image slots + the chain words (sp_tile.h)
   long lts;
   int32_t *info;
@@ -461,6 +463,14 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
 //                                            the chain's fixed CU mate -- the blocks of the second super-panel,
 //                                            which have their CU to themselves otherwise, go from 14 to 17-20 us.)
 // Nobody waits for a sleeper and the chain waits for nobody: only time is at stake.
+// first column block of a row tile's left-looking product: the super-panel's first, or -- an identity riding along
+// -- the first one in which the tile holds anything (what lies left of it is zero: nothing to multiply)
+__device__ __forceinline__ int tri_first_block(const PanelArgs &a, int row_tile) {
+  if (a.tri0 < 0) return a.s0;
+  const int first = 64 * row_tile > a.tri0 ? (64 * row_tile - a.tri0) / 64 : 0;
+  return first > a.s0 ? first : a.s0;
+}
+
 __device__ __forceinline__ unsigned long long *chain_words(double *img_star) {
   return reinterpret_cast<unsigned long long *>(img_star + SP_IMG_WORDS);   // [0] seq << 32 | CU key, [1] seq when done
 }
@@ -533,7 +543,8 @@ __global__ __launch_bounds__(256, P_WGS) void panel_kernel(PanelArgs a) {
     // (one call site for the launch's other items: what differs between a row tile's item and the look-ahead
     //  item is data -- three inlined copies of the item cost the instantiation its registers)
     const bool la = idx >= nsingle;
-    panel_tile_item<1, LAZY, false, false>(a, M, mtx, la ? a.j + 2 : a.j + 2 + idx, la ? a.j + 1 : a.j, a.s0, a.j, la,
+    const int it = la ? a.j + 2 : a.j + 2 + idx;
+    panel_tile_item<1, LAZY, false, false>(a, M, mtx, it, la ? a.j + 1 : a.j, tri_first_block(a, it), a.j, la,
                                            true, img_star, smem, tid);
     return;
   }
@@ -569,7 +580,7 @@ __global__ __launch_bounds__(256, P_WGS) void panel_kernel(PanelArgs a) {
     if (t == 0)
       panel_tile_item<1, LAZY, RED, true>(a, M, mtx, i0, a.j, fla ? a.j - 1 : a.s0, a.j, false, !fla, img_star, smem, tid);
     else
-      panel_tile_item<1, LAZY, false, false>(a, M, mtx, i0, a.j, a.s0, a.j, false, true, img_star, smem, tid);
+      panel_tile_item<1, LAZY, false, false>(a, M, mtx, i0, a.j, tri_first_block(a, i0), a.j, false, true, img_star, smem, tid);
   } else {
     // look-ahead: tile (j + 2, j + 1) with the column blocks s0 .. j - 1
     panel_tile_item<1, LAZY, false, false>(a, M, mtx, a.j + 2, a.j + 1, a.s0, a.j, true, true, img_star, smem, tid);
@@ -593,6 +604,7 @@ int sp_launch_panel2(int layout, const SpReduceArgs *red, double *sys, long ld, 
            ((what & SP_PANEL_TAILD) ? P_TAILD : 0) | ((what & SP_PANEL_LA) ? P_LOOKAHEAD : 0) |
            ((what & SP_PANEL_FIRSTLA) ? P_FIRSTLA : 0);
   a.img = img; a.lts = lts; a.info = info;
+  a.tri0 = (layout & 2) ? (layout >> 8) : -1;     // (layout bits 8..: the identity's first row, see bit 1)
   a.lz = lazy ? *lazy : LazyCov{};
   a.red = red ? *red : SpReduceArgs{};
   if (a.red.lnlike && !(a.mode & P_TAILD)) return SP_ERR_INVALID;

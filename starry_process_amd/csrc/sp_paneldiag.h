@@ -39,6 +39,8 @@ struct DiagFuse {
   double *img;       // per-star scratch (lts doubles apart); slot j mod 3 receives the image (sp_tile.h)
   long lts;
   int32_t *info;
+  int tri0 = -1;     // >= 0: an identity rides along from this row on (sp_spd_inverse_batched): row tile j + ti of the
+  int s0 = 0;        // update holds nothing left of column block (64 (j + ti) - tri0) / 64; s0: the product's first block
 };
 
 // lds: SP_DIAG_LDS_DOUBLES doubles, free for the whole call.  All 256 threads.
