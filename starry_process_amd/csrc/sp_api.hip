@@ -47,7 +47,6 @@ int sp_launch_defer_finish(int S, int K, int M, int Kp, const sp_star *stars, co
                            double *rowsum, hipStream_t st);
 int sp_launch_cholesky_systems(sp_handle *h, double *sys, int S, int K, int Kp,
                                int32_t *info, double *invL, hipStream_t st);
-int sp_launch_cond_pad_rows(double *A, int S, int K, int Kr, int N, hipStream_t st);
 int sp_launch_cond_system(const double *B1, const double *A, int N, int Kr, int S, int K, int M, int Kp,
                           const double *t, const sp_star *stars, int temporal, const void *coef,
                           const double *diag, const double *flux, double *sys, double *part,
@@ -104,35 +103,94 @@ __global__ __launch_bounds__(256) void cond_prep_kernel(
   v[(size_t)s * N + n] = acc;
 }
 
-// f[s][k][n] = v[s][n] cos(m th) + v[s][mirror n] sin(m th)   (wigner.h:289-339)
-__global__ __launch_bounds__(256) void cond_rz_kernel(
-    int ydeg, int N, int K, int Kr, const int32_t *__restrict__ m_of,
-    const int32_t *__restrict__ mirror, const double *__restrict__ v,
-    const double *__restrict__ theta, double *__restrict__ f) {
-  __shared__ double cn[SP_MAX_YDEG + 1], sn[SP_MAX_YDEG + 1];
-  const int k = blockIdx.x, s = blockIdx.y;
-  if (threadIdx.x == 0) {
-    double s1, c1;
-    sincos(theta[(size_t)s * K + k], &s1, &c1);
-    cn[0] = 1.0;
-    sn[0] = 0.0;
-    if (ydeg >= 1) {
-      cn[1] = c1;
-      sn[1] = s1;
+// The design matrix in ONE kernel, on the matrix cores (flux.py:278-281, 88-105; round 4): row k of star s is
+//     A[s][k] = (v[s] o Rz(theta_k)) . blockdiag(Rx(pi/2)),     v[s] = rTA1 . Rx(-inc_s)  (cond_prep_kernel),
+// a function of theta_k alone, so the K x N intermediate of rounds 1-3 (a phase-rotation kernel's output: written,
+// padded, read back by two 190 us launches of dotrx_kernel with one 256-thread workgroup PER ROW) never exists.
+// A workgroup takes 64 rows of a star, a wavefront 16 of them: per degree l the (16 x w)(w x w) product, w = 2 l + 1,
+// as ceil(w / 16) x ceil(w / 4) v_mfma_f64_16x16x4_f64 -- the A fragments are formed on the fly from v and the
+// row's cos / sin table (the Chebyshev recurrence of wigner.h:305-316, one thread per row), the B fragments come
+// from the packed rotation in LDS (RLDS; from L2 for degrees whose NWIG doubles do not fit).  A first form on the
+// vector ALU (thread = output column, 8 rows per workgroup) spent 178 us on its LDS reads -- w x 9 of them for
+// 8 w multiply-adds; this one needs two per 64.  Rows K .. Kr - 1 are zero.
+typedef double cd_d4 __attribute__((ext_vector_type(4)));
+template <bool RLDS>
+__global__ __launch_bounds__(256) void cond_design_kernel(
+    int ydeg, int N, int nwig, int K, int Kr, const double *__restrict__ v, const double *__restrict__ theta,
+    const double *__restrict__ Rpk, double *__restrict__ A) {
+  extern __shared__ __attribute__((aligned(16))) double cd_lds[];
+  const int nc = ydeg + 1;
+  double *sV = cd_lds;                       // N
+  double *sC = sV + N;                       // 64 x nc: cos(m theta_row)
+  double *sS = sC + 64 * nc;                 // 64 x nc: sin
+  double *sR = sS + 64 * nc;                 // nwig (RLDS)
+  const int s = blockIdx.y, r0 = blockIdx.x * 64, tid = threadIdx.x;
+  if (RLDS) {
+    // (batches of eight loads per thread, all in flight before the first store)
+    for (int e0 = 0; e0 < nwig; e0 += 8 * 256) {
+      double tmp[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 256 * u + tid;
+        tmp[u] = Rpk[e < nwig ? e : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 256 * u + tid;
+        if (e < nwig) sR[e] = tmp[u];
+      }
     }
-    for (int n = 2; n <= ydeg; ++n) {
-      cn[n] = 2.0 * cn[n - 1] * c1 - cn[n - 2];
-      sn[n] = 2.0 * sn[n - 1] * c1 - sn[n - 2];
+  }
+  for (int n = tid; n < N; n += 256) sV[n] = v[(size_t)s * N + n];
+  if (tid < 64) {
+    double *cn = sC + tid * nc, *sn = sS + tid * nc;
+    if (r0 + tid < K) {
+      double s1, c1;
+      sincos(theta[(size_t)s * K + r0 + tid], &s1, &c1);
+      cn[0] = 1.0;
+      sn[0] = 0.0;
+      if (ydeg >= 1) {
+        cn[1] = c1;
+        sn[1] = s1;
+      }
+      for (int n = 2; n <= ydeg; ++n) {
+        cn[n] = 2.0 * cn[n - 1] * c1 - cn[n - 2];
+        sn[n] = 2.0 * sn[n - 1] * c1 - sn[n - 2];
+      }
+    } else {
+      for (int n = 0; n <= ydeg; ++n) cn[n] = sn[n] = 0.0;   // (a padding row: zeros)
     }
   }
   __syncthreads();
-  const double *vs = v + (size_t)s * N;
-  double *out = f + ((size_t)s * Kr + k) * N;
-  for (int n = threadIdx.x; n < N; n += blockDim.x) {
-    const int m = m_of[n];
-    const double cm = cn[m < 0 ? -m : m];
-    const double sm = m < 0 ? -sn[-m] : sn[m];
-    out[n] = vs[n] * cm + vs[mirror[n]] * sm;
+  const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fk = lane >> 4;
+  const double *crow = sC + (16 * wave + fr) * nc, *srow = sS + (16 * wave + fr) * nc;
+  const double *Rsrc = RLDS ? sR : Rpk;
+  for (int l = 0; l <= ydeg; ++l) {
+    const int w = 2 * l + 1, base = l * l, boff = l * (4 * l * l - 1) / 3;   // sum_{k < l} (2 k + 1)^2
+    const int nk = (w + 3) / 4, nct = (w + 15) / 16;
+    for (int ct = 0; ct < nct; ++ct) {
+      cd_d4 acc = {0.0, 0.0, 0.0, 0.0};
+      const int col = 16 * ct + fr;
+      for (int kk = 0; kk < nk; ++kk) {
+        const int k = 4 * kk + fk;
+        double a = 0.0, b = 0.0;
+        if (k < w) {
+          // entry n = base + k of the phase-rotated vector: m = k - l, its mirror is base + 2 l - k (wigner.h:289-339)
+          const int m = k - l, am = m < 0 ? -m : m;
+          const double sm = m < 0 ? -srow[am] : srow[am];
+          a = sV[base + k] * crow[am] + sV[base + 2 * l - k] * sm;
+          if (col < w) b = Rsrc[boff + k * w + col];
+        }
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      }
+      if (col < w) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int orow = r0 + 16 * wave + fk + 4 * r;
+          if (orow < Kr) A[((size_t)s * Kr + orow) * N + base + col] = acc[r];
+        }
+      }
+    }
   }
 }
 
@@ -256,7 +314,6 @@ int build_design(sp_handle *h, const Layout &L, void *ws, const sp_star *stars,
   const int S = L.S, K = L.K, N = L.N;
   double *cs = at<double>(ws, L.cs), *vrow = at<double>(ws, L.vrow);
   double *Rinc = at<double>(ws, L.Rinc), *theta = at<double>(ws, L.theta);
-  double *tmp = at<double>(ws, L.B1);  // reused as the pre-rotation buffer
   hipLaunchKernelGGL(inc_cs_kernel, dim3((S + 255) / 256), dim3(256), 0, st, S,
                      stars, cs);
   SP_LAUNCH_CHECK();
@@ -265,18 +322,19 @@ int build_design(sp_handle *h, const Layout &L, void *ws, const sp_star *stars,
   hipLaunchKernelGGL(cond_prep_kernel, dim3((N + 255) / 256, S), dim3(256), 0, st,
                      N, h->NWIG, h->d_l_of, h->d_blk, stars, rta1, Rinc, vrow);
   SP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(cond_rz_kernel, dim3(K, S), dim3(256), 0, st, h->ydeg, N, K, Kr,
-                     h->d_m_of, h->d_mirror, vrow, theta, tmp);
-  SP_LAUNCH_CHECK();
-  if ((rc = sp_launch_cond_pad_rows(tmp, S, K, Kr, N, st))) return rc;
-  // all stars share Rx(pi/2): treat the S*Kr rows as one tall matrix (zero rows stay zero)
-  const long rows = (long)S * Kr;
-  for (long r0 = 0; r0 < rows; r0 += 32768) {
-    const int nr = (int)(rows - r0 < 32768 ? rows - r0 : 32768);
-    rc = sp_launch_dotRx(h, tmp + (size_t)r0 * N, 0, N, 1, nr, h->d_Rx90, 0,
-                         A_out + (size_t)r0 * N, 1, st);
-    if (rc) return rc;
+  const size_t small = sizeof(double) * ((size_t)N + 2 * 64 * (h->ydeg + 1));
+  const size_t withR = small + sizeof(double) * (size_t)h->NWIG;
+  dim3 grid((Kr + 63) / 64, S);
+  if (withR <= 150 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cond_design_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipLaunchKernelGGL((cond_design_kernel<true>), grid, dim3(256), withR, st, h->ydeg, N, h->NWIG, K, Kr, vrow, theta,
+                       h->d_Rx90, A_out);
+  } else {
+    hipLaunchKernelGGL((cond_design_kernel<false>), grid, dim3(256), small, st, h->ydeg, N, h->NWIG, K, Kr, vrow, theta,
+                       h->d_Rx90, A_out);
   }
+  SP_LAUNCH_CHECK();
   return SP_OK;
 }
 

@@ -122,22 +122,7 @@ __global__ __launch_bounds__(256) void cond_system_kernel(
   }
 }
 
-// rows K .. Kr - 1 of every star's design matrix: zero (the tiles of the products read full 64-row tiles)
-__global__ void cond_pad_rows_kernel(double *__restrict__ A, int K, int Kr, int N, long strideA) {
-  const int s = blockIdx.y;
-  const long n = (long)(Kr - K) * N;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
-    A[(size_t)s * strideA + (size_t)K * N + e] = 0.0;
-}
-
 }  // namespace
-
-int sp_launch_cond_pad_rows(double *A, int S, int K, int Kr, int N, hipStream_t st) {
-  if (Kr <= K || S <= 0) return SP_OK;
-  hipLaunchKernelGGL(cond_pad_rows_kernel, dim3(8, S), dim3(256), 0, st, A, K, Kr, N, (long)Kr * N);
-  SP_LAUNCH_CHECK();
-  return SP_OK;
-}
 
 // The lower tiles of B1 A^T into the padded systems, assembled (see the header).  defer: part != null.
 int sp_launch_cond_system(const double *B1, const double *A, int N, int Kr, int S, int K, int M, int Kp,
