@@ -394,6 +394,8 @@ class EnsembleGradient(object):
         # main stream: the tables at the point, then the sweep
         with torch.cuda.stream(self._stream):
             yp0, mean0, (mu, Sig, tab, mv) = self._tables(e, **hp0)
+            at_point = torch.cuda.Event()
+            at_point.record(self._stream)
             lnl, ybar, mbar, status = e.lnlike_grad_marginal(
                 self._t, self._flux, self._stars, tab, mv, diag=self._diag, covpts=self._covpts,
                 temporal=self._temporal, normalized=self._normalized, workspace=self._ws)
@@ -426,7 +428,9 @@ class EnsembleGradient(object):
             eu = e3
             # c and n, exactly: mu_y = c n m, Sigma_y = c^2 n S + eps; the second moment f = yp + mean^2 is linear in
             # Sigma_y + mu_y mu_y^T:  f = c^2 n f_S + c^2 n^2 f_mm + f_eps,  mean = c n m1
-            ypA, meanA, (muA, SigA, _, _) = self._tables(eu, **hp0)
+            # (the tables at the point are the main stream's: they are ready long before the sweep is)
+            s3.wait_event(at_point)
+            ypA, meanA, muA, SigA = yp0, mean0, mu, Sig
             N = muA.shape[0]
             eps = torch.full((N,), float(self._ukw.get("epsy", defaults["epsy"])), dtype=torch.float64, device=eu.device)
             eps[15 ** 2:] = float(self._ukw.get("epsy15", defaults["epsy15"]))
@@ -453,17 +457,21 @@ class EnsembleGradient(object):
             Yb = torch.zeros(self._ntab, ybar.shape[1], dtype=torch.float64, device=e.device).index_add_(0, self._table, ybar)
             Mb = torch.zeros(self._ntab, dtype=torch.float64, device=e.device).index_add_(0, self._table, mbar)
             names = [k for k in ("r", "dr", "a", "b", "c", "n") if k in dy]
-            g = torch.stack([(Yb * dy[k]).sum() + (Mb * dm[k]).sum() for k in names]) if names else None
-            total = lnl.sum()
-        torch.cuda.synchronize(e.device)
-        self.lnlike = lnl.cpu().numpy()
-        self.status = status.cpu().numpy()
-        gv = g.cpu().numpy() if g is not None else np.zeros(0)
-        grad = {k: float(v) for k, v in zip(names, gv)}
+            # ONE transfer for everything the host wants: [gradient | per-star values | per-star status]
+            parts = [lnl, status.to(torch.float64)]
+            if names:
+                DY, DM = torch.stack([dy[k] for k in names]), torch.stack([dm[k] for k in names])
+                parts.insert(0, (DY * Yb).sum(dim=(1, 2)) + (DM * Mb).sum(dim=1))
+            host = torch.cat(parts).cpu().numpy()    # (on the main stream, which has waited for the others)
+        ng = len(names)
+        self.lnlike = host[ng:ng + self.S].copy()
+        self.status = host[ng + self.S:].astype(np.uint32)
+        total = float(self.lnlike.sum())
+        grad = {k: float(v) for k, v in zip(names, host[:ng])}
         if c == 0 or n == 0:
             grad.setdefault("c", float("nan"))
             grad.setdefault("n", float("nan"))
-        return float(total.item()), grad
+        return total, grad
 
 
 def ensemble_gradient(t, flux, ferr=1.0e-3, p=1.0, r=defaults["r"], a=defaults["a"], b=defaults["b"],

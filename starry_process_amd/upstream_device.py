@@ -51,9 +51,29 @@ def gauss_jacobi(n, a, b):
     return t, w
 
 
+_memo = {}
+
+
+def _memoised(kind, key, make):
+    """The last few results of a host-side preparation step (size moments, quadrature nodes): a gradient evaluation
+    asks for the same (r, dr) with six different (a, b) and the same (a, b) with four different r, and each costs
+    20 us of NumPy -- a tenth of the device sweep they are meant to hide behind (grad.EnsembleGradient)."""
+    d = _memo.setdefault(kind, {})
+    v = d.get(key)
+    if v is None:
+        if len(d) >= 16:
+            d.pop(next(iter(d)))
+        v = d[key] = make()
+    return v
+
+
 def quadrature_nodes(ydeg, alpha, beta):
     """(phi [P], w_phi [P], lam [Q]): latitude angles with their weights (sum 1) and the
     equispaced longitudes (weight 1 / Q each)."""
+    return _memoised("nodes", (int(ydeg), float(alpha), float(beta)), lambda: _quadrature_nodes(ydeg, alpha, beta))
+
+
+def _quadrature_nodes(ydeg, alpha, beta):
     t, w = gauss_jacobi(ydeg + 2, beta - 1.0, alpha - 1.0)   # weight (1 - t)^(beta-1) (1 + t)^(alpha-1)
     x = 0.5 * (1.0 + t)                                 # cos(phi) in (0, 1)
     phi = np.arccos(x)
@@ -75,7 +95,8 @@ def ylm_moments_device(engine, r=defaults["r"], dr=defaults["dr"], a=defaults["a
     ydeg, N = e.ydeg, e.N
     n = CheckBoundsOp(name="n", lower=0, upper=np.inf)(n)
     skw = {k: kwargs[k] for k in ("spts", "eps4", "smoothing", "sfac", "cutoff") if k in kwargs}
-    s1, eigS = size_moments(r, dr, ydeg, **skw)        # first moment [N], factor of the second [N, m]
+    s1, eigS = _memoised("size", (float(r), None if dr is None else float(dr), int(ydeg), tuple(sorted(skw.items()))),
+                         lambda: size_moments(r, dr, ydeg, **skw))   # first moment [N], factor of the second [N, m]
     alpha, beta = ab_to_alphabeta(a, b, **kwargs)
     phi, wphi, lam = quadrature_nodes(ydeg, alpha, beta)
     P, Q = phi.shape[0], lam.shape[0]
