@@ -267,6 +267,22 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
   if (fast) {
     // 128 x 128 tiles for full products of that granularity (0.80 of peak against 0.73), 64 x 64
     // tiles otherwise (lower-triangular updates: no wasted half tiles)
+#ifdef SP_MM_TILE_PROBE
+    // (tools/mm_tile_bench.py: the engine's tile shapes against each other on one full product)
+    static const int probe = getenv("SP_MM_TILE") ? atoi(getenv("SP_MM_TILE")) : 0;
+    if (!lower_only && probe == 1 && (Mrows % 128) == 0)
+      return mm_launch<MM2<128, 64, 8, 4, 4>>(A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd, alpha,
+                                              beta, lower_only, batch, st, skip00);
+    if (!lower_only && probe == 2 && (Mrows % 128) == 0)
+      return mm_launch<MM2<128, 64, 8, 5, 4>>(A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd, alpha,
+                                              beta, lower_only, batch, st, skip00);
+    if (!lower_only && probe == 3 && (Mrows % 128) == 0)
+      return mm_launch<MM2<128, 64, 16, 3, 4>>(A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd, alpha,
+                                               beta, lower_only, batch, st, skip00);
+    if (!lower_only && probe == 4)
+      return mm_launch<MM2<64, 64, 8, 6, 4>>(A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd, alpha,
+                                             beta, lower_only, batch, st, skip00);
+#endif
     if (!lower_only && (Mrows % 128) == 0 && (Nrows % 128) == 0)
       return mm_launch<MM2<128, 128, 8, 4, 2>>(A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows,
                                                Nrows, Kd, alpha, beta, lower_only, batch, st, skip00);
