@@ -442,7 +442,7 @@ int lnlike_assemble(sp_handle *h, const Layout &L, void *ws, int K, int M, const
     // deferred normalisation: ONE pass over the K^2 entries (raw tiles + their row / column sums),
     // then the normalisation's vectors as three more rows of the system (sp_assemble.hip)
     double *part = at<double>(ws, L.part);
-    if (!rawp && ptab)
+    if (!rawp && ptab && sp_assemble_sums_lds(L.Kp, cp, temporal) <= SP_ASM_LDS_MAX)
       rc = sp_launch_assemble_sums(S, K, M, L.Kp, theta, t_dev, stars_dev, cp, ptab, meanvar_dev, temporal,
                                    flux_dev, sys, st, part, lazy_nfull);
     else

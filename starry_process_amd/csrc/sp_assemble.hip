@@ -344,6 +344,9 @@ __global__ __launch_bounds__(256) void assemble_kernel(
 // Same operations per entry as the general kernel and as the tiles formed at first touch: same bits; the sums
 // land in the slots defer_finish_kernel adds up (the column sums of a strip segment in the segment's first
 // slot, zeros in its others).
+#ifdef SP_ASM_STAMPS
+__device__ long long sp_asm_dbg[8 * 8192];
+#endif
 #ifndef SP_ASM_BATCH
 #define SP_ASM_BATCH 16      // entries per SplineGen::many batch (4, 8 or 16)
 #endif
@@ -358,63 +361,133 @@ __global__ __launch_bounds__(256, SP_ASM_OCC) void assemble_sums_kernel(
     long strideo, int ntr, double *__restrict__ part, int lazy_nfull, int nchunk) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int s = blockIdx.y, np = covpts + 4, tid = threadIdx.x;
+#ifdef SP_ASM_STAMPS
+  const long long stamp_begin = __builtin_readcyclecounter();
+  const long long wall_begin = wall_clock64();
+#endif
   const sp_star st = stars[s];
   const int ntiles = ntr * (ntr + 1) / 2;
-  const int per = (ntiles + nchunk - 1) / nchunk;
-  const int t0 = per * blockIdx.x, t1 = t0 + per < ntiles ? t0 + per : ntiles;
-  if (t0 >= t1) return;
-  // strip-major tile order: strip tj holds the tiles ti = tj .. ntr - 1
-  int tj = 0, ti;
+  // Chunks of equal COST, not of equal length: a tile of the last row tile (masks, residual rows, identity
+  // padding; it also ends its strip: the column sums' trip through LDS) costs 3.8 tiles, a tile that is written
+  // 1.2 (per-workgroup stamps, tools/asm_wall.py: with 17 tiles each the workgroup of the last strips -- five
+  // last-row tiles -- ran for 50-58 us, the others for 33-37, and the launch lasted as long as it did).  The
+  // weights depend on the shape alone -- not on the batch, not on which tiles are left to their first touch: a
+  // star's sums are the same bits whoever shares its launch and whichever way its tiles are formed.
+  int t0, t1, tj, ti;
   {
-    int rem = t0;
-    while (rem >= ntr - tj) {
-      rem -= ntr - tj;
-      ++tj;
-    }
-    ti = tj + rem;
+    // strip b: its first tile (the diagonal one, or any tile of strip 0: written) 12, the tiles between 10, its
+    // last (row tile ntr - 1) 38; the first tile whose cumulative weight BEFORE it reaches `target`:
+    const auto strip_weight = [&](int b) {
+      const int n = ntr - b;
+      return n == 1 ? 38 : 12 + (n - 2) * (b == 0 ? 12 : 10) + 38;
+    };
+    const auto first_at = [&](int target, int &b_out, int &a_out) {
+      int c0 = 0;
+      int tile = 0;
+      for (int b = 0; b < ntr; ++b) {
+        const int n = ntr - b;
+        const int w = strip_weight(b);
+        if (target <= c0) {
+          b_out = b;
+          a_out = b;
+          return tile;
+        }
+        if (target <= c0 + w - 38) {
+          // inside this strip: tile k >= 1 has c0 + 12 + (k - 1) wm before it
+          const int d = target - c0 - 12;     // (divisions by constants)
+          int k = 1 + (b == 0 ? (d + 11) / 12 : (d + 9) / 10);
+          if (k < 1) k = 1;
+          if (k > n - 1) k = n - 1;
+          b_out = b;
+          a_out = b + k;
+          return tile + k;
+        }
+        c0 += w;
+        tile += n;
+      }
+      b_out = ntr;
+      a_out = ntr;
+      return ntiles;
+    };
+    int total = 0;                          // (<= 38 tiles' worth per tile: 32 bits hold any system this library takes)
+    for (int b = 0; b < ntr; ++b) total += strip_weight(b);
+    // chunk c = the tiles whose cumulative weight before them lies in [c total / nchunk, (c + 1) total / nchunk)
+    int bj, bi;
+    t0 = first_at((int)((unsigned)(blockIdx.x * total) / (unsigned)nchunk), tj, ti);
+    t1 = first_at((int)((unsigned)((blockIdx.x + 1) * total) / (unsigned)nchunk), bj, bi);
   }
+  if (t0 >= t1) return;
   double *s_tab = lds;                       // 4 np
   double *s_col = s_tab + 4 * np;            // [16][64] column-sum partials
+  double *s_th = s_col + 16 * 64;            // [Kp] the star's phases (zero beyond K)
+  double *s_tt = s_th + Kp;                  // [Kp] its times (temporal kernels only)
   const int nobs = star_nobs(st, K);
   const double *th = theta + (size_t)s * K, *tt = t + (size_t)s * K;
   // thread -> columns cl, cl + 16, cl + 32, cl + 48 of rows ri, ri + 16, ri + 32, ri + 48 of a tile (the 16 lanes of
   // a row look up ADJACENT columns: neighbouring table segments on distinct bank groups)
   const int cl = tid & 15, ri = tid >> 4;
+  // The phases (and times) of the whole star go to LDS once: the tile loop then issues NO vector-memory load.
+  // Fetched from memory one tile ahead -- the first long-lived form -- every tile waited for its predecessor's
+  // STORES: loads and stores share one in-order counter, so the wait for the prefetched rows (the youngest
+  // operations) was a wait for the row-sum and tile stores issued before them: 2.75 us per tile for 0.6 us of
+  // arithmetic, whatever the arithmetic was (a gather with five instructions less per entry changed nothing).
+  {
+    double a[4], b[4];
+    for (int base = 0; base < Kp; base += 1024) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int i = base + tid + 256 * c;
+        a[c] = i < K ? th[i] : 0.0;
+        b[c] = (TK != SP_TEMPORAL_NONE && i < K) ? tt[i] : 0.0;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int i = base + tid + 256 * c;
+        if (i < Kp) {
+          s_th[i] = a[c];
+          if (TK != SP_TEMPORAL_NONE) s_tt[i] = b[c];
+        }
+      }
+    }
+  }
   double thj[4], tmj[4], thi[4], tmi[4];
   auto load_cols = [&](int tjj) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int j = 64 * tjj + cl + 16 * e;
-      thj[e] = j < K ? th[j] : 0.0;
-      tmj[e] = (TK != SP_TEMPORAL_NONE && j < K) ? tt[j] : 0.0;
+      thj[e] = s_th[j];
+      tmj[e] = TK != SP_TEMPORAL_NONE ? s_tt[j] : 0.0;
     }
   };
   auto load_rows = [&](int tii, double (&a)[4], double (&b)[4]) {
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       const int i = 64 * tii + ri + 16 * pass;
-      a[pass] = i < K ? th[i] : 0.0;
-      b[pass] = (TK != SP_TEMPORAL_NONE && i < K) ? tt[i] : 0.0;
+      a[pass] = s_th[i];
+      b[pass] = TK != SP_TEMPORAL_NONE ? s_tt[i] : 0.0;
     }
   };
-  load_cols(tj);
-  load_rows(ti, thi, tmi);
   spline_table_to_lds(ptab + (size_t)s * 4 * np, s_tab, np, tid);
   __syncthreads();
+  load_cols(tj);
+  load_rows(ti, thi, tmi);
   SplineGen g{s_tab, 2 * np, 6.283185307179586 / covpts, 1.0 / (6.283185307179586 / covpts), covpts};
   const double var1 = nobs == 1 ? meanvar[2 * st.table + 1] : 0.0;
   double *ob = out + (size_t)s * strideo;
   double *ps = part + (size_t)s * ntr * K;
   double csum[4] = {0.0, 0.0, 0.0, 0.0};
   int seg0 = -1;                             // first row tile below the diagonal of this strip segment
+#ifdef SP_ASM_STAMPS
+  long long stamp_eval = 0, stamp_sums = 0, stamp_rest = 0, stamp_loop0 = __builtin_readcyclecounter();
+#define SP_STAMP(acc, since) do { const long long now_ = __builtin_readcyclecounter(); acc += now_ - since; since = now_; } while (0)
+  long long stamp_t = stamp_loop0;
+#else
+#define SP_STAMP(acc, since)
+#endif
   for (int tile = t0; tile < t1; ++tile) {
     const int i0 = 64 * ti, j0 = 64 * tj;
     const bool strip_ends = ti == ntr - 1 || tile == t1 - 1;
-    // the next tile's rows (and, behind a strip's last tile, the next strip's columns) are on their way
-    // while this tile is evaluated
     const int nti = ti == ntr - 1 ? tj + 1 : ti + 1;
-    double nthi[4], ntmi[4];
-    if (tile + 1 < t1) load_rows(nti, nthi, ntmi);
     double v[16];
 #pragma unroll
     for (int p0 = 0; p0 < 4; p0 += SP_ASM_BATCH / 4) {
@@ -441,15 +514,10 @@ __global__ __launch_bounds__(256, SP_ASM_OCC) void assemble_sums_kernel(
           v[4 * pass + e] *= temporal_factor(TK, tmi[pass], tmj[e], st.tau);
         }
     }
-    // the next tile's rows are taken over HERE, ahead of this tile's stores: the counter of outstanding memory
-    // operations is one for loads and stores, so a wait for loads that sits behind the stores waits for the
-    // stores' acknowledgements too (1-2 us per tile: the first form of this loop ran at 4 us per tile)
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      thi[pass] = nthi[pass];
-      tmi[pass] = ntmi[pass];
-    }
-    asm volatile("" : "+v"(thi[0]), "+v"(thi[1]), "+v"(thi[2]), "+v"(thi[3]));
+    asm volatile("" : "+v"(v[0]), "+v"(v[5]), "+v"(v[10]), "+v"(v[15]));
+    SP_STAMP(stamp_eval, stamp_t);
+    // the next tile's rows (LDS)
+    if (tile + 1 < t1) load_rows(nti, thi, tmi);
     // (tiles the factorisation forms itself at first touch: sums taken, nothing written -- not the first block
     //  column: its panel launch has no product to form the tile behind)
     const bool skip_write = ti > tj && tj > 0 && ti < lazy_nfull;
@@ -510,6 +578,7 @@ __global__ __launch_bounds__(256, SP_ASM_OCC) void assemble_sums_kernel(
           if (j0 + cl + 16 * e < Kp) dst[16 * e] = w[e];
       }
     }
+    SP_STAMP(stamp_sums, stamp_t);
     if (ti == tj) {
       // (the diagonal tile has no mirror: its entries are not column sums of anything)
 #pragma unroll
@@ -545,7 +614,19 @@ __global__ __launch_bounds__(256, SP_ASM_OCC) void assemble_sums_kernel(
     } else {
       ++ti;
     }
+    SP_STAMP(stamp_rest, stamp_t);
   }
+#ifdef SP_ASM_STAMPS
+  if (tid == 0) {
+    long long *o = sp_asm_dbg + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
+    o[0] = blockIdx.x; o[1] = blockIdx.y; o[2] = wall_begin; o[3] = wall_clock64();
+    o[4] = stamp_loop0 - stamp_begin; o[5] = stamp_eval; o[6] = stamp_sums; o[7] = stamp_rest;
+  }
+  if (false && (tid & 63) == 0 && blockIdx.y == 5 && (blockIdx.x == 3 || blockIdx.x == 9))
+    printf("asm stamps wg %d wave %d: tiles %d  prologue %lld  eval %lld  sums+stores %lld  rest %lld  (ticks, per tile: %lld %lld %lld)\n",
+           (int)blockIdx.x, tid >> 6, t1 - t0, stamp_loop0 - stamp_begin, stamp_eval, stamp_sums, stamp_rest,
+           stamp_eval / (t1 - t0), stamp_sums / (t1 - t0), stamp_rest / (t1 - t0));
+#endif
 }
 
 // Deferred normalisation, second half: one workgroup per star.
@@ -733,23 +814,39 @@ int sp_launch_assemble(int S, int K, int M, int Kp, int system,
   return SP_OK;
 }
 
+#ifdef SP_ASM_STAMPS
+extern "C" int sp_debug_asm_stamps(long long *out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sp_asm_dbg), sizeof(long long) * n);
+}
+#endif
+
+// LDS of the hot form: the star's table, the column-sum partials, its phases (and times); two workgroups per CU
+size_t sp_assemble_sums_lds(int Kp, int covpts, int temporal) {
+  return sizeof(double) * (4 * (size_t)(covpts + 4) + 16 * 64 + (size_t)Kp * (temporal == SP_TEMPORAL_NONE ? 1 : 2));
+}
+
 int sp_launch_assemble_sums(int S, int K, int M, int Kp, const double *theta, const double *t,
                             const sp_star *stars, int covpts, const double *ptab, const double *meanvar,
                             int temporal, const double *flux, double *sys, hipStream_t st, double *part,
                             int lazy_nfull) {
   const int np = covpts + 4;
-  const size_t lds = sizeof(double) * (4 * (size_t)np + 16 * 64);
-  if (lds > attr_lds_limit || !ptab || !part) return SP_ERR_INVALID;
+  const size_t lds = sp_assemble_sums_lds(Kp, covpts, temporal);
+  if (lds > SP_ASM_LDS_MAX || !ptab || !part) return SP_ERR_INVALID;
   const int ntr = Kp / 64, ntiles = ntr * (ntr + 1) / 2;
   // tiles per workgroup: a function of nothing but the build -- the column sums of a strip segment are added
   // in the segment's order, and a star's value must not depend on how many stars share its launch
   static const int per = [] {
     const char *e = getenv("SP_ASM_TILES");
-    const int v = e ? atoi(e) : 8;
+    const int v = e ? atoi(e) : 17;
     return v < 1 ? 1 : v;
   }();
   const int nchunk = (ntiles + per - 1) / per;
   dim3 grid(nchunk, S);
+#ifdef SP_PROBE
+  // (what would a free assembly be worth?  results are garbage; timing probe only)
+  static const bool skip = getenv("SP_PROBE_SKIP_ASM") != nullptr;
+  if (skip) return SP_OK;
+#endif
 #define SP_ASMS(TK)                                                                                     \
   do {                                                                                                  \
     allow_big_lds(assemble_sums_kernel<TK>);                                                            \

@@ -81,10 +81,12 @@ struct SplineGen {
       idx = (int)floor(x / dx);
       x0 = q - (double)idx;
     }
-    idx = idx < 0 ? 0 : (idx > covpts ? covpts : idx);
-    // two 16-byte LDS reads fetch the four coefficients of the segment
-    const dd2 c01 = *reinterpret_cast<const dd2 *>(tab + 2 * idx);
-    const dd2 c23 = *reinterpret_cast<const dd2 *>(tab + np2 + 2 * idx);
+    idx = idx > covpts ? covpts : idx;      // (a conversion of |.| * inv_dx: never negative, 0 for a NaN)
+    // two 16-byte LDS reads fetch the four coefficients of the segment (addresses by hand: see many())
+    typedef const __attribute__((address_space(3))) dd2 *lds_dd2;
+    const unsigned a1 = (unsigned)(size_t)(const __attribute__((address_space(3))) double *)tab + ((unsigned)idx << 4);
+    const dd2 c01 = *(lds_dd2)(size_t)a1;
+    const dd2 c23 = *(lds_dd2)(size_t)(a1 + 8u * (unsigned)np2);
     // a0 + a1 x0 + a2 x0^2 + a3 x0^3 in Horner form (the value, unlike the index, only has
     // to agree to rounding: fused multiply-adds)
     return __builtin_fma(x0, __builtin_fma(x0, __builtin_fma(x0, c23.y, c23.x), c01.y), c01.x);
@@ -119,11 +121,19 @@ struct SplineGen {
         }
     }
     dd2 c01[N], c23[N];
+    // 32-bit LDS addresses by hand: min, shift-add, add per entry.  (From `tab + 2 k` the compiler made eight
+    // vector instructions and a two-cycle bubble per entry -- a signed clamp through a compare and a select, two
+    // shifts, an add of the LDS base's relocation, an add of the second array's offset -- a third of everything the
+    // assembly issued.  The index is a conversion of |.| * inv_dx: never negative, 0 for a NaN.)
+    typedef const __attribute__((address_space(3))) dd2 *lds_dd2;
+    const unsigned base = (unsigned)(size_t)(const __attribute__((address_space(3))) double *)tab;
+    const unsigned off2 = 8u * (unsigned)np2;
 #pragma unroll
     for (int e = 0; e < N; ++e) {
-      const int k = idx[e] < 0 ? 0 : (idx[e] > covpts ? covpts : idx[e]);
-      c01[e] = *reinterpret_cast<const dd2 *>(tab + 2 * k);
-      c23[e] = *reinterpret_cast<const dd2 *>(tab + np2 + 2 * k);
+      const int k = idx[e] > covpts ? covpts : idx[e];
+      const unsigned a1 = base + ((unsigned)k << 4);
+      c01[e] = *(lds_dd2)(size_t)a1;
+      c23[e] = *(lds_dd2)(size_t)(a1 + off2);
     }
 #pragma unroll
     for (int e = 0; e < N; ++e)

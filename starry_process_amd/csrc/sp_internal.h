@@ -262,6 +262,9 @@ int sp_launch_syrk_diag(const double *X, long ld, long stride, double *T, int n,
 
 // reverse sweep of the marginal-branch likelihood (sp_grad.hip): C^-1 (lower tiles in, full out) -> lnL, the table's
 // adjoint ybar [S, covpts + 4], the flux mean's adjoint [S]
+// LDS the hot form of the assembly needs (sp_assemble.hip, assemble_sums_kernel) and the most it may ask for
+#define SP_ASM_LDS_MAX (80 * 1024)
+size_t sp_assemble_sums_lds(int Kp, int covpts, int temporal);
 int sp_launch_grad_sweep(int S, int K, int Kr, double *Cinv, const double *theta, const double *t,
                          const double *flux, const sp_star *stars, const void *coef, const double *qv,
                          const double *diag, const double *logdet, const int32_t *info, int covpts, int temporal,
