@@ -347,6 +347,11 @@ __global__ __launch_bounds__(256) void assemble_kernel(
 #ifdef SP_ASM_STAMPS
 __device__ long long sp_asm_dbg[8 * 8192];
 #endif
+// first tile of every chunk (strip-major order), by value in the kernel arguments: see asm_chunks() below
+#define SP_ASM_MAX_CHUNKS 511
+struct AsmChunks {
+  unsigned short start[SP_ASM_MAX_CHUNKS + 1];
+};
 #ifndef SP_ASM_BATCH
 #define SP_ASM_BATCH 16      // entries per SplineGen::many batch (4, 8 or 16)
 #endif
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(256, SP_ASM_OCC) void assemble_sums_kernel(
     int K, int M, int Kp, const double *__restrict__ theta, const double *__restrict__ t,
     const sp_star *__restrict__ stars, int covpts, const double *__restrict__ ptab,
     const double *__restrict__ meanvar, const double *__restrict__ flux, double *__restrict__ out, long ldo,
-    long strideo, int ntr, double *__restrict__ part, int lazy_nfull, int nchunk) {
+    long strideo, int ntr, double *__restrict__ part, int lazy_nfull, AsmChunks chunks) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int s = blockIdx.y, np = covpts + 4, tid = threadIdx.x;
 #ifdef SP_ASM_STAMPS
@@ -367,56 +372,18 @@ __global__ __launch_bounds__(256, SP_ASM_OCC) void assemble_sums_kernel(
 #endif
   const sp_star st = stars[s];
   const int ntiles = ntr * (ntr + 1) / 2;
-  // Chunks of equal COST, not of equal length: a tile of the last row tile (masks, residual rows, identity
-  // padding; it also ends its strip: the column sums' trip through LDS) costs 3.8 tiles, a tile that is written
-  // 1.2 (per-workgroup stamps, tools/asm_wall.py: with 17 tiles each the workgroup of the last strips -- five
-  // last-row tiles -- ran for 50-58 us, the others for 33-37, and the launch lasted as long as it did).  The
-  // weights depend on the shape alone -- not on the batch, not on which tiles are left to their first touch: a
-  // star's sums are the same bits whoever shares its launch and whichever way its tiles are formed.
-  int t0, t1, tj, ti;
-  {
-    // strip b: its first tile (the diagonal one, or any tile of strip 0: written) 12, the tiles between 10, its
-    // last (row tile ntr - 1) 38; the first tile whose cumulative weight BEFORE it reaches `target`:
-    const auto strip_weight = [&](int b) {
-      const int n = ntr - b;
-      return n == 1 ? 38 : 12 + (n - 2) * (b == 0 ? 12 : 10) + 38;
-    };
-    const auto first_at = [&](int target, int &b_out, int &a_out) {
-      int c0 = 0;
-      int tile = 0;
-      for (int b = 0; b < ntr; ++b) {
-        const int n = ntr - b;
-        const int w = strip_weight(b);
-        if (target <= c0) {
-          b_out = b;
-          a_out = b;
-          return tile;
-        }
-        if (target <= c0 + w - 38) {
-          // inside this strip: tile k >= 1 has c0 + 12 + (k - 1) wm before it
-          const int d = target - c0 - 12;     // (divisions by constants)
-          int k = 1 + (b == 0 ? (d + 11) / 12 : (d + 9) / 10);
-          if (k < 1) k = 1;
-          if (k > n - 1) k = n - 1;
-          b_out = b;
-          a_out = b + k;
-          return tile + k;
-        }
-        c0 += w;
-        tile += n;
-      }
-      b_out = ntr;
-      a_out = ntr;
-      return ntiles;
-    };
-    int total = 0;                          // (<= 38 tiles' worth per tile: 32 bits hold any system this library takes)
-    for (int b = 0; b < ntr; ++b) total += strip_weight(b);
-    // chunk c = the tiles whose cumulative weight before them lies in [c total / nchunk, (c + 1) total / nchunk)
-    int bj, bi;
-    t0 = first_at((int)((unsigned)(blockIdx.x * total) / (unsigned)nchunk), tj, ti);
-    t1 = first_at((int)((unsigned)((blockIdx.x + 1) * total) / (unsigned)nchunk), bj, bi);
-  }
+  const int t0 = chunks.start[blockIdx.x], t1 = chunks.start[blockIdx.x + 1];
   if (t0 >= t1) return;
+  // strip-major tile order: strip tj holds the tiles ti = tj .. ntr - 1
+  int tj = 0, ti;
+  {
+    int rem = t0;
+    while (rem >= ntr - tj) {
+      rem -= ntr - tj;
+      ++tj;
+    }
+    ti = tj + rem;
+  }
   double *s_tab = lds;                       // 4 np
   double *s_col = s_tab + 4 * np;            // [16][64] column-sum partials
   double *s_th = s_col + 16 * 64;            // [Kp] the star's phases (zero beyond K)
@@ -820,6 +787,36 @@ extern "C" int sp_debug_asm_stamps(long long *out, int n) {
 }
 #endif
 
+// Chunks of equal COST, not of equal length: a tile of the last row tile (masks, residual rows, identity padding; it
+// also ends its strip: the column sums' trip through LDS) costs 3.8 tiles, a tile that is written (the diagonal one,
+// any tile of strip 0) 1.2 -- per-workgroup stamps, tools/asm_wall.py: with 17 tiles each the workgroup of the last
+// strips (five last-row tiles) ran for 50-58 us, the others for 33-37, and the launch lasted as long as it did.  The
+// weights depend on the shape alone -- not on the batch, not on which tiles are left to their first touch: a star's
+// sums are the same bits whoever shares its launch and whichever way its tiles are formed.
+// Chunk c = the tiles whose cumulative weight BEFORE them lies in [c total / nchunk, (c + 1) total / nchunk).
+static AsmChunks asm_chunks(int ntr, int nchunk) {
+  static thread_local int have_ntr = -1, have_nchunk = -1;
+  static thread_local AsmChunks have;
+  if (ntr == have_ntr && nchunk == have_nchunk) return have;
+  const auto weight = [&](int a, int b) { return a == ntr - 1 ? 38 : ((b == 0 || a == b) ? 12 : 10); };
+  long total = 0;
+  for (int b = 0; b < ntr; ++b)
+    for (int a = b; a < ntr; ++a) total += weight(a, b);
+  AsmChunks c;
+  int chunk = 0, tile = 0;
+  long cum = 0;
+  for (int b = 0; b < ntr; ++b)
+    for (int a = b; a < ntr; ++a, ++tile) {
+      while (chunk <= nchunk && cum >= (long)chunk * total / nchunk) c.start[chunk++] = (unsigned short)tile;
+      cum += weight(a, b);
+    }
+  while (chunk <= nchunk) c.start[chunk++] = (unsigned short)tile;
+  have = c;
+  have_ntr = ntr;
+  have_nchunk = nchunk;
+  return c;
+}
+
 // LDS of the hot form: the star's table, the column-sum partials, its phases (and times); two workgroups per CU
 size_t sp_assemble_sums_lds(int Kp, int covpts, int temporal) {
   return sizeof(double) * (4 * (size_t)(covpts + 4) + 16 * 64 + (size_t)Kp * (temporal == SP_TEMPORAL_NONE ? 1 : 2));
@@ -840,7 +837,10 @@ int sp_launch_assemble_sums(int S, int K, int M, int Kp, const double *theta, co
     const int v = e ? atoi(e) : 17;
     return v < 1 ? 1 : v;
   }();
-  const int nchunk = (ntiles + per - 1) / per;
+  int nchunk = (ntiles + per - 1) / per;
+  if (nchunk > SP_ASM_MAX_CHUNKS) nchunk = SP_ASM_MAX_CHUNKS;
+  if (ntiles > 65535) return SP_ERR_INVALID;
+  const AsmChunks chunks = asm_chunks(ntr, nchunk);
   dim3 grid(nchunk, S);
 #ifdef SP_PROBE
   // (what would a free assembly be worth?  results are garbage; timing probe only)
@@ -851,7 +851,7 @@ int sp_launch_assemble_sums(int S, int K, int M, int Kp, const double *theta, co
   do {                                                                                                  \
     allow_big_lds(assemble_sums_kernel<TK>);                                                            \
     hipLaunchKernelGGL((assemble_sums_kernel<TK>), grid, dim3(256), lds, st, K, M, Kp, theta, t, stars, \
-                       covpts, ptab, meanvar, flux, sys, (long)Kp, (long)Kp * Kp, ntr, part, lazy_nfull, nchunk); \
+                       covpts, ptab, meanvar, flux, sys, (long)Kp, (long)Kp * Kp, ntr, part, lazy_nfull, chunks); \
   } while (0)
   if (temporal == SP_TEMPORAL_NONE) SP_ASMS(SP_TEMPORAL_NONE);
   else if (temporal == SP_TEMPORAL_MATERN32) SP_ASMS(SP_TEMPORAL_MATERN32);
