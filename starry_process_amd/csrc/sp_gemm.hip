@@ -117,6 +117,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
 namespace {
 // SGN: alpha is +1 or -1 and the accumulators start from +-C (no second register tile, exact);
 // otherwise the C tile waits in registers and is combined after the loop.
+#ifdef SP_MM_STAMPS
+__device__ long long sp_mm_dbg[8 * 4096];
+#endif
 template <class Core, bool SGN>
 __global__ __launch_bounds__(256) void mm_nt_kernel(
     const double *__restrict__ A, long lda, long strideA, const double *__restrict__ B, long ldb,
@@ -125,6 +128,9 @@ __global__ __launch_bounds__(256) void mm_nt_kernel(
   constexpr int TM = Core::TM_, TN = Core::TN_;
   static_assert(Core::LDS_DOUBLES >= SP_DIAG_LDS_DOUBLES, "the tile-(0,0) workgroup factors a pivot block in this LDS");
   __shared__ __attribute__((aligned(16))) double lds[Core::LDS_DOUBLES];
+#ifdef SP_MM_STAMPS
+  const long long wall_begin = wall_clock64(), cyc_begin = __builtin_readcyclecounter();
+#endif
   int mtx, tile;
   if (!sp_xcd_decode(blockIdx.x, batch, ntiles, mtx, tile)) return;
   int ti, tj;
@@ -203,7 +209,13 @@ __global__ __launch_bounds__(256) void mm_nt_kernel(
         cin[m][n] = c;
       }
     }
+#ifdef SP_MM_STAMPS
+  const long long cyc_loop = __builtin_readcyclecounter();
+#endif
   mm.loop(lds, k_first, Kd, acc);
+#ifdef SP_MM_STAMPS
+  const long long cyc_store = __builtin_readcyclecounter();
+#endif
 #pragma unroll
   for (int m = 0; m < Core::MA; ++m)
 #pragma unroll
@@ -217,6 +229,14 @@ __global__ __launch_bounds__(256) void mm_nt_kernel(
           v = fma(alpha, acc[m][n][r], cin[m][n][r]);
         Cb[(size_t)mm.acc_row(m, r) * ldc + mm.acc_col(n)] = v;
       }
+#ifdef SP_MM_STAMPS
+  if (threadIdx.x == 0 && lower_only && df.sys && blockIdx.x < 4096) {
+    long long *o = sp_mm_dbg + 8 * blockIdx.x;
+    o[0] = (long long)mtx * 4096 + tile; o[1] = lazy; o[2] = wall_begin; o[3] = wall_clock64();
+    o[4] = cyc_loop - cyc_begin; o[5] = cyc_store - cyc_loop; o[6] = __builtin_readcyclecounter() - cyc_store;
+    o[7] = ((__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) & 15u) << 8) | ((__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) >> 8) & 255u);
+  }
+#endif
 }
 
 
@@ -243,6 +263,12 @@ int mm_launch(const double *A, long lda, long strideA, const double *B, long ldb
   return SP_OK;
 }
 }  // namespace
+
+#ifdef SP_MM_STAMPS
+extern "C" int sp_debug_mm_stamps(long long *out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sp_mm_dbg), sizeof(long long) * n);
+}
+#endif
 
 static int launch_gemm(const double *A, long lda, long strideA, const double *B, long ldb,
                        long strideB, double *C, long ldc, long strideC, int Mrows, int Nrows,
