@@ -453,6 +453,10 @@ int sp_debug_panel2_trace(long long *out);
  * 16 x 64 x 4 int64 (pivot block j, star, {first item start, block start, block end, CU key}), then
  * 16 x 1024 int32: the CU key + 1 of every workgroup of the launch (0: none).                     */
 int sp_debug_panel2_chain(long long *out);
+/* (debug, host only) how the hot assembly kernel (csrc/sp_assemble.hip, assemble_sums_kernel) cuts a star's
+ * ntr (ntr + 1) / 2 lower tiles (column-strip order) into nchunk chunks of equal COST: start_host[c] = first tile
+ * of chunk c, c = 0 .. nchunk (start_host[nchunk] = the number of tiles).  A function of the shape alone.   */
+int sp_debug_asm_chunks(int ntr, int nchunk, int *start_host);
 
 #ifdef __cplusplus
 }

@@ -817,6 +817,13 @@ static AsmChunks asm_chunks(int ntr, int nchunk) {
   return c;
 }
 
+extern "C" int sp_debug_asm_chunks(int ntr, int nchunk, int *start_host) {
+  if (ntr < 1 || nchunk < 1 || nchunk > SP_ASM_MAX_CHUNKS || ntr * (ntr + 1) / 2 > 65535 || !start_host) return SP_ERR_INVALID;
+  const AsmChunks c = asm_chunks(ntr, nchunk);
+  for (int k = 0; k <= nchunk; ++k) start_host[k] = c.start[k];
+  return SP_OK;
+}
+
 // LDS of the hot form: the star's table, the column-sum partials, its phases (and times); two workgroups per CU
 size_t sp_assemble_sums_lds(int Kp, int covpts, int temporal) {
   return sizeof(double) * (4 * (size_t)(covpts + 4) + 16 * 64 + (size_t)Kp * (temporal == SP_TEMPORAL_NONE ? 1 : 2));

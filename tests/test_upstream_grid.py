@@ -86,3 +86,25 @@ def test_quadrature_method_matches_reference_over_the_grid():
             assert np.abs(mu - mr).max() < 1e-9 * np.abs(mr).max(), (a, b)
             scale, e4, e8, elow = grid_cov_errors(S, g, i, j)
             assert e4 < 1e-7 * scale and e8 < 1e-5 * scale and elow < 5e-2 * scale, (a, b)
+
+
+def test_assembly_chunks_partition_the_tiles_by_cost():
+    """The hot assembly kernel's chunks (csrc/sp_assemble.hip, asm_chunks): every tile in exactly one chunk, in order,
+    and no chunk heavier than the mean by more than one tile's weight -- a function of the shape alone (host code)."""
+    from starry_process_amd import _lib
+
+    L = _lib.lib()
+    for ntr in (1, 2, 3, 9, 16, 17, 47, 64):
+        ntiles = ntr * (ntr + 1) // 2
+        w = np.array([38 if a == ntr - 1 else (12 if (b == 0 or a == b) else 10)
+                      for b in range(ntr) for a in range(b, ntr)])
+        for nchunk in sorted({1, 2, max(1, -(-ntiles // 17)), max(1, -(-ntiles // 8)), min(511, ntiles)}):
+            st = np.zeros(nchunk + 1, dtype=np.int32)
+            assert L.sp_debug_asm_chunks(ntr, nchunk, _lib.hptr(st)) == 0
+            assert st[0] == 0 and st[-1] == ntiles and np.all(np.diff(st) >= 0)
+            cost = np.array([w[st[c]:st[c + 1]].sum() for c in range(nchunk)])
+            assert cost.sum() == w.sum()
+            assert cost.max() <= w.sum() / nchunk + 38
+    bad = np.zeros(4, dtype=np.int32)
+    assert L.sp_debug_asm_chunks(0, 1, _lib.hptr(bad)) != 0
+    assert L.sp_debug_asm_chunks(16, 600, _lib.hptr(bad)) != 0
