@@ -276,6 +276,11 @@ static int cholesky_panel2(sp_handle *h, int ngroups, const sp_chol_group *grp, 
                                     : 0;
           // (the launch whose tail factors the LAST pivot block carries the reduction, if there is one)
           const SpReduceArgs *red = (tail && j + 1 == nsteps - 1 && fuse_reduce) ? &G.red : nullptr;
+#ifdef SP_PROBE
+          // (what is each kind of launch worth with several steps in flight?  results are garbage; timing probe only)
+          static const int probe_skip_p = getenv("SP_PROBE_SKIP_PANELS") ? atoi(getenv("SP_PROBE_SKIP_PANELS")) : 0;
+          if (probe_skip_p == 3 || (probe_skip_p == 1 && s0 == 0) || (probe_skip_p == 2 && s0 > 0)) continue;
+#endif
           if (rc == SP_OK && what)
             rc = sp_launch_panel2(h->panel_layout | (tri0 >= 0 ? (2 | (tri0 << 8)) : 0), red, G.sys, ld, stride, G.S, ntile, j, s0, nact_of(j), tail ? nact_of(j + 1) : 0,
                                   last, what, h->ncu, G.invL, lts, G.info, G.st, lzp);
@@ -294,6 +299,10 @@ static int cholesky_panel2(sp_handle *h, int ngroups, const sp_chol_group *grp, 
         lzv.tr0 = lzv.tc0 = jE;
         DiagFuse df{G.sys, ld, stride, jE, nact_of(jE), G.invL, lts, G.info, tri0, s0};
         SpProfScope prof(h, G.st, SP_PROF_SYRK, (double)G.S * (double)n * (n + 1) * kd);
+#ifdef SP_PROBE
+        static const bool probe_skip_mm = getenv("SP_PROBE_SKIP_MM2") != nullptr;
+        if (probe_skip_mm) continue;
+#endif
         int rc = sp_launch_syrk_diag(G.sys + (size_t)cE * ld + cS, ld, stride, G.sys + (size_t)cE * ld + cE,
                                      n, kd, G.S, G.st, (G.lazy.theta && s0 == 0) ? &lzv : nullptr, &df, tj_limit);
         if (rc != SP_OK) return rc;

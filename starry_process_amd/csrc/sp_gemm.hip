@@ -120,8 +120,14 @@ namespace {
 #ifdef SP_MM_STAMPS
 __device__ long long sp_mm_dbg[8 * 4096];
 #endif
+#ifndef SP_MM_WAVES
+#define SP_MM_WAVES 1      // (probe: 4 = a register budget for four workgroups per CU, with SP_MM_SYRK_NS = 5)
+#endif
+#ifndef SP_MM_SYRK_NS
+#define SP_MM_SYRK_NS 6
+#endif
 template <class Core, bool SGN>
-__global__ __launch_bounds__(256) void mm_nt_kernel(
+__global__ __launch_bounds__(256, SP_MM_WAVES) void mm_nt_kernel(
     const double *__restrict__ A, long lda, long strideA, const double *__restrict__ B, long ldb,
     long strideB, double *__restrict__ C, long ldc, long strideC, int Kd, double alpha, int beta,
     int lower_only, int batch, int ntn, int ntiles, int skip00, LazyCov lz, DiagFuse df) {
@@ -330,7 +336,7 @@ int sp_launch_syrk_diag(const double *X, long ld, long stride, double *T, int n,
   if ((n % GT) || (kd % 16) || kd <= 0 || (ld & 1) || (stride & 1) ||
       ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(T)) & 15))
     return SP_ERR_INVALID;
-  return mm_launch<MM2<64, 64, 8, 6, 4>>(X, ld, stride, X, ld, stride, T, ld, stride, n, n, kd, -1.0, 1, 1,
+  return mm_launch<MM2<64, 64, 8, SP_MM_SYRK_NS, 4>>(X, ld, stride, X, ld, stride, T, ld, stride, n, n, kd, -1.0, 1, 1,
                                          batch, st, 1 | (tj_limit > 0 ? tj_limit << 8 : 0),
                                          (lazy && lazy->theta) ? lazy : nullptr, df);
 }
