@@ -1185,7 +1185,7 @@ int sp_lnlike_ensemble(sp_handle *h, int S, int K, int M, const double *t_dev,
   //  it saves -- cfg5 shape: -2.5 %)
   if (h->lazy_cov && !conditional && temporal == SP_TEMPORAL_NONE && normalized && h->defer_norm && G == 1 &&
       K / SP_NB >= 2 &&
-      (size_t)K * L.N >= 4 * (size_t)(covpts + 4) && 4 * (covpts + 4) <= SP_TILE_LDS_MIN) {
+      (size_t)K * L.N >= 4 * (size_t)(covpts + 4) && 4 * (covpts + 4) + 64 <= SP_TILE_LDS_MIN) {   // (+ a tile's column phases)
     lazy_nfull = K / SP_NB;
     CG[0].lazy = LazyCov{at<double>(ws, L.theta), t_dev, stars_dev, at<double>(ws, L.A), K, covpts,
                          temporal, lazy_nfull, 0, 0};

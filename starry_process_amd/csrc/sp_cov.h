@@ -231,11 +231,16 @@ __device__ __forceinline__ void lazy_cov_tile(const LazyCov &z, int star, const 
 // (sp_lnlike_ensemble; the exp per entry, evaluated twice, costs more than the traffic saves), and
 // sixteen inlined copies of exp() would be dead code in the panel kernel.
 #ifndef SP_LAZY_ROW_BATCH
-#define SP_LAZY_ROW_BATCH 0    // entries per SplineGen::many batch in the panel kernel; 0: one at a time -- batches of
-                               // four cost the lazy instantiations 26 (layout) to 180 (pairs) spilled registers
-                               // of their 168: 0.871 against 0.855 ms per step, 104.0k against 106.9k in flight
+#define SP_LAZY_ROW_BATCH 0    // entries per SplineGen::many batch in the panel kernel's 64-row items (0: one at a time; the
+                               // 128-row pair items always take one at a time).  Batches of four cost the lazy
+                               // instantiations 26-31 spilled registers of their 168 whatever is done about it (the
+                               // column phases through LDS, a scheduling barrier between batches): 107.9k against
+                               // 110.6-112.8k in flight.  Pairs fit (154 registers) and measure the same as one at a
+                               // time: 110.1-111.4k against 110.9-112.3k in flight, 0.816-0.821 against 0.821-0.828 ms
+                               // alone.  (What the evaluation costs there: 0.052 ms of a 0.573 ms step with four in
+                               // flight, 0.026 alone -- a build that fills these tiles with constants.)
 #endif
-template <typename V4>
+template <int ROWB, typename V4>
 __device__ __forceinline__ void lazy_cov_row(const LazyCov &z, int star, int ri, int c0, V4 (&out)[4],
                                              double *stage, int tid) {
   const sp_star st = z.stars[star];
@@ -243,50 +248,74 @@ __device__ __forceinline__ void lazy_cov_row(const LazyCov &z, int star, int ri,
   const double *th = z.theta + (size_t)star * z.K;
   const bool oi = ri < nobs;
   const double thi = oi ? th[ri] : 0.0;
+  double *s_thj = stage + 4 * np;      // the tile's 64 column phases, behind the table (zero beyond the cadences)
   {
     // (a plain copy loop here: the unrolled form's 16 registers in flight spill the panel kernel's budget)
     const double *src = z.ptab + (size_t)star * 4 * np;
     for (int e = 2 * tid; e < 4 * np; e += 512)
       *reinterpret_cast<dd2 *>(stage + e) = *reinterpret_cast<const dd2 *>(src + e);
+    const int cbase = c0 & ~63;
+    if (tid < 64) s_thj[tid] = cbase + tid < nobs ? th[cbase + tid] : 0.0;
   }
   __syncthreads();
   SplineGen g{stage, 2 * np, 6.283185307179586 / z.covpts,
               1.0 / (6.283185307179586 / z.covpts), z.covpts};
+  const int cl = c0 & 63;
   // (unrolled -- a run-time index into the caller's accumulators would send them to scratch memory)
-#if SP_LAZY_ROW_BATCH == 0
+  // The column phases come from LDS, four at a time: fetched from memory all sixteen were in flight across the
+  // whole evaluation (32 registers), which is what made batches spill in this kernel.
+  if constexpr (ROWB == 2) {
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
-    double thj[4];
+    V4 o;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int c = c0 + 16 * m + r;
-      thj[r] = c < nobs ? th[c] : 0.0;
+    for (int half = 0; half < 2; ++half) {
+      const dd2 tt = *reinterpret_cast<const dd2 *>(s_thj + cl + 16 * m + 2 * half);
+      const double a[2] = {thi, thi}, b[2] = {tt.x, tt.y};
+      double v[2];
+      g.many<2>(a, b, v);
+      o[2 * half] = (oi && c0 + 16 * m + 2 * half < nobs) ? v[0] : 0.0;
+      o[2 * half + 1] = (oi && c0 + 16 * m + 2 * half + 1 < nobs) ? v[1] : 0.0;
+      __builtin_amdgcn_sched_barrier(0);
     }
+    out[m] = o;
+  }
+  } else if constexpr (ROWB == 0) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const dd2 t01 = *reinterpret_cast<const dd2 *>(s_thj + cl + 16 * m), t23 = *reinterpret_cast<const dd2 *>(s_thj + cl + 16 * m + 2);
+    const double thj[4] = {t01.x, t01.y, t23.x, t23.y};
     V4 o;
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = (oi && c0 + 16 * m + r < nobs) ? g(thi, thj[r]) : 0.0;
     out[m] = o;
   }
-#else
+  } else {
 #pragma unroll
-  for (int m0 = 0; m0 < 4; m0 += SP_LAZY_ROW_BATCH / 4) {
-    double a[SP_LAZY_ROW_BATCH], b[SP_LAZY_ROW_BATCH], v[SP_LAZY_ROW_BATCH];
+  for (int m0 = 0; m0 < 4; m0 += ROWB / 4) {
+    double a[ROWB], b[ROWB], v[ROWB];
 #pragma unroll
-    for (int e = 0; e < SP_LAZY_ROW_BATCH; ++e) {
-      const int c = c0 + 16 * (m0 + (e >> 2)) + (e & 3);
-      a[e] = thi;
-      b[e] = c < nobs ? th[c] : 0.0;
+    for (int h = 0; h < ROWB / 4; ++h) {
+      const dd2 t01 = *reinterpret_cast<const dd2 *>(s_thj + cl + 16 * (m0 + h));
+      const dd2 t23 = *reinterpret_cast<const dd2 *>(s_thj + cl + 16 * (m0 + h) + 2);
+      a[4 * h] = a[4 * h + 1] = a[4 * h + 2] = a[4 * h + 3] = thi;
+      b[4 * h] = t01.x;
+      b[4 * h + 1] = t01.y;
+      b[4 * h + 2] = t23.x;
+      b[4 * h + 3] = t23.y;
     }
-    g.many<SP_LAZY_ROW_BATCH>(a, b, v);
+    g.many<ROWB>(a, b, v);
 #pragma unroll
-    for (int h = 0; h < SP_LAZY_ROW_BATCH / 4; ++h) {
+    for (int h = 0; h < ROWB / 4; ++h) {
       V4 o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[r] = (oi && c0 + 16 * (m0 + h) + r < nobs) ? v[4 * h + r] : 0.0;
       out[m0 + h] = o;
     }
+    // (one batch after the other: left to itself the scheduler starts all of them at once)
+    __builtin_amdgcn_sched_barrier(0);
   }
-#endif
+  }
   __syncthreads();   // the scratch goes back to its owner
 }
 

@@ -164,7 +164,11 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
                                                 double *img_star, double *smem, int tid) {
   const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fk = lane >> 4;
   const long ld = a.ld;
+#ifdef P_NO_PRODUCT
+  const int Kd = 0 * (kb1 - kb0);       // (timing probe: results are garbage)
+#else
   const int Kd = 64 * (kb1 - kb0);
+#endif
   const double *img = img_star + sp_img_off(a.j);
   const bool chain = CHAIN && NR == 1 && !la && i0 == a.j + 1 && (a.mode & P_TAILD);   // this item factors the next block
 #ifdef SP_PANEL_TRACE
@@ -212,7 +216,12 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
         g[h][m] = pd4{lo.x, lo.y, hi.x, hi.y};
       }
     } else {
-      lazy_cov_row(a.lz, mtx, 64 * (i0 + h) + 16 * wave + fr, 64 * cb + 4 * fk, g[h], smem, tid);
+#ifdef P_NO_LAZYEVAL
+#pragma unroll
+      for (int m = 0; m < 4; ++m) g[h][m] = pd4{0.0, 0.0, 0.0, 1.0e-3 * (m + fk)};     // (timing probe)
+#else
+      lazy_cov_row<(NR == 1 ? SP_LAZY_ROW_BATCH : 0)>(a.lz, mtx, 64 * (i0 + h) + 16 * wave + fr, 64 * cb + 4 * fk, g[h], smem, tid);
+#endif
     }
   }
   if (Kd > 0 && any_lazy) first_loads();
