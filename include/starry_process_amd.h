@@ -453,6 +453,10 @@ int sp_debug_panel2_trace(long long *out);
  * 16 x 64 x 4 int64 (pivot block j, star, {first item start, block start, block end, CU key}), then
  * 16 x 1024 int32: the CU key + 1 of every workgroup of the launch (0: none).                     */
 int sp_debug_panel2_chain(long long *out);
+/* (debug, process-wide) the symmetric trailing update of a remainder of at least `blocks` 64-column blocks runs on
+ * 128 x 64 tiles (csrc/sp_gemm.hip, syrk128_kernel; default 17, environment SP_SYRK128_FROM; 0 = never, -1 = back to
+ * the default): which kernel multiplies, never what is computed -- the results are bit-identical.        */
+int sp_debug_set_syrk128_from(int blocks);
 /* (debug, host only) how the hot assembly kernel (csrc/sp_assemble.hip, assemble_sums_kernel) cuts a star's
  * ntr (ntr + 1) / 2 lower tiles (column-strip order) into nchunk chunks of equal COST: start_host[c] = first tile
  * of chunk c, c = 0 .. nchunk (start_host[nchunk] = the number of tiles).  A function of the shape alone.   */

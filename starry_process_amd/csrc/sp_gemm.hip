@@ -246,6 +246,72 @@ __global__ __launch_bounds__(256, SP_MM_WAVES) void mm_nt_kernel(
 }
 
 
+// The symmetric trailing update of a LARGE remainder on 128 x 64 tiles:  T -= X X^T  on the blocks on and below the
+// diagonal of an n x n block, n = nb 64.  Row tiles pair the block rows from the bottom up (block row 0 stays
+// out when nb is odd: it holds nothing but the pivot block); row tile I (block rows R0 = o + 2 I, R0 + 1, o = nb & 1)
+// takes the column blocks J = 0 .. R0 + 1; a wavefront owns 32 rows (MA = 2), i.e. one of the tile's two blocks: a
+// block above the diagonal -- (R0, R0 + 1) -- and the pivot block (0, 0) are computed and not stored (2.4 % of the
+// blocks at nb = 39).  One more workgroup factors the pivot block (DiagFuse), as in mm_nt_kernel.  Twice the
+// flops per operand byte and per barrier of the 64 x 64 tiles: 0.777 against 0.720 of the fp64 peak on a full
+// product of the size (tools/mm_tile_bench.py); for small remainders the wasted blocks weigh more than that
+// (nb = 8: 40 blocks executed for 35) and the 64 x 64 kernel stays (sp_launch_syrk_diag).
+using Syrk128Core = MM2<128, 64, 8, 4, 4>;
+__global__ __launch_bounds__(256) void syrk128_kernel(const double *__restrict__ X, long ld, long stride,
+                                                      double *__restrict__ T, int Kd, int batch, int nb, int ntiles,
+                                                      DiagFuse df) {
+  using Core = Syrk128Core;
+  static_assert(Core::LDS_DOUBLES >= SP_DIAG_LDS_DOUBLES, "the last workgroup of a star factors a pivot block in this LDS");
+  static_assert(Core::MA == 2 && Core::NA == 4, "a wavefront = 32 rows of one block row");
+  __shared__ __attribute__((aligned(16))) double lds[Core::LDS_DOUBLES];
+  int mtx, tile;
+  if (!sp_xcd_decode(blockIdx.x, batch, ntiles, mtx, tile)) return;
+  if (tile == 0) {
+    // the next pivot block carries every update already (the panel kernels keep it up to date)
+    if (df.sys) {
+      __builtin_amdgcn_s_setprio(3);
+      panel_diag_item(df.sys + (size_t)mtx * df.stride, df.ld, df.j, df.nact,
+                      df.img + (size_t)mtx * df.lts + sp_img_off(df.j), df.info ? df.info + mtx : nullptr, lds, threadIdx.x);
+    }
+    return;
+  }
+  tile -= 1;
+  const int o = nb & 1;
+  // tiles before row tile I: I^2 + I (o + 1)
+  int I = (int)((sqrt((double)((o + 1) * (o + 1) + 4 * tile)) - (o + 1)) * 0.5);
+  while (I * I + I * (o + 1) > tile) --I;
+  while ((I + 1) * (I + 1) + (I + 1) * (o + 1) <= tile) ++I;
+  const int J = tile - (I * I + I * (o + 1)), R0 = o + 2 * I;
+  const double *Xb = X + (size_t)mtx * stride;
+  const double *Ab = Xb + (size_t)R0 * 64 * ld, *Bb = Xb + (size_t)J * 64 * ld;
+  double *Cb = T + (size_t)mtx * stride + (size_t)R0 * 64 * ld + (size_t)J * 64;
+  Core mm;
+  mm.init(Ab, ld, Bb, ld);
+  mm.prologue(lds, 0, Kd);
+  // this wavefront's block row and whether its block is wanted
+  const int R = R0 + (mm.acc_row(0, 0) >> 6);
+  const bool want = R >= J && !(R == 0 && J == 0);
+  mm_d4 acc[Core::MA][Core::NA];
+#pragma unroll
+  for (int m = 0; m < Core::MA; ++m)
+#pragma unroll
+    for (int n = 0; n < Core::NA; ++n) {
+      mm_d4 c = mm_d4{0.0, 0.0, 0.0, 0.0};
+      if (want) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[r] = Cb[(size_t)mm.acc_row(m, r) * ld + mm.acc_col(n)];
+      }
+      acc[m][n] = -c;
+    }
+  mm.loop(lds, 0, Kd, acc);
+  if (!want) return;
+#pragma unroll
+  for (int m = 0; m < Core::MA; ++m)
+#pragma unroll
+    for (int n = 0; n < Core::NA; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cb[(size_t)mm.acc_row(m, r) * ld + mm.acc_col(n)] = -acc[m][n][r];
+}
+
 template <class Core>
 int mm_launch(const double *A, long lda, long strideA, const double *B, long ldb, long strideB,
               double *C, long ldc, long strideC, int Mrows, int Nrows, int Kd, double alpha, int beta,
@@ -328,6 +394,21 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
   return SP_OK;
 }
 
+// from how many 64-blocks on a remainder takes the 128 x 64 tiles (environment SP_SYRK128_FROM; 0 = never)
+static int g_syrk128_from = -1;
+static int syrk128_from() {
+  if (g_syrk128_from < 0) {
+    const char *e = getenv("SP_SYRK128_FROM");
+    g_syrk128_from = e ? atoi(e) : 17;
+    if (g_syrk128_from < 0) g_syrk128_from = 0;
+  }
+  return g_syrk128_from;
+}
+extern "C" int sp_debug_set_syrk128_from(int blocks) {
+  g_syrk128_from = blocks < 0 ? -1 : blocks;      // (-1: back to the environment / default)
+  return SP_OK;
+}
+
 // C -= X X^T on the lower 64 x 64 tiles of an n x n block, tile (0, 0) skipped -- its workgroup
 // factors the pivot block `df` describes instead (sp_cholesky.hip)
 int sp_launch_syrk_diag(const double *X, long ld, long stride, double *T, int n, int kd, int batch,
@@ -336,6 +417,18 @@ int sp_launch_syrk_diag(const double *X, long ld, long stride, double *T, int n,
   if ((n % GT) || (kd % 16) || kd <= 0 || (ld & 1) || (stride & 1) ||
       ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(T)) & 15))
     return SP_ERR_INVALID;
+  // large remainders without first-touch tiles or an identity riding along: 128 x 64 tiles (syrk128_kernel)
+  const int big_from = syrk128_from();
+  const int nb = n / GT;
+  if (big_from > 0 && nb >= big_from && !(lazy && lazy->theta) && tj_limit == 0 && (!df || df->tri0 < 0) && (kd % 16) == 0) {
+    const int o = nb & 1, nrt = (nb - o) / 2, ntiles = nrt * nrt + nrt * (o + 1) + 1;
+    const long nblk = sp_xcd_grid(batch, ntiles);
+    if (nblk > 0x7fffffffL) return SP_ERR_INVALID;
+    const DiagFuse d = df ? *df : DiagFuse{nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, -1, 0};
+    hipLaunchKernelGGL(syrk128_kernel, dim3((unsigned)nblk), dim3(256), 0, st, X, ld, stride, T, kd, batch, nb, ntiles, d);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+  }
   return mm_launch<MM2<64, 64, 8, SP_MM_SYRK_NS, 4>>(X, ld, stride, X, ld, stride, T, ld, stride, n, n, kd, -1.0, 1, 1,
                                          batch, st, 1 | (tj_limit > 0 ? tj_limit << 8 : 0),
                                          (lazy && lazy->theta) ? lazy : nullptr, df);

@@ -347,3 +347,25 @@ def test_deferred_normalisation_matches_direct():
                                             e[on].stars_to_device(make_stars(1, period=1.0, data_var=1e-6)),
                                             tab=tab, meanvar=mv)
         assert out.cpu().numpy()[0] == -np.inf and (status.cpu().numpy()[0] & 2)
+
+
+@pytest.mark.parametrize("K,kw", [(2100, {}), (2112, dict(tau=2.5)), (3000, dict(tau=3.0, u=(0.4, 0.2)))])
+def test_large_trailing_updates_on_128_row_tiles_are_the_same_bits(K, kw):
+    """Remainders of 17 blocks and more take the trailing update's 128 x 64 tiles (csrc/sp_gemm.hip, syrk128_kernel;
+    odd and even block counts, the pivot block's workgroup, blocks above the diagonal computed and dropped): same
+    k-order per entry as the 64 x 64 tiles, hence IDENTICAL log-likelihoods (the golden L20 / K = 3000 values pin them
+    against the reference: tests/test_gpu_golden*.py)."""
+    from starry_process_amd import _lib
+
+    L = _lib.lib()
+    res = []
+    try:
+        for frm in (0, 17):
+            assert L.sp_debug_set_syrk128_from(frm) == 0
+            e = make_engine(15)
+            v, st = lnl(e, K, range(3), **kw)
+            assert not st.any() and np.all(np.isfinite(v))
+            res.append(v)
+    finally:
+        L.sp_debug_set_syrk128_from(-1)
+    assert np.array_equal(res[0], res[1])
