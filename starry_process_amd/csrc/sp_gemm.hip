@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, SP_MM_WAVES) void mm_nt_kernel(
 using Syrk128Core = MM2<128, 64, 8, 4, 4>;
 __global__ __launch_bounds__(256) void syrk128_kernel(const double *__restrict__ X, long ld, long stride,
                                                       double *__restrict__ T, int Kd, int batch, int nb, int ntiles,
-                                                      DiagFuse df) {
+                                                      LazyCov lz, DiagFuse df) {
   using Core = Syrk128Core;
   static_assert(Core::LDS_DOUBLES >= SP_DIAG_LDS_DOUBLES, "the last workgroup of a star factors a pivot block in this LDS");
   static_assert(Core::MA == 2 && Core::NA == 4, "a wavefront = 32 rows of one block row");
@@ -286,17 +286,38 @@ __global__ __launch_bounds__(256) void syrk128_kernel(const double *__restrict__
   double *Cb = T + (size_t)mtx * stride + (size_t)R0 * 64 * ld + (size_t)J * 64;
   Core mm;
   mm.init(Ab, ld, Bb, ld);
-  mm.prologue(lds, 0, Kd);
   // this wavefront's block row and whether its block is wanted
   const int R = R0 + (mm.acc_row(0, 0) >> 6);
   const bool want = R >= J && !(R == 0 && J == 0);
+  // (first trailing update of a factorisation whose assembly left the tiles below the diagonal to their first
+  //  touch, sp_cov.h: a block of covariance rows is evaluated, not loaded -- per block, so per wavefront; the
+  //  evaluation is the workgroup's, the star's table passes through the LDS stages before the product claims them)
+  const auto is_lazy = [&](int Rb) {
+    return lz.theta && lz.tr0 + Rb > lz.tc0 + J && lz.tc0 + J > 0 && lz.tr0 + Rb < lz.nfull;
+  };
+  const bool any_lazy = is_lazy(R0) || is_lazy(R0 + 1), my_lazy = is_lazy(R);
   mm_d4 acc[Core::MA][Core::NA];
+  if (any_lazy) {
+#pragma unroll
+    for (int m = 0; m < Core::MA; ++m) {
+      int ri[4], cj[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        ri[k] = 64 * (lz.tr0 + R0) + mm.acc_row(m, k);
+        cj[k] = 64 * (lz.tc0 + J) + mm.acc_col(k);
+      }
+      lazy_cov_tile(lz, mtx, ri, cj, acc[m], lds);
+    }
+  }
+  mm.prologue(lds, 0, Kd);
 #pragma unroll
   for (int m = 0; m < Core::MA; ++m)
 #pragma unroll
     for (int n = 0; n < Core::NA; ++n) {
       mm_d4 c = mm_d4{0.0, 0.0, 0.0, 0.0};
-      if (want) {
+      if (any_lazy && my_lazy) {
+        c = acc[m][n];
+      } else if (want) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) c[r] = Cb[(size_t)mm.acc_row(m, r) * ld + mm.acc_col(n)];
       }
@@ -417,15 +438,16 @@ int sp_launch_syrk_diag(const double *X, long ld, long stride, double *T, int n,
   if ((n % GT) || (kd % 16) || kd <= 0 || (ld & 1) || (stride & 1) ||
       ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(T)) & 15))
     return SP_ERR_INVALID;
-  // large remainders without first-touch tiles or an identity riding along: 128 x 64 tiles (syrk128_kernel)
+  // large remainders without an identity riding along: 128 x 64 tiles (syrk128_kernel)
   const int big_from = syrk128_from();
   const int nb = n / GT;
-  if (big_from > 0 && nb >= big_from && !(lazy && lazy->theta) && tj_limit == 0 && (!df || df->tri0 < 0) && (kd % 16) == 0) {
+  if (big_from > 0 && nb >= big_from && tj_limit == 0 && (!df || df->tri0 < 0) && (kd % 16) == 0) {
     const int o = nb & 1, nrt = (nb - o) / 2, ntiles = nrt * nrt + nrt * (o + 1) + 1;
     const long nblk = sp_xcd_grid(batch, ntiles);
     if (nblk > 0x7fffffffL) return SP_ERR_INVALID;
     const DiagFuse d = df ? *df : DiagFuse{nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, -1, 0};
-    hipLaunchKernelGGL(syrk128_kernel, dim3((unsigned)nblk), dim3(256), 0, st, X, ld, stride, T, kd, batch, nb, ntiles, d);
+    const LazyCov lzv = (lazy && lazy->theta) ? *lazy : LazyCov{};
+    hipLaunchKernelGGL(syrk128_kernel, dim3((unsigned)nblk), dim3(256), 0, st, X, ld, stride, T, kd, batch, nb, ntiles, lzv, d);
     SP_LAUNCH_CHECK();
     return SP_OK;
   }

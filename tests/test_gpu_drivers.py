@@ -177,6 +177,7 @@ def test_layout_by_cu_and_fused_reduction_do_not_change_a_bit(K, M, S):
 @pytest.mark.parametrize("K,M,kw", [
     (200, 1, {}), (127, 1, {}), (128, 1, {}), (129, 1, {}), (513, 1, {}), (960, 70, {}), (1000, 1, {}),
     (1345, 1, {}), (1100, 5, {}), (1000, 1, dict(tau=2.5)), (1000, 1, dict(u=(0.4, 0.2))),
+    (2100, 1, {}), (2176, 2, {}),       # (first trailing update on 128 x 64 tiles: blocks formed per wavefront)
 ])
 def test_tiles_formed_at_first_touch_are_the_assembled_ones(K, M, kw):
     """sp_set_lazy_cov: the assembly leaves the tiles below the
