@@ -398,14 +398,16 @@ __global__ __launch_bounds__(256, SP_ASM_OCC) void assemble_sums_kernel(
   // STORES: loads and stores share one in-order counter, so the wait for the prefetched rows (the youngest
   // operations) was a wait for the row-sum and tile stores issued before them: 2.75 us per tile for 0.6 us of
   // arithmetic, whatever the arithmetic was (a gather with five instructions less per entry changed nothing).
+  int unsorted = 0;       // (Matern-3/2 only) some cadence of this star earlier than its predecessor
   {
-    double a[4], b[4];
+    double a[4], b[4], bp[4];
     for (int base = 0; base < Kp; base += 1024) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int i = base + tid + 256 * c;
         a[c] = i < K ? th[i] : 0.0;
         b[c] = (TK != SP_TEMPORAL_NONE && i < K) ? tt[i] : 0.0;
+        bp[c] = (TK == SP_TEMPORAL_MATERN32 && i > 0 && i < nobs) ? tt[i - 1] : -INFINITY;
       }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -414,6 +416,7 @@ __global__ __launch_bounds__(256, SP_ASM_OCC) void assemble_sums_kernel(
           s_th[i] = a[c];
           if (TK != SP_TEMPORAL_NONE) s_tt[i] = b[c];
         }
+        if (TK == SP_TEMPORAL_MATERN32 && i < nobs && !(b[c] >= bp[c])) unsorted = 1;
       }
     }
   }
@@ -435,8 +438,34 @@ __global__ __launch_bounds__(256, SP_ASM_OCC) void assemble_sums_kernel(
     }
   };
   spline_table_to_lds(ptab + (size_t)s * 4 * np, s_tab, np, tid);
-  __syncthreads();
+  // The Matern-3/2 factor (1 + x) exp(-x), x = sqrt(3) |t_i - t_j| / tau (temporal.py:8-11), SEPARATES below the
+  // diagonal of a light curve whose cadences are in order: exp(-c (t_i - t_j)) = exp(-c (t_i - b)) exp(c (t_j - b))
+  // for any b -- four exponentials per thread and tile (its rows; the columns' are a strip's) instead of sixteen,
+  // and no division (c = sqrt(3) / tau once).  A division, an exponential and the polynomial per entry were three
+  // times the spline's own cost: cfg5's assembly 351 us.  b = the strip's first cadence, so that the column
+  // factors are exp(c (span of 64 cadences)): a strip whose span would overflow that (c span > 600: a gap of
+  // years at a tau of hours), a light curve out of order, the diagonal tile (|t_i - t_j| both ways) and the last
+  // row tile (padding) take the entry-by-entry form.  The two forms agree to a few ulp, not bit for bit.
+  const bool in_order = TK == SP_TEMPORAL_MATERN32 ? !__syncthreads_or(unsorted) : (__syncthreads(), false);
+  const double cm = TK == SP_TEMPORAL_MATERN32 ? 1.7320508075688772 / st.tau : 0.0;
+  double bref = 0.0, fc[4] = {1.0, 1.0, 1.0, 1.0};
+  bool sep_strip = false;
+  auto strip_factors = [&](int tjj) {
+    if (TK != SP_TEMPORAL_MATERN32) return;
+    const int j0s = 64 * tjj, j1s = (j0s + 63 < nobs ? j0s + 63 : nobs - 1);
+    bref = s_tt[j0s];
+#ifdef SP_ASM_NO_SEP_MATERN
+    sep_strip = false;      // (A/B: every entry its own exponential)
+#else
+    sep_strip = in_order && j1s >= j0s && cm * (s_tt[j1s] - bref) < 600.0 && cm > 0.0;
+#endif
+    if (sep_strip) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) fc[e] = exp(cm * (tmj[e] - bref));
+    }
+  };
   load_cols(tj);
+  strip_factors(tj);
   load_rows(ti, thi, tmi);
   SplineGen g{s_tab, 2 * np, 6.283185307179586 / covpts, 1.0 / (6.283185307179586 / covpts), covpts};
   const double var1 = nobs == 1 ? meanvar[2 * st.table + 1] : 0.0;
@@ -472,7 +501,18 @@ __global__ __launch_bounds__(256, SP_ASM_OCC) void assemble_sums_kernel(
 #pragma unroll
       for (int k = 0; k < 16; ++k) v[k] = var1;
     }
-    if (TK != SP_TEMPORAL_NONE) {
+    if (TK == SP_TEMPORAL_MATERN32 && sep_strip && ti > tj && ti < ntr - 1) {
+      double er[4];
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) er[pass] = exp(-(cm * (tmi[pass] - bref)));
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const double x = cm * (tmi[pass] - tmj[e]);
+          v[4 * pass + e] *= (1.0 + x) * (er[pass] * fc[e]);
+        }
+    } else if (TK != SP_TEMPORAL_NONE) {
 #pragma unroll
       for (int pass = 0; pass < 4; ++pass)
 #pragma unroll
@@ -573,7 +613,10 @@ __global__ __launch_bounds__(256, SP_ASM_OCC) void assemble_sums_kernel(
         for (int e = 0; e < 4; ++e) csum[e] = 0.0;
         seg0 = -1;
       }
-      if (tile + 1 < t1) load_cols(tj + 1);
+      if (tile + 1 < t1) {
+        load_cols(tj + 1);
+        strip_factors(tj + 1);
+      }
     }
     if (ti == ntr - 1) {
       ++tj;
