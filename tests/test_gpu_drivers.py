@@ -304,6 +304,10 @@ def test_deferred_normalisation_matches_direct():
         "plain": dict(),
         "baseline": dict(baseline_var=3e-5, baseline_mean=2e-3),
         "temporal": dict(tau=2.5, temporal="matern32"),
+        # (the hot assembly separates the Matern factor only for cadences in order and strips of moderate span)
+        "temporal_out_of_order": dict(tau=2.5, temporal="matern32", swap=True),
+        "temporal_short_tau": dict(tau=1.0e-3, temporal="matern32"),
+        "temporal_ragged": dict(tau=2.5, temporal="matern32", nobs=[K, K - 1, 200, 65, 64, 63, 2]),
         "ragged": dict(nobs=[K, K - 1, 200, 65, 64, 63, 2]),
         "multi": dict(M=4),
         "vector_variance": dict(diag=1e-6 * (1.0 + rng.rand(S, K))),
@@ -313,6 +317,10 @@ def test_deferred_normalisation_matches_direct():
     for name, kw in cases.items():
         M = kw.get("M", 1)
         flux = np.array([[np.roll(st["flux"], 5 * m) for m in range(M)] for st in sts])
+        tt = t.copy()
+        if kw.get("swap"):
+            tt[:, [10, 11]] = tt[:, [11, 10]]
+            tt[2, [200, 100]] = tt[2, [100, 200]]
         res = {}
         for on in (0, 1):
             eng = e[on]
@@ -323,7 +331,7 @@ def test_deferred_normalisation_matches_direct():
             rta1 = eng.f64(eng.rTA1L([0.3, 0.1]))
             tab, mv = eng.kernel_table(rta1, 300)
             out, status = eng.lnlike_ensemble(
-                eng.f64(t), eng.f64(flux), eng.stars_to_device(stars),
+                eng.f64(tt), eng.f64(flux), eng.stars_to_device(stars),
                 diag=None if "diag" not in kw else eng.f64(kw["diag"]),
                 conditional=kw.get("conditional", False), covpts=300, tab=tab, meanvar=mv, rta1=rta1,
                 temporal=kw.get("temporal"), normalized=True)

@@ -290,7 +290,7 @@ def test_ragged_ensemble_equals_per_star_calls():
         ps.append(st["p"])
         dcs.append(1e-6 * (1 + rng.rand(n)))
     inc = [60.0, 35.0, 80.0, 15.0, 50.0, 70.0]
-    for kw in (dict(), dict(marginalize_over_inclination=False), dict(normalized=False, tau=2.0)):
+    for kw in (dict(), dict(marginalize_over_inclination=False), dict(normalized=False, tau=2.0), dict(tau=2.0)):
         sp = SP(15, **kw)
         for data_cov in (1e-6, dcs):
             ens = np.array(sp.log_likelihood_ensemble(ts, fs, data_cov, p=ps, i=inc, baseline_var=1e-7))
