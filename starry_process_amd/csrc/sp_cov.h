@@ -250,12 +250,27 @@ __device__ __forceinline__ void lazy_cov_row(const LazyCov &z, int star, int ri,
   const double thi = oi ? th[ri] : 0.0;
   double *s_thj = stage + 4 * np;      // the tile's 64 column phases, behind the table (zero beyond the cadences)
   {
-    // (a plain copy loop here: the unrolled form's 16 registers in flight spill the panel kernel's budget)
+    // the table in three 16-byte pieces per thread, all three loads (and the column phases') in flight before
+    // the first store: a plain copy loop waits out one memory round trip per iteration -- 2.4 of them per item,
+    // 5 us of a workgroup slot each time a tile is formed.  (Four pieces, spline_table_to_lds, cost this kernel
+    // its register budget; tables beyond 764 segments take the loop for the rest.)
     const double *src = z.ptab + (size_t)star * 4 * np;
-    for (int e = 2 * tid; e < 4 * np; e += 512)
-      *reinterpret_cast<dd2 *>(stage + e) = *reinterpret_cast<const dd2 *>(src + e);
-    const int cbase = c0 & ~63;
-    if (tid < 64) s_thj[tid] = cbase + tid < nobs ? th[cbase + tid] : 0.0;
+    const int n2 = 2 * np, cbase = c0 & ~63;
+    dd2 v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int e = tid + 256 * c;
+      v[c] = e < n2 ? *reinterpret_cast<const dd2 *>(src + 2 * e) : dd2{0.0, 0.0};
+    }
+    const double tj = (tid < 64 && cbase + tid < nobs) ? th[cbase + tid] : 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int e = tid + 256 * c;
+      if (e < n2) *reinterpret_cast<dd2 *>(stage + 2 * e) = v[c];
+    }
+    for (int e = tid + 768; e < n2; e += 256)
+      *reinterpret_cast<dd2 *>(stage + 2 * e) = *reinterpret_cast<const dd2 *>(src + 2 * e);
+    if (tid < 64) s_thj[tid] = tj;
   }
   __syncthreads();
   SplineGen g{stage, 2 * np, 6.283185307179586 / z.covpts,
