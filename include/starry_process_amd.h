@@ -48,6 +48,8 @@ typedef enum {
 #define SP_STAR_NOT_PD 1u   /* Cholesky pivot <= 0 or NaN (math.py:82-91)     */
 #define SP_STAR_ZMAX 2u     /* z > normalization_zmax (sp.py:1178-1183)       */
 #define SP_STAR_NAN 4u      /* NaN reached the final value (sp.py:1186-1188)  */
+#define SP_STAR_STALE_PLAN 8u /* sp_lnlike_ensemble_planned: the star's period, tau
+                               or nobs differ from the planned ones; value = NaN   */
 
 /* temporal kernels (reference temporal.py:8-16) */
 #define SP_TEMPORAL_NONE 0
@@ -273,6 +275,40 @@ int sp_lnlike_ensemble(sp_handle *h, int S, int K, int M, const double *t_dev,
                        int norm_order, double zmax, void *workspace_dev,
                        double *lnlike_dev, uint32_t *status_dev, void *stream);
 
+/* ---- the planned step (round 5): what depends on the DATA alone, taken out of the per-sample call -------------
+ * A sampler evaluates the likelihood of ONE data set (t, flux, data variances, periods) at many hyperparameter
+ * samples -- the reference fixes the data when the log-probability is built, calibrate/log_prob.py:7-55.  The
+ * normalisation (sp.py:705-727) needs m = mean(Sigma) before the factorisation, and rounds 2-4 took it -- with the
+ * row sums of Sigma -- from a pass over all K^2 entries per evaluation.  But the spline is linear in the kernel
+ * table, cov_ij = sum_k yp[s_ij + k] b_k(x0_ij) (flux.py:256-276, 322-330), so
+ *     m = sum_n yp[n] wbar[n] / K^2,   wbar[n] = sum_ij [s_ij + k = n] b_k(x0_ij) T_ij
+ * with wbar a function of (t, period, covpts[, tau]) only, and the row sums are not needed at all (DESIGN.md 4.7:
+ * Sigma 1 = B 1 - d).  sp_plan_data computes, once per data set: the cadences' phases theta = 2 pi mod(t / p, 1),
+ * wbar per star, the sums of each light curve's flux and of the per-cadence variances.  sp_lnlike_ensemble_planned
+ * is then sp_lnlike_ensemble(conditional = 0, normalized = 1) with the same results to rounding: its assembly
+ * evaluates only the tiles the factorisation wants in memory (every other tile is formed once, at first touch).
+ * The plan owns its device memory (about (K + covpts + M + 8) doubles per star); it is read-only afterwards and may
+ * be shared by any number of handles / streams of the same GPU.
+ *   t_dev [S,K], flux_dev [S,M,K], diag_dev [S,K] or NULL, stars_dev [S]: as for sp_lnlike_ensemble; what the plan
+ *   fixes of a star is its period, nobs and (temporal != NONE) tau -- table, baseline_mean, baseline_var, data_var
+ *   may change from call to call.  A call whose stars differ in a planned field returns NaN for that star and sets
+ *   SP_STAR_STALE_PLAN.  workspace_dev: sp_lnlike_workspace_bytes(S, K, M) bytes, used as scratch.
+ *   Synchronises `stream` (one-off: ~0.2 ms + the allocation).                                             */
+typedef struct sp_plan sp_plan;
+int sp_plan_data(sp_handle *h, int S, int K, int M, const double *t_dev, const double *flux_dev,
+                 const double *diag_dev, const sp_star *stars_dev, int covpts, int temporal,
+                 void *workspace_dev, void *stream, sp_plan **out);
+void sp_plan_destroy(sp_plan *plan);
+/* wbar of the plan, [S, covpts + 4] (host; for tests) */
+int sp_plan_get_wbar(const sp_plan *plan, double *wbar_host);
+/* The per-sample call on planned data: marginal branch, normalised (sp.py:1129-1188 with sp.py:705-727).  The
+ * data pointers must be the planned ones' contents (t, flux, diag are read again: residual rows, temporal
+ * factors, variances); shapes, covpts and the temporal kernel come from the plan.                          */
+int sp_lnlike_ensemble_planned(sp_handle *h, const sp_plan *plan, const double *t_dev, const double *flux_dev,
+                               const double *diag_dev, const sp_star *stars_dev, const double *tab_dev,
+                               const double *meanvar_dev, int norm_order, double zmax, void *workspace_dev,
+                               double *lnlike_dev, uint32_t *status_dev, void *stream);
+
 /* The factorisation stage alone: C_dev holds S assembled (K+M padded) systems
  * as produced internally; exposed for testing and for callers that assemble
  * their own covariance.  cov_dev: [S, K, K] (ld = K) full symmetric matrices
@@ -406,11 +442,12 @@ int sp_profile_begin_kinds(sp_handle *h, int max_launches, unsigned kind_mask);
 
 /* Normalised likelihoods (sp.py:705-727: C = c1 Sigma + z ((alpha + beta) p p^T - alpha q q^T),
  * q = row sums / (K m)), per handle:
- *   1 (default): deferred -- the assembly writes the raw covariance ONCE and takes its row sums in
+ *   1 (default): deferred -- the assembly writes the raw covariance ONCE and takes its sum in
  *                the same pass; the factorisation is that of Sigma + N / c1 and the rank-2 (and
  *                baseline) part is applied to the result by the matrix-determinant / Sherman-
- *                Morrison identities from three extra rows of the system (p, q, 1).  A workspace
- *                sized for this mode also serves the other one.
+ *                Morrison identities from one extra row of the system (L^-1 1; a second one, L^-1 d,
+ *                with per-cadence variances) and sums of the data.  A workspace sized for this mode
+ *                also serves the other one.
  *   0: the separate row-sum pass, then the normalised matrix assembled and factored as such.
  * The two agree to rounding (1e-12 relative on the BASELINE configurations); -inf for a matrix
  * that is not positive definite or z > zmax either way.  Set before sizing the workspace

@@ -43,8 +43,8 @@ int sp_launch_assemble_sums(int S, int K, int M, int Kp, const double *theta, co
                             int lazy_nfull);
 int sp_launch_defer_finish(int S, int K, int M, int Kp, const sp_star *stars, const double *meanvar,
                            const double *condmean, int order, double zmax, const double *part,
-                           const double *diag, double *sys, void *coef, uint32_t *status,
-                           double *rowsum, hipStream_t st);
+                           const double *diag, const double *flux, double *sys, void *coef, double *rscal,
+                           uint32_t *status, hipStream_t st);
 int sp_launch_cholesky_systems(sp_handle *h, double *sys, int S, int K, int Kp,
                                int32_t *info, double *invL, hipStream_t st);
 int sp_launch_cond_system(const double *B1, const double *A, int N, int Kr, int S, int K, int M, int Kp,
@@ -56,7 +56,8 @@ int sp_launch_cholesky_groups(sp_handle *h, int ngroups, const sp_chol_group *gr
 int sp_launch_lnlike_reduce(const double *sys, int S, int K, int M, int Kp,
                             const int32_t *info, double *lnlike, uint32_t *status,
                             hipStream_t st, uint32_t *status_out = nullptr,
-                            const sp_star *stars = nullptr, const void *defer_coef = nullptr);
+                            const sp_star *stars = nullptr, const void *defer_coef = nullptr,
+                            const double *rscal = nullptr, int dvec = 0);
 int sp_launch_pad_in(const double *A, int K, long lda, long strideA, double *sys,
                      int Kp, int M, const double *resid, int S, hipStream_t st, int ident = 0);
 int sp_launch_pad_out(const double *sys, int Kp, double *A, int K, long lda,
@@ -227,12 +228,13 @@ inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 struct Layout {
   int S, K, M, Kp, N, NWIG;
   int Kr;   // rows per star of the design-matrix buffers A, B1: roundup(K, 64), the rows beyond K zero
-  size_t theta, rowsum, qv, coef, info, status, condmean, cs, vrow, Rinc, invL, A,
+  size_t theta, rowsum, qv, coef, rscal, info, status, condmean, cs, vrow, Rinc, invL, A,
       B1, raw, part, sys, total;
 };
 
-// rows below the matrix that the deferred normalisation adds (p, q, 1; sp_assemble.hip)
-#define SP_DEFER_ROWS 3
+// rows below the matrix that the deferred normalisation adds (L^-1 1 and, with per-cadence variances, L^-1 d;
+// sp_reduce.h -- rounds 2-4: p, q, 1)
+#define SP_DEFER_ROWS 2
 
 Layout make_layout(const sp_handle *h, int S, int K, int M, bool with_sys) {
   Layout L;
@@ -256,6 +258,7 @@ Layout make_layout(const sp_handle *h, int S, int K, int M, bool with_sys) {
   L.rowsum = take(d * S * K);
   L.qv = take(d * S * K);
   L.coef = take(d * S * 8);
+  L.rscal = take(d * S * (SP_RSCAL_HEAD + (size_t)M));
   L.info = take(sizeof(int32_t) * S);
   L.status = take(sizeof(uint32_t) * S);
   L.condmean = take(d * S);
@@ -367,6 +370,7 @@ Layout sub_layout(const Layout &L, int s0, int Sg) {
   G.rowsum += z * L.K * d;
   G.qv += z * L.K * d;
   G.coef += z * 8 * d;
+  G.rscal += z * (SP_RSCAL_HEAD + (size_t)L.M) * d;
   G.info += z * sizeof(int32_t);
   G.status += z * sizeof(uint32_t);
   G.condmean += z * d;
@@ -422,7 +426,7 @@ int lnlike_assemble(sp_handle *h, const Layout &L, void *ws, int K, int M, const
                                       nullptr, flux_dev, sys, part, st)))
         return rc;
       return sp_launch_defer_finish(S, K, M, L.Kp, stars_dev, meanvar_dev, cm, norm_order, zmax, part,
-                                    diag_dev, sys, coef, status, rowsum, st);
+                                    diag_dev, flux_dev, sys, coef, at<double>(ws, L.rscal), status, st);
     }
     if ((rc = sp_launch_norm_coef(S, K, stars_dev, meanvar_dev, cm, 0, norm_order, zmax, rowsum, qv, coef,
                                   status, st)))
@@ -451,7 +455,7 @@ int lnlike_assemble(sp_handle *h, const Layout &L, void *ws, int K, int M, const
                               L.Kp, (long)L.Kp * L.Kp, st, part, lazy_nfull);
     if (rc) return rc;
     return sp_launch_defer_finish(S, K, M, L.Kp, stars_dev, meanvar_dev, condmean, norm_order, zmax,
-                                  part, diag_dev, sys, coef, status, rowsum, st);
+                                  part, diag_dev, flux_dev, sys, coef, at<double>(ws, L.rscal), status, st);
   }
   if (normalized)
     if ((rc = sp_launch_rowsum(S, K, theta, t_dev, stars_dev, cp, tab_dev, meanvar_dev,
@@ -467,14 +471,15 @@ int lnlike_assemble(sp_handle *h, const Layout &L, void *ws, int K, int M, const
 
 // stage C: reduction of one group's factored systems
 int lnlike_finish(const Layout &L, void *ws, int K, int M, double *lnlike_dev,
-                  uint32_t *status_dev, hipStream_t st, const sp_star *stars_dev, bool deferred) {
+                  uint32_t *status_dev, hipStream_t st, const sp_star *stars_dev, bool deferred, bool dvec) {
   const int S = L.S;
   int rc;
   uint32_t *status = at<uint32_t>(ws, L.status);
   if ((rc = sp_launch_lnlike_reduce(at<double>(ws, L.sys), S, K, M, L.Kp,
                                     at<int32_t>(ws, L.info), lnlike_dev, status, st,
                                     status_dev, stars_dev,
-                                    deferred ? at<double>(ws, L.coef) : nullptr)))
+                                    deferred ? at<double>(ws, L.coef) : nullptr,
+                                    deferred ? at<double>(ws, L.rscal) : nullptr, dvec ? 1 : 0)))
     return rc;
   return SP_OK;
 }
@@ -1176,7 +1181,8 @@ int sp_lnlike_ensemble(sp_handle *h, int S, int K, int M, const double *t_dev,
       CG[g].red = SpReduceArgs{lnlike_dev + s0, at<uint32_t>(ws, LG[g].status),
                                status_dev ? status_dev + s0 : nullptr, stars_dev + s0,
                                (normalized && h->defer_norm) ? (const void *)at<double>(ws, LG[g].coef) : nullptr,
-                               K, M, K + M + 3};
+                               at<double>(ws, LG[g].rscal), diag_dev ? 1 : 0, K, M,
+                               K + M + ((normalized && h->defer_norm) ? (diag_dev ? 2 : 1) : 0)};
   }
   // Tiles formed at first touch (LazyCov, sp_cov.h): the marginal path under the deferred
   // normalisation.
@@ -1208,7 +1214,7 @@ int sp_lnlike_ensemble(sp_handle *h, int S, int K, int M, const double *t_dev,
     int rc = fused_reduce ? SP_OK
                           : lnlike_finish(LG[g], ws, K, M, lnlike_dev + s0,
                                           status_dev ? status_dev + s0 : nullptr, CG[g].st, stars_dev + s0,
-                                          normalized && h->defer_norm);
+                                          normalized && h->defer_norm, diag_dev != nullptr);
     if (rc) return rc;
     if (g > 0) {
       SP_HIP(hipEventRecord(h->gdone[g - 1], CG[g].st));

@@ -371,7 +371,6 @@ __global__ __launch_bounds__(256, SP_ASM_OCC) void assemble_sums_kernel(
   const long long wall_begin = wall_clock64();
 #endif
   const sp_star st = stars[s];
-  const int ntiles = ntr * (ntr + 1) / 2;
   const int t0 = chunks.start[blockIdx.x], t1 = chunks.start[blockIdx.x + 1];
   if (t0 >= t1) return;
   // strip-major tile order: strip tj holds the tiles ti = tj .. ntr - 1
@@ -640,17 +639,54 @@ __global__ __launch_bounds__(256, SP_ASM_OCC) void assemble_sums_kernel(
 }
 
 // Deferred normalisation, second half: one workgroup per star.
-//   rowsum_r = sum over the column tiles of part[s][c][r]            (fixed order: deterministic)
+//   total = sum of the tiles' row / column partial sums of part[s][c][r]   (fixed order: deterministic)
 //   m, z, alpha(z), beta(z), c1 = alpha / mu^2                       (sp.py:705-727, ops/norm/norm.py:26-44)
-//   the system holds  B'' = Sigma + N / c1  (N: data variance): the diagonal gets N / c1 here
-//   three more rows below the residuals:  p = 1 - q,  q = rowsum / (K m),  1
-// C = c1 (B'' + d_p p p^T + d_q q q^T + d_1 1 1^T) with d_p = z (alpha + beta) / c1,
-// d_q = -z alpha / c1, d_1 = baseline_var / c1: lnlike_reduce_kernel finishes the job.
+//   the system holds  B = Sigma + D / c1  (D: data variance): the diagonal gets D / c1 here
+//   one more row below the residuals: 1 (valid cadences); with per-cadence variances a second one: d = diag(D) / c1
+//   rscal[s] = {K m, sum(d), delta, sum(r_0), ...}: what the reduction needs of q = Sigma 1 / (K m) without
+//   ever forming it (sp_reduce.h; rounds 2-4 wrote p = 1 - q and q as rows here)
+// C = c1 (B + d_p p p^T + d_q q q^T + d_1 1 1^T) with d_p = z (alpha + beta) / c1,
+// d_q = -z alpha / c1, d_1 = baseline_var / c1: the reduction finishes the job.
+__device__ __forceinline__ double block_sum_1024(double v, double *red) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  __syncthreads();                       // (red may still be read from the previous sum)
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double total = 0.0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) total += red[w];
+  return total;
+}
+
+// alpha(z), beta(z) of the normalisation series (ops/norm/norm.py:26-44) and the star's coefficients
+__device__ __forceinline__ Coef defer_coef(double m, double fmean, int order, double baseline_var) {
+  const double mu = 1.0 + fmean;
+  const double z = m / (mu * mu);
+  double fac = 1.0, alpha = 0.0, beta = 0.0;
+  for (int n = 0; n <= order; ++n) {
+    alpha += fac;
+    beta += 2 * n * fac;
+    fac *= z * (2 * n + 3);
+  }
+  const double c1 = alpha / (mu * mu);
+  Coef c;
+  c.c1 = c1;
+  c.zab = z * (alpha + beta) / c1;   // d_p
+  c.za = -z * alpha / c1;            // d_q
+  c.z = z;
+  c.gpmean = 0.0;
+  c.m = m;
+  c.mu = mu;
+  c.d1 = baseline_var / c1;          // d_1
+  return c;
+}
+
 __global__ __launch_bounds__(1024) void defer_finish_kernel(
     int K, int M, int Kp, int ntr, const sp_star *__restrict__ stars,
     const double *__restrict__ meanvar, const double *__restrict__ condmean, int order, double zmax,
-    const double *__restrict__ part, const double *__restrict__ diag, double *__restrict__ sys,
-    Coef *__restrict__ coef, uint32_t *__restrict__ status, double *__restrict__ rowsum) {
+    const double *__restrict__ part, const double *__restrict__ diag, const double *__restrict__ flux,
+    double *__restrict__ sys, Coef *__restrict__ coef, double *__restrict__ rscal,
+    uint32_t *__restrict__ status) {
   __shared__ double red[16];
   const int s = blockIdx.x;
   const sp_star st = stars[s];
@@ -659,7 +695,6 @@ __global__ __launch_bounds__(1024) void defer_finish_kernel(
   const double *P = part + (size_t)s * ntr * K;
   // (ragged stars: tiles beyond nobs contribute zeros)
   double mine = 0.0;
-  double *rs = rowsum + (size_t)s * K;   // (each thread re-reads only what it wrote itself)
   for (int r = threadIdx.x; r < K; r += 1024) {
     // the column tiles eight at a time: the loads of a group are independent, the sum keeps its order
     double a = 0.0;
@@ -671,49 +706,41 @@ __global__ __launch_bounds__(1024) void defer_finish_kernel(
       for (int c = 0; c < 8; ++c) a += v[c];
     }
     if (r >= nobs) a = 0.0;
-    rs[r] = a;
     mine += a;
   }
-  for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mine;
-  __syncthreads();
-  double total = 0.0;
-#pragma unroll
-  for (int w = 0; w < 16; ++w) total += red[w];
+  const double total = block_sum_1024(mine, red);
   const double fmean = condmean ? condmean[s] : meanvar[2 * st.table];
-  const double mu = 1.0 + fmean;
   const double m = total / ((double)nobs * (double)nobs);
-  const double z = m / (mu * mu);
-  double fac = 1.0, alpha = 0.0, beta = 0.0;
-  for (int n = 0; n <= order; ++n) {
-    alpha += fac;
-    beta += 2 * n * fac;
-    fac *= z * (2 * n + 3);
-  }
-  const double c1 = alpha / (mu * mu);
-  const double km = (double)nobs * m;
-  double *rowp = Mx + (size_t)(K + M) * Kp, *rowq = rowp + Kp, *row1 = rowq + Kp;
+  const Coef c = defer_coef(m, fmean, order, st.baseline_var);
+  const double c1 = c.c1;
+  double *row1 = Mx + (size_t)(K + M) * Kp, *rowd = row1 + Kp;
+  double sdm = 0.0;
   for (int r = threadIdx.x; r < K; r += 1024) {
-    const double a = rs[r];
     const bool ok = r < nobs;
-    const double q = ok ? a / km : 0.0;
-    rowp[r] = ok ? 1.0 - q : 0.0;
-    rowq[r] = q;
+    const double d = (diag ? diag[(size_t)s * K + r] : st.data_var) / c1;
     row1[r] = ok ? 1.0 : 0.0;
-    if (ok) Mx[(size_t)r * Kp + r] += (diag ? diag[(size_t)s * K + r] : st.data_var) / c1;
+    if (diag) rowd[r] = ok ? d : 0.0;
+    if (ok) {
+      Mx[(size_t)r * Kp + r] += d;
+      sdm += d;
+    }
+  }
+  double *rs = rscal + (size_t)s * (SP_RSCAL_HEAD + M);
+  const double delta = st.data_var / c1;
+  const double sd = diag ? block_sum_1024(sdm, red) : (double)nobs * delta;
+  for (int mm = 0; mm < M; ++mm) {
+    const double *f = flux + ((size_t)s * M + mm) * K;
+    double a = 0.0;
+    for (int r = threadIdx.x; r < nobs; r += 1024) a += f[r];
+    const double sf = block_sum_1024(a, red);
+    if (threadIdx.x == 0) rs[SP_RSCAL_HEAD + mm] = sf - (double)nobs * st.baseline_mean;
   }
   if (threadIdx.x == 0) {
-    Coef c;
-    c.c1 = c1;
-    c.zab = z * (alpha + beta) / c1;   // d_p
-    c.za = -z * alpha / c1;            // d_q
-    c.z = z;
-    c.gpmean = 0.0;
-    c.m = m;
-    c.mu = mu;
-    c.d1 = st.baseline_var / c1;       // d_1
+    rs[0] = (double)nobs * m;
+    rs[1] = sd;
+    rs[2] = delta;
     coef[s] = c;
-    if (status && z > zmax) atomicOr(&status[s], SP_STAR_ZMAX);
+    if (status && c.z > zmax) atomicOr(&status[s], SP_STAR_ZMAX);
   }
 }
 
@@ -876,7 +903,6 @@ int sp_launch_assemble_sums(int S, int K, int M, int Kp, const double *theta, co
                             const sp_star *stars, int covpts, const double *ptab, const double *meanvar,
                             int temporal, const double *flux, double *sys, hipStream_t st, double *part,
                             int lazy_nfull) {
-  const int np = covpts + 4;
   const size_t lds = sp_assemble_sums_lds(Kp, covpts, temporal);
   if (lds > SP_ASM_LDS_MAX || !ptab || !part) return SP_ERR_INVALID;
   const int ntr = Kp / 64, ntiles = ntr * (ntr + 1) / 2;
@@ -914,10 +940,10 @@ int sp_launch_assemble_sums(int S, int K, int M, int Kp, const double *theta, co
 
 int sp_launch_defer_finish(int S, int K, int M, int Kp, const sp_star *stars, const double *meanvar,
                            const double *condmean, int order, double zmax, const double *part,
-                           const double *diag, double *sys, void *coef, uint32_t *status,
-                           double *rowsum, hipStream_t st) {
+                           const double *diag, const double *flux, double *sys, void *coef, double *rscal,
+                           uint32_t *status, hipStream_t st) {
   hipLaunchKernelGGL(defer_finish_kernel, dim3(S), dim3(1024), 0, st, K, M, Kp, Kp / 64, stars, meanvar,
-                     condmean, order, zmax, part, diag, sys, (Coef *)coef, status, rowsum);
+                     condmean, order, zmax, part, diag, flux, sys, (Coef *)coef, rscal, status);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }

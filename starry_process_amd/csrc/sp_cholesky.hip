@@ -32,12 +32,14 @@ __global__ __launch_bounds__(256) void lnlike_reduce_kernel(
     const double *__restrict__ sys, long ld, long stride, int K, int M,
     const int32_t *__restrict__ info, double *__restrict__ lnlike,
     uint32_t *__restrict__ status, uint32_t *__restrict__ status_out,
-    const sp_star *__restrict__ stars, const RedCoef *__restrict__ coef) {
+    const sp_star *__restrict__ stars, const RedCoef *__restrict__ coef, const double *__restrict__ rscal,
+    int dvec) {
   __shared__ double red[48];
   const int s = blockIdx.x;
   lnlike_reduce_body<false>(sys + (size_t)s * stride, ld, K, M, info ? info + s : nullptr, lnlike + s,
                             status ? status + s : nullptr, status_out ? status_out + s : nullptr,
-                            stars ? stars + s : nullptr, coef ? coef + s : nullptr, red, threadIdx.x);
+                            stars ? stars + s : nullptr, coef ? coef + s : nullptr,
+                            rscal ? rscal + (size_t)s * (SP_RSCAL_HEAD + M) : nullptr, dvec, red, threadIdx.x);
 }
 
 // copy a batch of K x K matrices into zero/identity padded Kp x Kp systems
@@ -352,10 +354,11 @@ int sp_launch_cholesky_systems(sp_handle *h, double *sys, int S, int K, int Kp,
 int sp_launch_lnlike_reduce(const double *sys, int S, int K, int M, int Kp,
                             const int32_t *info, double *lnlike, uint32_t *status,
                             hipStream_t st, uint32_t *status_out, const sp_star *stars,
-                            const void *defer_coef) {
+                            const void *defer_coef, const double *rscal, int dvec) {
+  if (defer_coef && !rscal) return SP_ERR_INVALID;
   hipLaunchKernelGGL(lnlike_reduce_kernel, dim3(S), dim3(256), 0, st, sys,
                      (long)Kp, (long)Kp * Kp, K, M, info, lnlike, status, status_out, stars,
-                     (const RedCoef *)defer_coef);
+                     (const RedCoef *)defer_coef, rscal, dvec);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }

@@ -188,11 +188,15 @@ static_assert(sizeof(SpCoef) == 64, "8 doubles per star (Layout::coef, sub_layou
 // What the workgroup that factors a group's LAST pivot block does behind it (sp_panel.hip): the
 // log-likelihood reduction of its star (sp_reduce.h), when the residual / normalisation rows live in
 // that block's row tile and the block is factored in a panel launch's tail (sp_panel_fuses_reduce).
+// per-star scalars of the deferred normalisation's reduction (sp_reduce.h): {K m, sum(d), delta, sum(r_0), ...}
+#define SP_RSCAL_HEAD 3
 struct SpReduceArgs {
   double *lnlike;               // null: no reduction (plain factorisations)
   uint32_t *status, *status_out;
   const sp_star *stars;
   const void *coef;             // SpCoef per star (deferred normalisation) or null
+  const double *rscal;          // [S][SP_RSCAL_HEAD + M] (deferred normalisation)
+  int dvec;                     // per-cadence data variances: L^-1 d rides in row K + M + 1
   int K, M;
   int live_rows;                // rows of the padded system that carry data (0: all): the rest is identity padding
 };

@@ -245,7 +245,7 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
       const double *pb = sA + (16 * wave + fr) * PLDW + fk;   // own rows 64 h + 16 wave + fr
       // (NR = 2: unrolled by two k-steps only -- fully unrolled the scheduler hoists the fragment
       //  reads of all eight steps above the MFMAs and spills the accumulators)
-#pragma unroll(NR == 2 ? 2 : 8)
+#pragma clang loop unroll_count(NR == 2 ? 2 : 8)
       for (int kk = 0; kk < PK; kk += 4) {
         const double a0 = pa[kk], a1 = pa[16 * PLDW + kk], a2 = pa[32 * PLDW + kk], a3 = pa[48 * PLDW + kk];
 #pragma unroll
@@ -443,7 +443,9 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
                                  a.red.status ? a.red.status + mtx : nullptr,
                                  a.red.status_out ? a.red.status_out + mtx : nullptr,
                                  a.red.stars ? a.red.stars + mtx : nullptr,
-                                 a.red.coef ? static_cast<const RedCoef *>(a.red.coef) + mtx : nullptr, smem, tid);
+                                 a.red.coef ? static_cast<const RedCoef *>(a.red.coef) + mtx : nullptr,
+                                 a.red.coef ? a.red.rscal + (size_t)mtx * (SP_RSCAL_HEAD + a.red.M) : nullptr, a.red.dvec,
+                                 smem, tid);
       }
       __builtin_amdgcn_s_setprio(0);
       P2_CHAIN(2, wall_clock64());
