@@ -50,7 +50,7 @@ STAR_DTYPE = np.dtype(
 )
 assert STAR_DTYPE.itemsize == ctypes.sizeof(sp_star) == 56
 
-SP_STAR_NOT_PD, SP_STAR_ZMAX, SP_STAR_NAN = 1, 2, 4
+SP_STAR_NOT_PD, SP_STAR_ZMAX, SP_STAR_NAN, SP_STAR_STALE_PLAN = 1, 2, 4, 8
 TEMPORAL = {None: 0, "none": 0, "matern32": 1, "expsquared": 2}
 
 # name -> (restype, argtypes); every symbol the header declares
@@ -122,6 +122,10 @@ PROTOTYPES = {
         _I, [_V, _I, _I, _I, _V, _V, _V, _V, _I, _I, _V, _V, _V, _I, _I, _I, _D,
              _V, _V, _V, _V]),
     "sp_cholesky_lnlike_batched": (_I, [_V, _I, _I, _I, _V, _V, _V, _V, _V, _V]),
+    "sp_plan_data": (_I, [_V, _I, _I, _I, _V, _V, _V, _V, _I, _I, _V, _V, ctypes.POINTER(_V)]),
+    "sp_plan_destroy": (None, [_V]),
+    "sp_plan_get_wbar": (_I, [_V, _V]),
+    "sp_lnlike_ensemble_planned": (_I, [_V, _V, _V, _V, _V, _V, _V, _V, _I, _D, _V, _V, _V, _V]),
 }
 
 _lib = None

@@ -45,6 +45,11 @@ int sp_launch_defer_finish(int S, int K, int M, int Kp, const sp_star *stars, co
                            const double *condmean, int order, double zmax, const double *part,
                            const double *diag, const double *flux, double *sys, void *coef, double *rscal,
                            uint32_t *status, hipStream_t st);
+int sp_launch_assemble_planned(int S, int K, int M, int Kp, const PlanDev &plan, const double *t,
+                               const sp_star *stars, int covpts, const double *tab, const double *meanvar,
+                               int temporal, const double *flux, const double *diag, double *sys, int nfull,
+                               int order, double zmax, void *coef, double *rscal, double *ptab, int32_t *info,
+                               uint32_t *status, hipStream_t st);
 int sp_launch_cholesky_systems(sp_handle *h, double *sys, int S, int K, int Kp,
                                int32_t *info, double *invL, hipStream_t st);
 int sp_launch_cond_system(const double *B1, const double *A, int N, int Kr, int S, int K, int M, int Kp,
@@ -1221,6 +1226,46 @@ int sp_lnlike_ensemble(sp_handle *h, int S, int K, int M, const double *t_dev,
       SP_HIP(hipStreamWaitEvent(st, h->gdone[g - 1], 0));
     }
   }
+  return SP_OK;
+}
+
+// The per-sample call on planned data (sp_plan.hip): sp_lnlike_ensemble's marginal, normalised branch with the
+// pre-pass over the covariance's entries gone -- one assembly launch (only the tiles the factorisation wants in
+// memory, the normalisation's coefficients from the table and the plan's weights), then the factorisation.
+int sp_lnlike_ensemble_planned(sp_handle *h, const sp_plan *plan, const double *t_dev, const double *flux_dev,
+                               const double *diag_dev, const sp_star *stars_dev, const double *tab_dev,
+                               const double *meanvar_dev, int norm_order, double zmax, void *workspace_dev,
+                               double *lnlike_dev, uint32_t *status_dev, void *stream) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || !plan || !t_dev || !flux_dev || !stars_dev || !tab_dev || !meanvar_dev || !workspace_dev || !lnlike_dev ||
+      norm_order < 0 || norm_order > SP_NORM_MAXORDER)
+    return SP_ERR_INVALID;
+  if (plan->device != h->device || (diag_dev != nullptr) != (plan->has_diag != 0)) return SP_ERR_INVALID;
+  const int S = plan->S, K = plan->K, M = plan->M, covpts = plan->covpts, temporal = plan->temporal;
+  if (h->xp_covpts != covpts) return SP_ERR_STATE;
+  hipStream_t st = (hipStream_t)stream;
+  Layout L = make_layout(h, S, K, M, true);
+  void *ws = workspace_dev;
+  // (the stars' packed tables for the kernels that form tiles at first touch: the design-matrix region)
+  double *ptab = 4 * (size_t)(covpts + 4) > (size_t)L.Kr * L.N ? nullptr : at<double>(ws, L.A);
+  int lazy_nfull = 0;
+  if (h->lazy_cov && ptab && temporal == SP_TEMPORAL_NONE && K / SP_NB >= 2 &&
+      4 * (covpts + 4) + 64 <= SP_TILE_LDS_MIN)
+    lazy_nfull = K / SP_NB;
+  int rc = sp_launch_assemble_planned(S, K, M, L.Kp, plan->dev, t_dev, stars_dev, covpts, tab_dev, meanvar_dev, temporal,
+                                      flux_dev, diag_dev, at<double>(ws, L.sys), lazy_nfull, norm_order, zmax,
+                                      at<double>(ws, L.coef), at<double>(ws, L.rscal), ptab, at<int32_t>(ws, L.info),
+                                      at<uint32_t>(ws, L.status), st);
+  if (rc) return rc;
+  const bool fused_reduce = sp_panel_fuses_reduce(h, K, L.Kp);
+  sp_chol_group G{at<double>(ws, L.sys), at<int32_t>(ws, L.info), at<double>(ws, L.invL), S, st, LazyCov{}, SpReduceArgs{}};
+  if (fused_reduce)
+    G.red = SpReduceArgs{lnlike_dev, at<uint32_t>(ws, L.status), status_dev, stars_dev, (const void *)at<double>(ws, L.coef),
+                         at<double>(ws, L.rscal), diag_dev ? 1 : 0, K, M, K + M + (diag_dev ? 2 : 1)};
+  if (lazy_nfull)
+    G.lazy = LazyCov{plan->dev.theta, t_dev, stars_dev, ptab, K, covpts, temporal, lazy_nfull, 0, 0};
+  if ((rc = sp_launch_cholesky_groups(h, 1, &G, K, L.Kp))) return rc;
+  if (!fused_reduce) return lnlike_finish(L, ws, K, M, lnlike_dev, status_dev, st, stars_dev, true, diag_dev != nullptr);
   return SP_OK;
 }
 

@@ -185,6 +185,21 @@ struct SpCoef {
 };
 static_assert(sizeof(SpCoef) == 64, "8 doubles per star (Layout::coef, sub_layout)");
 
+// The data plan of the likelihood step (sp_plan.hip; include/starry_process_amd.h: sp_plan_data): device pointers
+struct PlanDev {
+  const double *theta;     // [S][K] phases 2 pi mod(t / p, 1)
+  const double *wbar;      // [S][covpts + 4] weight of every kernel-table entry in the sum of the covariance
+  const double *sflux;     // [S][M] sums of the light curves over the valid cadences
+  const double *sdv;       // [S] sum of the per-cadence variances over the valid cadences (0 without them)
+  const double *key;       // [S][3] period, tau, nobs as planned
+};
+struct sp_plan {
+  int device, S, K, M, covpts, temporal, has_diag;
+  void *buf;               // one device allocation behind the pointers of `dev`
+  size_t bytes;
+  PlanDev dev;
+};
+
 // What the workgroup that factors a group's LAST pivot block does behind it (sp_panel.hip): the
 // log-likelihood reduction of its star (sp_reduce.h), when the residual / normalisation rows live in
 // that block's row tile and the block is factored in a panel launch's tail (sp_panel_fuses_reduce).

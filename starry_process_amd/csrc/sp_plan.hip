@@ -16,6 +16,8 @@
 //   key       period, tau, nobs as planned (a call with other values gets NaN and SP_STAR_STALE_PLAN).
 //
 // Compiled with -ffp-contract=off: the segment index must be the reference's int64 floor(x / dx) bit for bit.
+#include <new>
+
 #include "sp_internal.h"
 #include "sp_cov.h"
 

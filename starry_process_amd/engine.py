@@ -13,7 +13,7 @@ from . import _lib
 from . import hostconst
 from ._lib import STAR_DTYPE, TEMPORAL, SPError, c_void_p, check, hptr
 
-__all__ = ["Engine", "get_engine", "make_stars"]
+__all__ = ["Engine", "DataPlan", "get_engine", "make_stars"]
 
 
 def _torch():
@@ -503,6 +503,37 @@ class Engine(object):
             float(zmax), self._p(ws), self._p(out), self._p(status), self._stream()))
         return out, status
 
+    def plan_data(self, t, flux, stars_dev, diag=None, covpts=300, temporal=None, workspace=None):
+        """What depends on the data alone, once per data set (sp_plan_data): phases, the weights of the kernel
+        table in the covariance's sum, sums of the flux and of the variances.  t [S,K], flux [S,M,K] device
+        tensors, stars_dev from stars_to_device().  The plan fixes the stars' period, nobs and tau; it may be
+        shared by every engine of this GPU.  Returns a ``DataPlan``."""
+        S, K = t.shape
+        M = flux.shape[1]
+        ws = workspace if workspace is not None else self.workspace(S, K, M)
+        p = c_void_p()
+        check(self._L.sp_plan_data(self._h, S, K, M, self._p(t), self._p(flux), self._p(diag), self._p(stars_dev),
+                                   int(covpts), TEMPORAL[temporal], self._p(ws), self._stream(), ctypes.byref(p)))
+        return DataPlan(self._L, p, S, K, M, int(covpts), temporal, diag is not None)
+
+    def lnlike_ensemble_planned(self, plan, t, flux, stars_dev, tab, meanvar, diag=None, norm_order=20,
+                                zmax=0.023, out=None, status=None, workspace=None):
+        """``lnlike_ensemble(conditional=False, normalized=True)`` on planned data (sp_lnlike_ensemble_planned):
+        the same values to rounding, without the per-sample pass over the covariance's entries."""
+        torch = _torch()
+        S, K, M = plan.S, plan.K, plan.M
+        assert tuple(t.shape) == (S, K) and tuple(flux.shape) == (S, M, K)
+        ws = workspace if workspace is not None else self.workspace(S, K, M)
+        if out is None:
+            out = self.empty(S)
+        if status is None:
+            status = torch.zeros(S, dtype=torch.int32, device=self.device)
+        check(self._L.sp_lnlike_ensemble_planned(
+            self._h, plan.ptr, self._p(t), self._p(flux), self._p(diag), self._p(stars_dev), self._p(tab),
+            self._p(meanvar), int(norm_order), float(zmax), self._p(ws), self._p(out), self._p(status),
+            self._stream()))
+        return out, status
+
     def lnlike_grad_marginal(self, t, flux, stars_dev, tab, meanvar, diag=None, covpts=300, temporal=None,
                              normalized=True, norm_order=20, zmax=0.023, workspace=None):
         """Device half of the ensemble gradient (sp_lnlike_grad_marginal): t [S, K], flux [S, K] or [S, 1, K] ->
@@ -541,6 +572,28 @@ class Engine(object):
         check(self._L.sp_cholesky_lnlike_batched(self._h, S, K, M, self._p(cov), self._p(resid),
                                                  self._p(ws), self._p(out), self._p(status), self._stream()))
         return out, status
+
+
+class DataPlan(object):
+    """Owner of an ``sp_plan`` (include/starry_process_amd.h: sp_plan_data)."""
+
+    def __init__(self, L, ptr, S, K, M, covpts, temporal, has_diag):
+        self._L, self.ptr = L, ptr
+        self.S, self.K, self.M, self.covpts, self.temporal, self.has_diag = S, K, M, covpts, temporal, has_diag
+
+    def wbar(self):
+        """[S, covpts + 4] host copy of the table's weights in the covariance's sum."""
+        out = np.empty((self.S, self.covpts + 4))
+        check(self._L.sp_plan_get_wbar(self.ptr, hptr(out)))
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                self._L.sp_plan_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
 
 
 _engines = {}
