@@ -19,7 +19,10 @@ One "step" = one hyperparameter sample of an MCMC / nested-sampling loop:
   polar-frame moments of (mu_y, Sigma_y)   (sp_set_ylm_moments_dev)
   -> inclination-marginal kernel table      (sp_kernel_table)
   -> covariance assembly + Cholesky + solve + reduction for every star
-                                            (sp_lnlike_ensemble)
+                                            (sp_lnlike_ensemble_planned: the data set -- t, flux, variances,
+                                             periods -- is PLANNED once, untimed, by sp_plan_data, as the
+                                             reference fixes it when calibrate.get_log_prob is built;
+                                             `unplanned` reports sp_lnlike_ensemble, which plans nothing)
   -> N > 1: RCCL all-gather of the per-star log-likelihoods (torch.distributed).
 Consecutive steps are independent samples (the walkers / live points a sampler
 evaluates per iteration), so --in-flight F of them (default 4) are kept in flight:
@@ -174,6 +177,7 @@ class Slot(object):
         self.gathered = engine.empty(world * S) if use_dist else None
         self.covpts, self.conditional = covpts, conditional
         self.inputs = None
+        self.plan = None          # a DataPlan: the step goes through sp_lnlike_ensemble_planned
 
     def bind(self, **inputs):
         self.inputs = inputs
@@ -184,9 +188,13 @@ class Slot(object):
         tab = mv = None
         if not self.conditional:
             tab, mv = e.kernel_table(a["rta1_d"], self.covpts)
-        e.lnlike_ensemble(a["t_d"], a["f_d"], a["stars_d"], conditional=self.conditional, covpts=self.covpts,
-                          tab=tab, meanvar=mv, rta1=a["rta1_d"], temporal=a.get("temporal"), normalized=True,
-                          out=self.out, status=self.status, workspace=self.ws)
+        if self.plan is not None:
+            e.lnlike_ensemble_planned(self.plan, a["t_d"], a["f_d"], a["stars_d"], tab, mv, out=self.out,
+                                      status=self.status, workspace=self.ws)
+        else:
+            e.lnlike_ensemble(a["t_d"], a["f_d"], a["stars_d"], conditional=self.conditional, covpts=self.covpts,
+                              tab=tab, meanvar=mv, rta1=a["rta1_d"], temporal=a.get("temporal"), normalized=True,
+                              out=self.out, status=self.status, workspace=self.ws)
         if self.use_dist:
             # issued from this step's stream: torch orders the collectives of one communicator in
             # program order (the same on every rank), and only this step waits for its own
@@ -255,9 +263,9 @@ def roofline_entry(kind, rec, extra=None):
     return d
 
 
-def bench_shape(torch, dist, ydeg, Kc, S, tspan, tau, u, conditional, F, steps, device):
+def bench_shape(torch, dist, ydeg, Kc, S, tspan, tau, u, conditional, F, steps, device, planned=False):
     """evals/s and whole-step roofline fraction of another BASELINE shape on this GPU (same
-    in-flight scheme, its own handles; 6 untimed steps first)."""
+    in-flight scheme, its own handles; 6 untimed steps first).  planned: the data set planned once (untimed)."""
     from starry_process_amd.engine import engine_slots, make_stars
     from starry_process_amd.synthetic import synthetic_star
 
@@ -280,6 +288,11 @@ def bench_shape(torch, dist, ydeg, Kc, S, tspan, tau, u, conditional, F, steps, 
         sl = Slot(torch, ek, stream, S, Kc, 1, False, dist, COVPTS, conditional)
         sl.bind(**inputs)
         slots.append(sl)
+    if planned and not conditional:
+        plan = e0.plan_data(inputs["t_d"], inputs["f_d"], inputs["stars_d"], covpts=COVPTS, temporal=inputs["temporal"],
+                            workspace=slots[0].ws)
+        for sl in slots:
+            sl.plan = plan
     h = Harness(slots, torch.cuda.synchronize)
     elapsed, _, _ = timed_steps(h, steps, 6, 0.0, None)
     ms = 1e3 * elapsed / steps
@@ -287,6 +300,7 @@ def bench_shape(torch, dist, ydeg, Kc, S, tspan, tau, u, conditional, F, steps, 
     fl, by = step_work(S, Kc, 1, N)
     res = {"ydeg": ydeg, "K": Kc, "stars": S, "conditional": bool(conditional),
            "temporal": "matern32" if tau else None, "u": list(u), "steps": steps, "steps_in_flight": F,
+           "planned_data": bool(planned and not conditional),
            "evals_per_s": S * steps / elapsed, "ms_per_step": ms,
            "whole_step_TFLOPs": fl / (ms * 1e-3) / 1e12,
            "whole_step_frac": fl / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
@@ -520,6 +534,9 @@ def main():
     ap.add_argument("--cpu-stars", type=int, default=1024,
                     help="stars of the CPU-baseline sample (about 25 core-seconds of the C pipeline)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--unplanned", action="store_true",
+                    help="the headline through sp_lnlike_ensemble (nothing planned: the pre-pass over the covariance's "
+                         "entries in every step) instead of sp_plan_data + sp_lnlike_ensemble_planned")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the cfg5-shape and conditional-branch measurements (after the headline)")
     args = ap.parse_args()
@@ -586,6 +603,19 @@ def main():
         sl.bind(**inputs)
         slots.append(sl)
     torch.cuda.synchronize()
+    # The data plan (sp_plan_data): once per data set, UNTIMED -- phases, the kernel table's weights in the covariance's
+    # sum, sums of flux and variances.  One plan, read-only, shared by every slot.  Its cost is reported (second call:
+    # the first one loads the kernels' code).
+    plan, plan_ms = None, None
+    if not args.unplanned:
+        plan = e.plan_data(inputs["t_d"], inputs["f_d"], inputs["stars_d"], covpts=COVPTS, workspace=slots[0].ws)
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        plan = e.plan_data(inputs["t_d"], inputs["f_d"], inputs["stars_d"], covpts=COVPTS, workspace=slots[0].ws)
+        torch.cuda.synchronize()
+        plan_ms = 1e3 * (time.perf_counter() - tp)
+        for sl in slots:
+            sl.plan = plan
     if use_dist:
         # communicator set-up (lazy in RCCL) must not land in the timed region even with --warmup 0
         dist.all_gather_into_tensor(slots[0].gathered, slots[0].out)
@@ -664,6 +694,7 @@ def main():
     if world == 1:
         c0 = Slot(torch, e, torch.cuda.current_stream(), S, K, world, False, dist, COVPTS)
         c0.bind(**inputs)
+        c0.plan = plan
         e.set_moments(mu, Sig)
         nrep = 100    # (0.1 s: a 20-step sample of this latency-bound leg scatters by 8 % from run to run)
         for _ in range(10):
@@ -730,13 +761,50 @@ def main():
         fls, _ = step_work(S, K)
         sustained["whole_step_frac"] = fls / (sustained["ms_per_step"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
 
+    # the same workload with nothing planned (sp_lnlike_ensemble: phases, the pre-pass over all K^2 entries for the
+    # normalisation's sums, in every step) -- what a caller whose periods change from sample to sample gets; not `value`
+    unplanned = None
+    if world == 1 and plan is not None and not args.no_extras:
+        for sl in slots + [c0]:
+            sl.plan = None
+        for i in range(3 * F):
+            slots[i % F].run()
+        torch.cuda.synchronize()
+        nun = 120
+        t1 = time.perf_counter()
+        for i in range(nun):
+            slots[i % F].run()
+        torch.cuda.synchronize()
+        dtu = time.perf_counter() - t1
+        for _ in range(5):
+            c0.step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(50):
+            c0.step()
+        torch.cuda.synchronize()
+        dt1u = time.perf_counter() - t1
+        lnl_un = slots[0].out.cpu().numpy().copy()
+        unplanned = {"steps": nun, "steps_in_flight": F, "evals_per_s": S * nun / dtu, "ms_per_step": 1e3 * dtu / nun,
+                     "one_step_at_a_time_ms": 1e3 * dt1u / 50,
+                     "max_rel_diff_planned": float(np.max(np.abs(lnl_un / lnl - 1))),
+                     "note": "sp_lnlike_ensemble on the same inputs: theta, assembly pre-pass (every entry evaluated for "
+                             "the normalisation's sums, then again at first touch), normalisation vectors per step"}
+        for sl in slots + [c0]:
+            sl.plan = plan
+
     # the other shapes of BASELINE.json, after the headline and never in `value`
     extras = None
     if world == 1 and not args.no_extras:
         extras = {}
         try:
             extras["cfg5_shape"] = bench_shape(torch, dist, ydeg=20, Kc=3000, S=32, tspan=30.0, tau=3.0,
-                                               u=(0.4, 0.2), conditional=False, F=F, steps=12, device=local_rank)
+                                               u=(0.4, 0.2), conditional=False, F=F, steps=12, device=local_rank,
+                                               planned=plan is not None)
+            if plan is not None:
+                extras["cfg5_shape_unplanned"] = bench_shape(torch, dist, ydeg=20, Kc=3000, S=32, tspan=30.0, tau=3.0,
+                                                             u=(0.4, 0.2), conditional=False, F=F, steps=12,
+                                                             device=local_rank)
             extras["cfg3_conditional"] = bench_shape(torch, dist, ydeg=15, Kc=1000, S=64, tspan=4.0, tau=None,
                                                      u=(0.0, 0.0), conditional=True, F=F, steps=24,
                                                      device=local_rank)
@@ -848,7 +916,14 @@ def main():
                             "normalized, covpts=300 (cfg4 = the same at 8 GPUs: 512 stars, RCCL all-gather)",
                 "stars_per_gpu": S, "ydeg": YDEG, "K": K, "parallelism": "stars sharded %d-way" % world,
                 "steps_in_flight": F,
+                "planned_data": plan is not None,
             },
+            "plan": (None if plan is None else {
+                "ms": plan_ms, "timed": False,
+                "note": "sp_plan_data, once per data set (t, flux, variances, periods), outside every timed region: "
+                        "phases, the kernel table's weights in the covariance's sum (covpts + 4 per star), sums of "
+                        "flux / variances; one plan shared by all slots"}),
+            "unplanned": unplanned,
             "parity_ok": ok,
             "prewarm": {"steps": prewarm_steps, "min_ms": args.prewarm_ms, "timed": False},
             "steps_in_flight": F,

@@ -193,6 +193,13 @@ class EnsembleLogProb(object):
                         covpts=defaults["covpts"] if covpts is None else int(covpts))
         self._marg = bool(marginalize_over_inclination)
         self._ydeg, self._apply_jac = int(ydeg), bool(apply_jac)
+        # The data are fixed from here on (calibrate/log_prob.py:7-55 fixes them the same way): what depends on them
+        # alone -- phases, the kernel table's weights in the covariance's sum, the sums of the flux -- is taken once
+        # (sp_plan_data), and every sample goes through the planned call: no pass over the K^2 entries of every
+        # star's covariance before its factorisation.  One plan, read-only, shared by the slots.
+        self._plan = None
+        if self._marg and normalized and hi - lo > 0 and K >= 2:
+            self._plan = e0.plan_data(self._t, self._flux, self._stars, covpts=self._kw["covpts"], workspace=self._ws[0])
         torch.cuda.synchronize(e0.device)
 
     def __call__(self, samples):
@@ -225,9 +232,13 @@ class EnsembleLogProb(object):
                     tab = mv = None
                     if self._marg:
                         tab, mv = e.kernel_table(self._rta1, self._kw["covpts"])
-                    e.lnlike_ensemble(self._t, self._flux, self._stars, tab=tab, meanvar=mv,
-                                      rta1=self._rta1, out=outs[k], workspace=self._ws[k % len(self._slots)],
-                                      **self._kw)
+                    if self._plan is not None:
+                        e.lnlike_ensemble_planned(self._plan, self._t, self._flux, self._stars, tab, mv, out=outs[k],
+                                                  workspace=self._ws[k % len(self._slots)])
+                    else:
+                        e.lnlike_ensemble(self._t, self._flux, self._stars, tab=tab, meanvar=mv,
+                                          rta1=self._rta1, out=outs[k], workspace=self._ws[k % len(self._slots)],
+                                          **self._kw)
         torch.cuda.synchronize(e0.device)
         vals = outs[:, :nl]
         vals = torch.where(torch.isnan(vals), torch.full_like(vals, -float("inf")), vals)

@@ -49,7 +49,7 @@ int sp_launch_assemble_planned(int S, int K, int M, int Kp, const PlanDev &plan,
                                const sp_star *stars, int covpts, const double *tab, const double *meanvar,
                                int temporal, const double *flux, const double *diag, double *sys, int nfull,
                                int order, double zmax, void *coef, double *rscal, double *ptab, int32_t *info,
-                               uint32_t *status, hipStream_t st);
+                               uint32_t *status, hipStream_t st, double *img, long lts, int fuse0);
 int sp_launch_cholesky_systems(sp_handle *h, double *sys, int S, int K, int Kp,
                                int32_t *info, double *invL, hipStream_t st);
 int sp_launch_cond_system(const double *B1, const double *A, int N, int Kr, int S, int K, int M, int Kp,
@@ -1252,18 +1252,23 @@ int sp_lnlike_ensemble_planned(sp_handle *h, const sp_plan *plan, const double *
   if (h->lazy_cov && ptab && temporal == SP_TEMPORAL_NONE && K / SP_NB >= 2 &&
       4 * (covpts + 4) + 64 <= SP_TILE_LDS_MIN)
     lazy_nfull = K / SP_NB;
+  // (pivot block 0 is factored by the assembly's workgroup of tile (0, 0): no launch of its own; SP_PLAN_FUSE0=0 for
+  //  the separate launch)
+  static const bool fuse0_env = !(getenv("SP_PLAN_FUSE0") && atoi(getenv("SP_PLAN_FUSE0")) == 0);
+  const int fuse0 = (fuse0_env && K >= SP_NB) ? 1 : 0;
   int rc = sp_launch_assemble_planned(S, K, M, L.Kp, plan->dev, t_dev, stars_dev, covpts, tab_dev, meanvar_dev, temporal,
                                       flux_dev, diag_dev, at<double>(ws, L.sys), lazy_nfull, norm_order, zmax,
                                       at<double>(ws, L.coef), at<double>(ws, L.rscal), ptab, at<int32_t>(ws, L.info),
-                                      at<uint32_t>(ws, L.status), st);
+                                      at<uint32_t>(ws, L.status), st, at<double>(ws, L.invL), sp_lt_stride(L.Kp), fuse0);
   if (rc) return rc;
   const bool fused_reduce = sp_panel_fuses_reduce(h, K, L.Kp);
   sp_chol_group G{at<double>(ws, L.sys), at<int32_t>(ws, L.info), at<double>(ws, L.invL), S, st, LazyCov{}, SpReduceArgs{}};
   if (fused_reduce)
     G.red = SpReduceArgs{lnlike_dev, at<uint32_t>(ws, L.status), status_dev, stars_dev, (const void *)at<double>(ws, L.coef),
                          at<double>(ws, L.rscal), diag_dev ? 1 : 0, K, M, K + M + (diag_dev ? 2 : 1)};
+  G.block0_done = fuse0 != 0;
   if (lazy_nfull)
-    G.lazy = LazyCov{plan->dev.theta, t_dev, stars_dev, ptab, K, covpts, temporal, lazy_nfull, 0, 0};
+    G.lazy = LazyCov{plan->dev.theta, t_dev, stars_dev, ptab, K, covpts, temporal, lazy_nfull, 0, 0, 1};
   if ((rc = sp_launch_cholesky_groups(h, 1, &G, K, L.Kp))) return rc;
   if (!fused_reduce) return lnlike_finish(L, ws, K, M, lnlike_dev, status_dev, st, stars_dev, true, diag_dev != nullptr);
   return SP_OK;

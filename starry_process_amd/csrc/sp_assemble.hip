@@ -19,6 +19,7 @@
 
 #include "sp_internal.h"
 #include "sp_cov.h"
+#include "sp_asm.h"
 
 namespace {
 
@@ -347,11 +348,6 @@ __global__ __launch_bounds__(256) void assemble_kernel(
 #ifdef SP_ASM_STAMPS
 __device__ long long sp_asm_dbg[8 * 8192];
 #endif
-// first tile of every chunk (strip-major order), by value in the kernel arguments: see asm_chunks() below
-#define SP_ASM_MAX_CHUNKS 511
-struct AsmChunks {
-  unsigned short start[SP_ASM_MAX_CHUNKS + 1];
-};
 #ifndef SP_ASM_BATCH
 #define SP_ASM_BATCH 16      // entries per SplineGen::many batch (4, 8 or 16)
 #endif
@@ -658,29 +654,6 @@ __device__ __forceinline__ double block_sum_1024(double v, double *red) {
   return total;
 }
 
-// alpha(z), beta(z) of the normalisation series (ops/norm/norm.py:26-44) and the star's coefficients
-__device__ __forceinline__ Coef defer_coef(double m, double fmean, int order, double baseline_var) {
-  const double mu = 1.0 + fmean;
-  const double z = m / (mu * mu);
-  double fac = 1.0, alpha = 0.0, beta = 0.0;
-  for (int n = 0; n <= order; ++n) {
-    alpha += fac;
-    beta += 2 * n * fac;
-    fac *= z * (2 * n + 3);
-  }
-  const double c1 = alpha / (mu * mu);
-  Coef c;
-  c.c1 = c1;
-  c.zab = z * (alpha + beta) / c1;   // d_p
-  c.za = -z * alpha / c1;            // d_q
-  c.z = z;
-  c.gpmean = 0.0;
-  c.m = m;
-  c.mu = mu;
-  c.d1 = baseline_var / c1;          // d_1
-  return c;
-}
-
 __global__ __launch_bounds__(1024) void defer_finish_kernel(
     int K, int M, int Kp, int ntr, const sp_star *__restrict__ stars,
     const double *__restrict__ meanvar, const double *__restrict__ condmean, int order, double zmax,
@@ -741,268 +714,6 @@ __global__ __launch_bounds__(1024) void defer_finish_kernel(
     rs[2] = delta;
     coef[s] = c;
     if (status && c.z > zmax) atomicOr(&status[s], SP_STAR_ZMAX);
-  }
-}
-
-// ---- the planned step's assembly (round 5) -----------------------------------------------------------------
-// With a data plan (sp_plan.hip) nothing of the normalisation needs the covariance's entries before the
-// factorisation: m = yp . wbar / K^2, and the reduction takes q's Gram entries from rows that ride anyway
-// (sp_reduce.h).  What is left of the assembly is to put in memory the tiles the factorisation wants THERE:
-//   * with tiles formed at first touch (nfull > 0): the first block column (its panel launch has no product to
-//     form a tile behind), the diagonal tiles (the eager updates read-modify-write them; the data variance lands
-//     on them), the row tiles from nfull on (residual rows, the rows 1 and d, identity padding) -- 45 of cfg3's
-//     136 lower tiles, each entry of the others evaluated ONCE, by the kernel that touches it first;
-//   * otherwise every lower tile, still without sums.
-// Same long-lived workgroups as assemble_sums_kernel (table and the star's phases in LDS once, entries in batches
-// of 16, no memory load in the tile loop); every workgroup derives m, z, alpha, beta, c1 from the table and wbar
-// itself (304 multiply-adds; the same bits in every workgroup of a star: same code, same order) -- no launch of
-// its own for five numbers -- and the star's first workgroup leaves the coefficients, the reduction's scalars,
-// the packed table (for the kernels that form tiles) and the cleared flags in memory.
-#ifndef SP_PLAN_OCC
-#define SP_PLAN_OCC 2
-#endif
-template <int TK>
-__global__ __launch_bounds__(256, SP_PLAN_OCC) void assemble_planned_kernel(
-    int K, int M, int Kp, PlanDev plan, const double *__restrict__ t, const sp_star *__restrict__ stars, int covpts,
-    const double *__restrict__ tab, const double *__restrict__ meanvar, const double *__restrict__ flux,
-    const double *__restrict__ diag, double *__restrict__ out, long ldo, long strideo, int ntr, int nfull, int order,
-    double zmax, Coef *__restrict__ coef, double *__restrict__ rscal, double *__restrict__ ptab,
-    int32_t *__restrict__ info, uint32_t *__restrict__ status, int lds_phases, AsmChunks chunks) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int s = blockIdx.y, np = covpts + 4, tid = threadIdx.x;
-  const sp_star st = stars[s];
-  const int t0 = chunks.start[blockIdx.x], t1 = chunks.start[blockIdx.x + 1];
-  if (t0 >= t1 && blockIdx.x != 0) return;
-  double *s_tab = lds;                       // 4 np
-  double *s_red = s_tab + 4 * np;            // 8
-  double *s_th = s_red + 8;                  // [Kp] the star's phases (zero beyond K)            (lds_phases)
-  double *s_tt = s_th + Kp;                  // [Kp] its times (temporal kernels only)
-  const int nobs = star_nobs(st, K);
-  const double *th = plan.theta + (size_t)s * K, *tt = t + (size_t)s * K;
-  // the star's table: {a0, a1} pairs, then {a2, a3} pairs (SplineGen), and yp . wbar on the way -- every load in
-  // flight before the first store
-  double dot = 0.0;
-  {
-    const double *src = tab + (size_t)st.table * 5 * np, *wb = plan.wbar + (size_t)s * np;
-    double *pt = (blockIdx.x == 0 && ptab) ? ptab + (size_t)s * 4 * np : nullptr;
-    double y[2], w[2], a0[2], a1[2], a2[2], a3[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int e = tid + 256 * c;
-      const bool ok = e < np;
-      y[c] = ok ? src[e] : 0.0;
-      w[c] = ok ? wb[e] : 0.0;
-      a0[c] = ok ? src[np + e] : 0.0;
-      a1[c] = ok ? src[2 * np + e] : 0.0;
-      a2[c] = ok ? src[3 * np + e] : 0.0;
-      a3[c] = ok ? src[4 * np + e] : 0.0;
-    }
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int e = tid + 256 * c;
-      if (e < np) {
-        *reinterpret_cast<dd2 *>(s_tab + 2 * e) = dd2{a0[c], a1[c]};
-        *reinterpret_cast<dd2 *>(s_tab + 2 * np + 2 * e) = dd2{a2[c], a3[c]};
-        if (pt) {
-          *reinterpret_cast<dd2 *>(pt + 2 * e) = dd2{a0[c], a1[c]};
-          *reinterpret_cast<dd2 *>(pt + 2 * np + 2 * e) = dd2{a2[c], a3[c]};
-        }
-        dot += y[c] * w[c];
-      }
-    }
-    for (int e = tid + 512; e < np; e += 256) {    // (covpts > 508: calibrate's covpts = K - 1)
-      const dd2 c01 = dd2{src[np + e], src[2 * np + e]}, c23 = dd2{src[3 * np + e], src[4 * np + e]};
-      *reinterpret_cast<dd2 *>(s_tab + 2 * e) = c01;
-      *reinterpret_cast<dd2 *>(s_tab + 2 * np + 2 * e) = c23;
-      if (pt) {
-        *reinterpret_cast<dd2 *>(pt + 2 * e) = c01;
-        *reinterpret_cast<dd2 *>(pt + 2 * np + 2 * e) = c23;
-      }
-      dot += src[e] * wb[e];
-    }
-  }
-  const int cl = tid & 15, ri = tid >> 4;
-  // the star's phases (and times) to LDS once, as in assemble_sums_kernel; a light curve too long for that keeps
-  // them in memory (lds_phases == 0)
-  int unsorted = 0;
-  if (lds_phases || TK == SP_TEMPORAL_MATERN32) {
-    double a[4], b[4], bp[4];
-    for (int base = 0; base < Kp; base += 1024) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int i = base + tid + 256 * c;
-        a[c] = (lds_phases && i < K) ? th[i] : 0.0;
-        b[c] = (TK != SP_TEMPORAL_NONE && i < K) ? tt[i] : 0.0;
-        bp[c] = (TK == SP_TEMPORAL_MATERN32 && i > 0 && i < nobs) ? tt[i - 1] : -INFINITY;
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int i = base + tid + 256 * c;
-        if (lds_phases && i < Kp) {
-          s_th[i] = a[c];
-          if (TK != SP_TEMPORAL_NONE) s_tt[i] = b[c];
-        }
-        if (TK == SP_TEMPORAL_MATERN32 && i < nobs && !(b[c] >= bp[c])) unsorted = 1;
-      }
-    }
-  }
-  // m = yp . wbar / K^2 over the workgroup: wavefront sums, then the four of them in order
-  for (int off = 32; off > 0; off >>= 1) dot += __shfl_down(dot, off, 64);
-  if ((tid & 63) == 0) s_red[tid >> 6] = dot;
-  const bool in_order = TK == SP_TEMPORAL_MATERN32 ? !__syncthreads_or(unsorted) : (__syncthreads(), false);
-  const double total = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-  const double var1 = nobs == 1 ? meanvar[2 * st.table + 1] : 0.0;
-  // (a single cadence: the covariance is the variance, flux.py:274-275)
-  const double m = nobs == 1 ? var1 : total / ((double)nobs * (double)nobs);
-  const Coef c = defer_coef(m, meanvar[2 * st.table], order, st.baseline_var);
-  const double inv_c1 = 1.0 / c.c1;
-  if (blockIdx.x == 0) {
-    double *rs = rscal + (size_t)s * (SP_RSCAL_HEAD + M);
-    for (int mm = tid; mm < M; mm += 256)
-      rs[SP_RSCAL_HEAD + mm] = plan.sflux[(size_t)s * M + mm] - (double)nobs * st.baseline_mean;
-    if (tid == 0) {
-      const double delta = st.data_var / c.c1;
-      rs[0] = (double)nobs * m;
-      rs[1] = diag ? plan.sdv[s] / c.c1 : (double)nobs * delta;
-      rs[2] = delta;
-      coef[s] = c;
-      const double *key = plan.key + 3 * (size_t)s;
-      const bool stale = !(key[0] == st.period) || (TK != SP_TEMPORAL_NONE && !(key[1] == st.tau)) || key[2] != (double)nobs;
-      if (info) info[s] = 0;
-      if (status) status[s] = (c.z > zmax ? SP_STAR_ZMAX : 0u) | (stale ? SP_STAR_STALE_PLAN : 0u);
-    }
-  }
-  if (t0 >= t1) return;
-  // strip-major tile order: strip tj holds the tiles ti = tj .. ntr - 1; of those only the WRITTEN ones are visited
-  int tj = 0, ti;
-  {
-    int rem = t0;
-    while (rem >= ntr - tj) {
-      rem -= ntr - tj;
-      ++tj;
-    }
-    ti = tj + rem;
-  }
-  auto phase_of = [&](int i) { return lds_phases ? s_th[i] : (i < K ? th[i] : 0.0); };
-  auto time_of = [&](int i) { return TK == SP_TEMPORAL_NONE ? 0.0 : (lds_phases ? s_tt[i] : (i < K ? tt[i] : 0.0)); };
-  double thj[4], tmj[4], thi[4], tmi[4];
-  const double cm = TK == SP_TEMPORAL_MATERN32 ? 1.7320508075688772 / st.tau : 0.0;
-  double bref = 0.0, fc[4] = {1.0, 1.0, 1.0, 1.0};
-  bool sep_strip = false;
-  auto load_cols = [&](int tjj) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int j = 64 * tjj + cl + 16 * e;
-      thj[e] = phase_of(j);
-      tmj[e] = time_of(j);
-    }
-    // (the separated Matern-3/2 factor of a strip: see assemble_sums_kernel)
-    if (TK == SP_TEMPORAL_MATERN32) {
-      const int j0s = 64 * tjj, j1s = (j0s + 63 < nobs ? j0s + 63 : nobs - 1);
-      bref = time_of(j0s);
-      sep_strip = in_order && j1s >= j0s && cm * (time_of(j1s) - bref) < 600.0 && cm > 0.0;
-      if (sep_strip) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) fc[e] = exp(cm * (tmj[e] - bref));
-      }
-    }
-  };
-  load_cols(tj);
-  SplineGen g{s_tab, 2 * np, 6.283185307179586 / covpts, 1.0 / (6.283185307179586 / covpts), covpts};
-  double *ob = out + (size_t)s * strideo;
-  int tile = t0;
-  while (tile < t1) {
-    const int i0 = 64 * ti, j0 = 64 * tj;
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      const int i = i0 + ri + 16 * pass;
-      thi[pass] = phase_of(i);
-      tmi[pass] = time_of(i);
-    }
-    double v[16];
-    {
-      double a[16], b[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        a[k] = thi[k >> 2];
-        b[k] = thj[k & 3];
-      }
-      g.many<16>(a, b, v);
-    }
-    if (nobs == 1) {
-#pragma unroll
-      for (int k = 0; k < 16; ++k) v[k] = var1;
-    }
-    if (TK == SP_TEMPORAL_MATERN32 && sep_strip && ti > tj && ti < ntr - 1) {
-      double er[4];
-#pragma unroll
-      for (int pass = 0; pass < 4; ++pass) er[pass] = exp(-(cm * (tmi[pass] - bref)));
-#pragma unroll
-      for (int pass = 0; pass < 4; ++pass)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const double x = cm * (tmi[pass] - tmj[e]);
-          v[4 * pass + e] *= (1.0 + x) * (er[pass] * fc[e]);
-        }
-    } else if (TK != SP_TEMPORAL_NONE) {
-#pragma unroll
-      for (int pass = 0; pass < 4; ++pass)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[4 * pass + e] *= temporal_factor(TK, tmi[pass], tmj[e], st.tau);
-    }
-    if (i0 + 64 <= nobs && j0 + 64 <= nobs) {
-      // a tile of valid cadences only: no masks
-      if (ti == tj && ri == cl) {
-        // the diagonal entries of the tile are this thread's (pass, pass): B = Sigma + D / c1
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-          const int i = i0 + ri + 16 * pass;
-          v[5 * pass] += (diag ? diag[(size_t)s * K + i] : st.data_var) * inv_c1;
-        }
-      }
-#pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        double *dst = ob + (size_t)(i0 + ri + 16 * pass) * ldo + j0 + cl;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dst[16 * e] = v[4 * pass + e];
-      }
-    } else {
-#pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        const int i = i0 + ri + 16 * pass;
-        double *dst = ob + (size_t)i * ldo + j0 + cl;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int j = j0 + cl + 16 * e;
-          double val = 0.0;
-          if (i < nobs && j < nobs) {
-            val = v[4 * pass + e];
-            if (i == j) val += (diag ? diag[(size_t)s * K + i] : st.data_var) * inv_c1;
-          } else if (i >= K && i < K + M && j < nobs) {
-            val = flux[((size_t)s * M + (i - K)) * K + j] - st.baseline_mean;   // (the GP mean of the normalised process is 0)
-          } else if (i == K + M && j < nobs) {
-            val = 1.0;                                                         // L^-1 1 rides here
-          } else if (diag && i == K + M + 1 && j < nobs) {
-            val = diag[(size_t)s * K + j] * inv_c1;                             // L^-1 d
-          } else if (i == j) {
-            val = 1.0;
-          }
-          dst[16 * e] = val;
-        }
-      }
-    }
-    // the next written tile of the strip, or the next strip's diagonal tile
-    int nti = ti + 1;
-    if (tj > 0 && nti < nfull) nti = nfull;
-    if (nti >= ntr) {
-      tile += ntr - ti;
-      ++tj;
-      ti = tj;
-      if (tile < t1) load_cols(tj);
-    } else {
-      tile += nti - ti;
-      ti = nti;
-    }
   }
 }
 
@@ -1196,86 +907,6 @@ int sp_launch_assemble_sums(int S, int K, int M, int Kp, const double *theta, co
   else if (temporal == SP_TEMPORAL_EXPSQUARED) SP_ASMS(SP_TEMPORAL_EXPSQUARED);
   else return SP_ERR_INVALID;
 #undef SP_ASMS
-  SP_LAUNCH_CHECK();
-  return SP_OK;
-}
-
-// Chunks of the planned assembly: the WRITTEN tiles of a star (strip-major; written(a, b): a == b, b == 0 or
-// a >= nfull) cut into nchunk runs of equal cost.  start[c] = index of chunk c's first tile in the numbering of ALL
-// lower tiles.  No sums are taken in this kernel: the cut has no influence on any bit of the result.
-static AsmChunks plan_chunks(int ntr, int nfull, int nchunk) {
-  static thread_local int have_ntr = -1, have_nfull = -1, have_nchunk = -1;
-  static thread_local AsmChunks have;
-  if (ntr == have_ntr && nfull == have_nfull && nchunk == have_nchunk) return have;
-  const auto written = [&](int a, int b) { return a == b || b == 0 || a >= nfull; };
-  const auto weight = [&](int a, int b) { return a == ntr - 1 ? 20 : (a == b ? 11 : 10); };
-  long total = 0;
-  for (int b = 0; b < ntr; ++b)
-    for (int a = b; a < ntr; ++a)
-      if (written(a, b)) total += weight(a, b);
-  AsmChunks c;
-  int chunk = 0, tile = 0;
-  long cum = 0;
-  for (int b = 0; b < ntr; ++b)
-    for (int a = b; a < ntr; ++a, ++tile) {
-      if (!written(a, b)) continue;
-      while (chunk <= nchunk && cum >= (long)chunk * total / nchunk) c.start[chunk++] = (unsigned short)tile;
-      cum += weight(a, b);
-    }
-  while (chunk <= nchunk) c.start[chunk++] = (unsigned short)tile;
-  have = c;
-  have_ntr = ntr;
-  have_nfull = nfull;
-  have_nchunk = nchunk;
-  return c;
-}
-
-// LDS of the planned assembly: the star's table, a reduction's scratch, its phases (and times)
-static size_t assemble_planned_lds(int Kp, int covpts, int temporal, int lds_phases) {
-  return sizeof(double) * (4 * (size_t)(covpts + 4) + 8 +
-                           (lds_phases ? (size_t)Kp * (temporal == SP_TEMPORAL_NONE ? 1 : 2) : 0));
-}
-
-int sp_launch_assemble_planned(int S, int K, int M, int Kp, const PlanDev &plan, const double *t,
-                               const sp_star *stars, int covpts, const double *tab, const double *meanvar,
-                               int temporal, const double *flux, const double *diag, double *sys, int nfull,
-                               int order, double zmax, void *coef, double *rscal, double *ptab, int32_t *info,
-                               uint32_t *status, hipStream_t st) {
-  const int ntr = Kp / 64, ntiles = ntr * (ntr + 1) / 2;
-  if (ntiles > 65535 || !coef || !rscal) return SP_ERR_INVALID;
-  int lds_phases = 1;
-  size_t lds = assemble_planned_lds(Kp, covpts, temporal, 1);
-  if (lds > SP_ASM_LDS_MAX) {
-    lds_phases = 0;
-    lds = assemble_planned_lds(Kp, covpts, temporal, 0);
-    if (lds > attr_lds_limit) return SP_ERR_INVALID;
-  }
-  // written tiles per workgroup (SP_PLAN_TILES; the cut changes no bit of the result)
-  static const int per = [] {
-    const char *e = getenv("SP_PLAN_TILES");
-    const int v = e ? atoi(e) : 6;
-    return v < 1 ? 1 : v;
-  }();
-  int nwritten = 0;
-  for (int b = 0; b < ntr; ++b)
-    for (int a = b; a < ntr; ++a) nwritten += (a == b || b == 0 || a >= nfull) ? 1 : 0;
-  int nchunk = (nwritten + per - 1) / per;
-  if (nchunk > SP_ASM_MAX_CHUNKS) nchunk = SP_ASM_MAX_CHUNKS;
-  if (nchunk < 1) nchunk = 1;
-  const AsmChunks chunks = plan_chunks(ntr, nfull, nchunk);
-  dim3 grid(nchunk, S);
-#define SP_ASMP(TK)                                                                                       \
-  do {                                                                                                    \
-    allow_big_lds(assemble_planned_kernel<TK>);                                                           \
-    hipLaunchKernelGGL((assemble_planned_kernel<TK>), grid, dim3(256), lds, st, K, M, Kp, plan, t, stars, \
-                       covpts, tab, meanvar, flux, diag, sys, (long)Kp, (long)Kp * Kp, ntr, nfull, order, \
-                       zmax, (Coef *)coef, rscal, ptab, info, status, lds_phases, chunks);                \
-  } while (0)
-  if (temporal == SP_TEMPORAL_NONE) SP_ASMP(SP_TEMPORAL_NONE);
-  else if (temporal == SP_TEMPORAL_MATERN32) SP_ASMP(SP_TEMPORAL_MATERN32);
-  else if (temporal == SP_TEMPORAL_EXPSQUARED) SP_ASMP(SP_TEMPORAL_EXPSQUARED);
-  else return SP_ERR_INVALID;
-#undef SP_ASMP
   SP_LAUNCH_CHECK();
   return SP_OK;
 }

@@ -261,7 +261,7 @@ static int cholesky_panel2(sp_handle *h, int ngroups, const sp_chol_group *grp, 
           const bool tail = rows > 0 && j + 1 < nsteps && q + 1 < w;
           const bool la = la_on && q >= 1 && j + 2 < ntile && j + 1 < nsteps && q + 1 < w && rows > 0;
           const bool first_la = la_on && q >= 2 && rows > 0;   // (launch j - 1 qualified: q - 1 >= 1, j + 1 < ntile)
-          const int nl = d_alone && rows > 0 ? 2 : 1;
+          const int nl = (d_alone && !G.block0_done && rows > 0) ? 2 : 1;
           if (!d_alone && rows <= 0) {   // the last pivot block with no row tile below it: factored in launch j - 1's tail
             sp_scope.add(fl, 0);
             continue;
@@ -270,7 +270,7 @@ static int cholesky_panel2(sp_handle *h, int ngroups, const sp_chol_group *grp, 
           SpProfScope prof1(h, G.st, SP_PROF_PANEL_LAUNCH, fl, nl);
           sp_scope.add(fl, nl);
           int rc = SP_OK;
-          if (d_alone)
+          if (d_alone && !G.block0_done)
             rc = sp_launch_panel2(h->panel_layout | (tri0 >= 0 ? (2 | (tri0 << 8)) : 0), nullptr, G.sys, ld, stride, G.S, ntile, j, s0, nact_of(j), 0, last, SP_PANEL_D,
                                   h->ncu, G.invL, lts, G.info, G.st, nullptr);
           const int what = rows > 0 ? (SP_PANEL_T | (tail ? SP_PANEL_TAILD : 0) | (la ? SP_PANEL_LA : 0) |

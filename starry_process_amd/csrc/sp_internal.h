@@ -167,6 +167,8 @@ struct LazyCov {
   int K, covpts, temporal;
   int nfull;               // row tiles 0 .. nfull - 1 hold covariance rows only
   int tr0, tc0;            // system tile coordinates of the launch's tile (0, 0)
+  int c0lazy;              // the tiles of block column 0 are left to their first touch too (the planned step: its
+                           // assembly does not write them; panel launch 0 forms them)
 };
 
 // Per-star normalisation coefficients: 8 doubles per star in the workspace (`coef`), written by
@@ -228,6 +230,7 @@ struct sp_chol_group {
   int tri0 = -1;     // >= 0: the rows from this one on are an IDENTITY riding along (sp_spd_inverse_batched): row
                      // tri0 + m is zero left of column m until the factorisation reaches it, so a launch only
                      // takes the row tiles that hold something, and the columns beyond the matrix are never formed
+  bool block0_done = false;   // pivot block 0 is factored already (the planned step's assembly does it, sp_planasm.hip)
 };
 
 // does the factorisation of a (K, Kp) system by this handle end in a panel launch's tail (which can carry the reduction)?

@@ -196,7 +196,7 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
   // (tiles evaluated at first touch: the first operand slices are requested after the evaluation --
   //  48 registers of loads in flight across it made the compiler spill the spline's constants and
   //  reload them for every entry)
-  const bool any_lazy = LAZY && may_lazy && a.lz.theta && cb > 0 && i0 < a.lz.nfull;
+  const bool any_lazy = LAZY && may_lazy && a.lz.theta && (cb > 0 || a.lz.c0lazy) && i0 < a.lz.nfull;
   auto first_loads = [&]() {
 #pragma unroll
     for (int h = 0; h < NR; ++h) stage_load_fast<PK>(Ab, ld, 64 * h, 0, ra[h], tid);
@@ -207,7 +207,7 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
   for (int h = 0; h < NR; ++h) {
     // (first super-panel of a system whose assembly left the tile to its first touch, sp_cov.h:
     //  evaluated while the first operand slices are on their way)
-    const bool lazy = LAZY && may_lazy && a.lz.theta && cb > 0 && i0 + h < a.lz.nfull;
+    const bool lazy = LAZY && may_lazy && a.lz.theta && (cb > 0 || a.lz.c0lazy) && i0 + h < a.lz.nfull;
     if (!lazy) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
