@@ -333,7 +333,8 @@ int sp_spd_inverse_batched(sp_handle *h, int S, int K, const double *C_dev, long
                            void *stream);
 
 /* ---- the ensemble gradient's device half (round 4; tests/test_lnlike.py:100-136 for a whole batch) ------------
- * Marginal branch, one light curve per star (M = 1), every cadence valid (sp_star.nobs = 0).  For every star:
+ * Marginal branch, one light curve per star (M = 1), every cadence valid (sp_star.nobs = 0 or K: a ragged star gets
+ * NaN and SP_STAR_NAN, never a silently wrong value).  For every star:
  *   lnlike_dev [S]            the log-likelihood (sp.py:1129-1188; -inf as sp_lnlike_ensemble)
  *   ybar_dev [S, covpts + 4]  d lnL_s / d yp, yp = the star's kernel table (tab_dev[table_s][0, :], the second
  *                             moment on the lag grid minus mean^2, flux.py:310-320), everything else held fixed
@@ -342,7 +343,8 @@ int sp_spd_inverse_batched(sp_handle *h, int S, int K, const double *C_dev, long
  * pulled back through the normalisation (sp.py:705-727) and the cubic interpolation (flux.py:256-276; the spline
  * is linear in yp).  The caller chains (ybar, meanbar) to the hyperparameters: d lnL / d theta = sum_s ybar_s .
  * d yp / d theta + meanbar_s d mean / d theta (starry_process_amd/grad.py: ensemble_gradient).
- * workspace_dev: sp_lnlike_grad_workspace_bytes(h, S, K, covpts) bytes.                                      */
+ * workspace_dev: sp_lnlike_grad_workspace_bytes(h, S, K, covpts) bytes -- about S (2 K)^2 doubles for the system that
+ * carries the identity plus S K^2 for the inverse: 1.9 GB at cfg3's shape (64 x 1000), 8.5 GB at cfg5's (32 x 3000).  */
 size_t sp_lnlike_grad_workspace_bytes(sp_handle *h, int S, int K, int covpts);
 int sp_lnlike_grad_marginal(sp_handle *h, int S, int K, const double *t_dev, const double *flux_dev,
                             const double *diag_dev, const sp_star *stars_dev, int covpts, const double *tab_dev,

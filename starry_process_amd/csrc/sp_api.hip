@@ -241,7 +241,9 @@ struct Layout {
 // sp_reduce.h -- rounds 2-4: p, q, 1)
 #define SP_DEFER_ROWS 2
 
-Layout make_layout(const sp_handle *h, int S, int K, int M, bool with_sys) {
+// lean: no design-matrix buffers and no raw covariance (the SPD inverse and the gradient's sweep touch neither: at cfg3's
+// shape they were 1.5 GB of the 3.5 GB those calls asked for -- ADVICE r04)
+Layout make_layout(const sp_handle *h, int S, int K, int M, bool with_sys, bool lean = false) {
   Layout L;
   L.S = S;
   L.K = K;
@@ -271,9 +273,9 @@ Layout make_layout(const sp_handle *h, int S, int K, int M, bool with_sys) {
   L.vrow = take(d * S * L.N);
   L.Rinc = take(d * S * L.NWIG);
   L.invL = take(d * (size_t)S * sp_lt_stride(L.Kp));
-  L.A = take(d * (size_t)S * L.Kr * L.N);
-  L.B1 = take(d * (size_t)S * L.Kr * L.N);
-  L.raw = take(d * (size_t)S * K * K);
+  L.A = take(lean ? 0 : d * (size_t)S * L.Kr * L.N);
+  L.B1 = take(lean ? 0 : d * (size_t)S * L.Kr * L.N);
+  L.raw = take(lean ? 0 : d * (size_t)S * K * K);
   L.part = with_sys ? take(d * (size_t)S * (L.Kp / SP_NB) * K) : off;
   L.sys = with_sys ? take(d * (size_t)S * L.Kp * L.Kp) : off;
   L.total = off;
@@ -1338,7 +1340,7 @@ int sp_allgather_lnlike(sp_handle *h, void *nccl_comm, const double *local_dev, 
 
 size_t sp_spd_inverse_workspace_bytes(sp_handle *h, int S, int K) {
   if (!h || S < 0 || K < 1) return 0;
-  return make_layout(h, S, K, sp_roundup(K, SP_NB), true).total;
+  return make_layout(h, S, K, sp_roundup(K, SP_NB), true, true).total;
 }
 
 // C^-1 and log det C of S symmetric positive definite K x K matrices with the factorisation's own machinery:
@@ -1384,7 +1386,7 @@ int sp_spd_inverse_batched(sp_handle *h, int S, int K, const double *C_dev, long
   if (S == 0) return SP_OK;
   hipStream_t st = (hipStream_t)stream;
   const int Kr = sp_roundup(K, SP_NB);
-  Layout L = make_layout(h, S, K, Kr, true);
+  Layout L = make_layout(h, S, K, Kr, true, true);
   void *ws = workspace_dev;
   // the matrices into the systems' corners (nothing else of the systems is touched here)
   hipLaunchKernelGGL(corner_copy_kernel, dim3((K + 255) / 256, K, S), dim3(256), 0, st, C_dev, ldc, strideC,
@@ -1412,7 +1414,7 @@ GradLayout grad_layout(sp_handle *h, int S, int K, int covpts) {
     return o;
   };
   const size_t d = sizeof(double);
-  G.inv = take(make_layout(h, S, K, Kr, true).total);
+  G.inv = take(make_layout(h, S, K, Kr, true, true).total);
   G.cinv = take(d * (size_t)S * Kr * Kr);
   G.vec = take(d * (size_t)S * 4 * K);
   G.hcoef = take(d * S);
@@ -1448,7 +1450,7 @@ int sp_lnlike_grad_marginal(sp_handle *h, int S, int K, const double *t_dev, con
   const GradLayout G = grad_layout(h, S, K, covpts);
   char *base = static_cast<char *>(workspace_dev);
   void *ws = base + G.inv;
-  Layout L = make_layout(h, S, K, Kr, true);
+  Layout L = make_layout(h, S, K, Kr, true, true);
   double *theta = at<double>(ws, L.theta), *rowsum = at<double>(ws, L.rowsum), *qv = at<double>(ws, L.qv);
   double *coef = at<double>(ws, L.coef), *sys = at<double>(ws, L.sys);
   int32_t *info = at<int32_t>(ws, L.info);

@@ -112,7 +112,10 @@ __global__ __launch_bounds__(256) void grad_scalars_kernel(
 #pragma unroll
   for (int k = 0; k < 10; ++k) d[k] = (red[k][0] + red[k][1]) + (red[k][2] + red[k][3]);
   const double Kd = (double)K;
-  const bool bad = (info && info[s] != 0) || (normalized && c.z > zmax);
+  // (the sweep takes every cadence as valid: a ragged star -- 0 < nobs < K -- would get a silently wrong value from
+  //  the K-long products above; it gets NaN and SP_STAR_NAN instead)
+  const bool ragged = st.nobs > 0 && st.nobs < K;
+  const bool bad = (info && info[s] != 0) || (normalized && c.z > zmax) || ragged;
   double c1 = 1.0, wconst = 0.0, gscale_u = 0.0, gscale_v = 0.0, mbar = d[3];
   if (normalized) {
     const double z = c.z, mu = c.mu, m = c.m;
@@ -151,11 +154,11 @@ __global__ __launch_bounds__(256) void grad_scalars_kernel(
   if (tid == 0) {
     const double ll = -0.5 * d[0] - 0.5 * logdet[s] - 0.5 * Kd * 1.8378770664093453;   // log(2 pi)
     const bool dead = bad || !(ll == ll);
-    lnlike[s] = dead ? -INFINITY : ll;
+    lnlike[s] = ragged ? __builtin_nan("") : (dead ? -INFINITY : ll);
     meanbar[s] = dead ? 0.0 : mbar;
     hcoef[s] = dead ? 0.0 : c1;           // (0: the scatter adds nothing for a star the likelihood rejects)
     if (status) status[s] = ((info && info[s]) ? SP_STAR_NOT_PD : 0u) | ((normalized && c.z > zmax) ? SP_STAR_ZMAX : 0u) |
-                            ((!(ll == ll) && !bad) ? SP_STAR_NAN : 0u);
+                            (((!(ll == ll) && !bad) || ragged) ? SP_STAR_NAN : 0u);
   }
 }
 

@@ -448,6 +448,25 @@ class EnsembleGradient(object):
                 dm["c"] = meanA / c
                 dy["n"] = (f_S + 2.0 * f_mm) / n - 2.0 * meanA[:, None] ** 2 / n
                 dm["n"] = meanA / n
+            else:
+                # On the boundary c = 0 or n = 0 the tables at the point hold nothing to divide by: take them at unit
+                # contrast and unit number of spots instead (f is a polynomial in c and n: f = c^2 n f_S' + c^2 n^2 f_mm'
+                # + f_eps, mean = c n m1), one more upstream evaluation -- what hyper_gradient returns there too.
+                from .upstream_device import ylm_moments_device
+
+                mu1, Sig1 = ylm_moments_device(eu, **dict(hp0, c=1.0, n=1.0), **self._ukw)
+                eu.set_moments_dev(mu1, torch.zeros_like(Sig1))
+                t1, mv1 = eu.kernel_table(self._rta1, self._covpts)
+                m1 = mv1[:, 0]
+                f_mm1 = t1[:, 0, :] + m1[:, None] ** 2
+                eu.set_moments_dev(zero_mu, Sig1 - torch.diag(eps))
+                tS, _ = eu.kernel_table(self._rta1, self._covpts)
+                f_S1 = tS[:, 0, :]
+                cc, nn = float(c), float(n)
+                dy["c"] = 2.0 * cc * nn * f_S1 + 2.0 * cc * nn * nn * f_mm1 - 2.0 * cc * nn * nn * m1[:, None] ** 2
+                dm["c"] = nn * m1
+                dy["n"] = cc * cc * f_S1 + 2.0 * cc * cc * nn * f_mm1 - 2.0 * cc * cc * nn * m1[:, None] ** 2
+                dm["n"] = cc * m1
             events.append(torch.cuda.Event())
             events[-1].record(s3)
         with torch.cuda.stream(self._stream):
@@ -468,9 +487,6 @@ class EnsembleGradient(object):
         self.status = host[ng + self.S:].astype(np.uint32)
         total = float(self.lnlike.sum())
         grad = {k: float(v) for k, v in zip(names, host[:ng])}
-        if c == 0 or n == 0:
-            grad.setdefault("c", float("nan"))
-            grad.setdefault("n", float("nan"))
         return total, grad
 
 

@@ -266,6 +266,38 @@ def test_ensemble_gradient_against_finite_differences_of_the_oracle():
         assert abs(g[name] - fd) < 2e-5 * max(abs(fd), 1.0), (name, g[name], fd)
 
 
+@pytest.mark.parametrize("S,K,tau,tspan", [(2, 1000, None, 4.0), (1, 3000, 3.0, 30.0)])
+def test_ensemble_gradient_at_full_size_against_finite_differences_of_the_oracle(S, K, tau, tspan):
+    """The same at bench.py's sizes: K = 1000 -- two super-panels, a trailing update and a second
+    super-panel inside sp_spd_inverse_batched, which K = 100 (one pivot block) never reaches -- and K = 3000 with a
+    Matern-3/2 kernel (47 pivot blocks, trailing updates on 128 x 64 tiles).  Central differences of the ORACLE's summed
+    log-likelihood on the oracle's own upstream, one Richardson step, for every parameter of r, a, b, c, n."""
+    from starry_process_amd.grad import EnsembleGradient
+
+    sts = [synthetic_star(11 + s, K, tspan) for s in range(S)]
+    t, flux, p = np.array([s["t"] for s in sts]), np.array([s["flux"] for s in sts]), np.array([s["p"] for s in sts])
+    hp = dict(r=20.0, a=0.40, b=0.27, c=0.10, n=10.0)
+    eg = EnsembleGradient(t, flux, ferr=1e-3, p=p, tau=tau)
+    total, g = eg(**hp)
+
+    def f_of(name):
+        def f(d):
+            q = dict(hp)
+            q[name] = hp[name] + d
+            mu, Sig = _oracle_moments(q["r"], q["a"], q["b"], q["c"], q["n"])
+            return sum(_oracle_lnlike(mu, Sig, t[s], flux[s], 1e-6, p=float(p[s]), tau=tau) for s in range(S))
+        return f
+
+    ref0 = f_of("r")(0.0)
+    assert abs(total - ref0) < 1e-8 * abs(ref0)
+    # (steps: the oracle's value carries ~1e-10 relative of rounding at these sizes (cond C ~ 1e6), the differences
+    #  divide it by h -- ten times the steps of the K = 100 test keep that under the tolerance, and the Richardson step
+    #  keeps the truncation there too)
+    for name, h in (("r", 1e-2), ("a", 1e-3), ("b", 1e-3), ("c", 1e-4), ("n", 1e-2)):
+        fd = _central(f_of(name), h)
+        assert abs(g[name] - fd) < 2e-5 * max(abs(fd), 1.0), (name, g[name], fd)
+
+
 def test_ensemble_gradient_cfg3_shape_and_options():
     """cfg3's shape (64 stars, K = 1000): values equal sp_lnlike_ensemble's to 1e-9, the gradient is finite; per-
     cadence variances, a baseline variance, two limb-darkening tables and a temporal kernel take the same path."""
@@ -334,3 +366,44 @@ def test_ensemble_gradient_spread_of_radii_and_rejected_stars():
     total, g = eg(r=20.0, a=0.4, b=0.27, c=0.9, n=20.0)
     assert total == -np.inf and np.all(eg.lnlike == -np.inf) and np.all(eg.status & 2)
     assert all(v == 0.0 for v in g.values())
+
+
+def test_ensemble_gradient_on_the_boundary_of_the_contrast_box():
+    """c = 0 or n = 0: the analytic limits, as hyper_gradient returns them -- not NaN."""
+    from starry_process_amd.grad import EnsembleGradient, hyper_gradient
+
+    S, K = 2, 90
+    t, flux, p, _ = _ensemble(S, K, seed0=5)
+    eg = EnsembleGradient(t, flux, ferr=1e-3, p=p)
+    for cn in (dict(c=0.0, n=10.0), dict(c=0.1, n=0.0)):
+        hp = dict(r=20.0, a=0.4, b=0.27, **cn)
+        total, g = eg(**hp)
+        ref = {k: 0.0 for k in hp}
+        for s in range(S):
+            _, g1 = hyper_gradient(t[s], flux[s], 1e-6, p=float(p[s]), **hp)
+            for k in hp:
+                ref[k] += g1[k]
+        assert all(np.isfinite(g[k]) for k in hp), (cn, g)
+        scale = max(abs(v) for v in ref.values())
+        for k in ("c", "n"):
+            assert abs(g[k] - ref[k]) < 2e-6 * max(abs(ref[k]), 1e-3 * scale), (cn, k, g[k], ref[k])
+
+
+def test_gradient_sweep_refuses_ragged_stars_loudly():
+    """sp_lnlike_grad_marginal takes every cadence as valid: a star with 0 < nobs < K gets NaN and SP_STAR_NAN, its
+    neighbours their values (it used to return a silently wrong number)."""
+    from starry_process_amd.engine import get_engine, make_stars
+
+    S, K = 3, 100
+    t, flux, p, _ = _ensemble(S, K, seed0=9)
+    e = get_engine(15, 2)
+    mu, Sig = _moments()
+    e.set_moments(mu, Sig)
+    tab, mv = e.kernel_table(e.f64(e.rTA1L([0.0, 0.0])), 300)
+    good = e.lnlike_grad_marginal(e.f64(t), e.f64(flux), e.stars_to_device(make_stars(S, period=p, data_var=1e-6)),
+                                  tab, mv)
+    bad = e.lnlike_grad_marginal(e.f64(t), e.f64(flux),
+                                 e.stars_to_device(make_stars(S, period=p, data_var=1e-6, nobs=[0, K - 1, K])), tab, mv)
+    lg, lb = good[0].cpu().numpy(), bad[0].cpu().numpy()
+    assert np.isnan(lb[1]) and (bad[3].cpu().numpy()[1] & 4)
+    assert lb[0] == lg[0] and lb[2] == lg[2] and not good[3].cpu().numpy().any()

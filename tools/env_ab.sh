@@ -1,5 +1,7 @@
 #!/bin/bash
 # A/B of environment settings on one box: bash tools/env_ab.sh "VAR=a VAR=b ..." [rounds]; "-" = nothing set
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd "$ROOT" || exit 1
 SETTINGS=${1:-"-"}; ROUNDS=${2:-2}
 for r in $(seq $ROUNDS); do
 for S in $SETTINGS; do

@@ -1,5 +1,7 @@
 #!/bin/bash
 # like env_ab.sh, four steps in flight only, longer runs: bash tools/env_ab_inflight.sh "VAR=a VAR=b" [rounds] [steps]
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd "$ROOT" || exit 1
 SETTINGS=${1:-"-"}; ROUNDS=${2:-3}; STEPS=${3:-240}
 for r in $(seq $ROUNDS); do
 for S in $SETTINGS; do

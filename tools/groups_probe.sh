@@ -1,5 +1,7 @@
 #!/bin/bash
 # star groups on concurrent streams inside one call (SP_GROUPS) x steps in flight: the bench line's value and ms/step
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd "$ROOT" || exit 1
 mkdir -p gpurun_out
 for G in 1 2 4; do
   for F in 1 4; do

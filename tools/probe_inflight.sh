@@ -1,6 +1,8 @@
 #!/bin/bash
 # What each kind of launch costs with four steps in flight: the step without it (library built with -DSP_PROBE;
 # results are garbage, only the timing means anything):  bash tools/probe_inflight.sh
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd "$ROOT" || exit 1
 export SP_LIB_VARIANT=probe
 for F in 4 1; do
   echo "== F=$F"

@@ -1,5 +1,7 @@
 #!/bin/bash
 # A/B of library variants (tools/ab_build.sh; "-" = the default build) on one box: bash tools/variant_ab.sh "- a b" [rounds]
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd "$ROOT" || exit 1
 VARIANTS=${1:-"-"}; ROUNDS=${2:-2}
 for r in $(seq $ROUNDS); do
 for V in $VARIANTS; do
