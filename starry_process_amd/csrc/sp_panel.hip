@@ -92,7 +92,10 @@ namespace {
 
 constexpr int PK = 32;                 // depth of an operand slice in LDS
 constexpr int PLDW = PK + 1;
-constexpr int XLD = 66;                // LDS row of the solved tile (eager update): 16-byte aligned rows
+constexpr int XLD = 66;                // LDS row of the solved tile (eager update): 16-byte aligned rows, 33 slots of 16 B
+// where the four columns 16 nb + 4 fk .. + 3 of the solved tile sit in its LDS row: the slot index of a lane's 16-byte
+// read must not depend on fk & 1 modulo 16 (the row length adds one slot per row)
+__device__ __forceinline__ constexpr int sx_col(int nb, int fk) { return 32 * (fk & 1) + 8 * nb + 4 * (fk >> 1); }
 #ifndef P_PAIRS
 #define P_PAIRS 1           // 128-row items where 64-row ones would not fit the CUs in one round
 #endif
@@ -362,9 +365,13 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
     if (i > a.last) break;
     double *sX = smem;
       __syncthreads();               // (the image / the previous half's X has been read by every wavefront)
+    // (columns permuted inside a row, sx_col: the 16-byte fragment reads below are served in the lane groups
+    //  {0-3, 12-15, 20-27}, ... -- fk = 0 for eight of a group's fragment rows, fk = 1 for the other eight -- and with
+    //  the columns in their natural order the two halves of a group overlapped on two of its sixteen 16-byte slots:
+    //  a 2-way conflict on every read, tools/lds_bank_model.py)
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
-      double *dst = sX + (16 * wave + fr) * XLD + 16 * nb + 4 * fk;
+      double *dst = sX + (16 * wave + fr) * XLD + sx_col(nb, fk);
       *reinterpret_cast<d2v *>(dst) = d2v{y[h][nb][0], y[h][nb][1]};
       *reinterpret_cast<d2v *>(dst + 2) = d2v{y[h][nb][2], y[h][nb][3]};
     }
@@ -385,7 +392,7 @@ __device__ __forceinline__ void panel_tile_item(const PanelArgs &a, double *M, i
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         if (m > wave) continue;      // (10 of the tile's 16 blocks)
-        const double *f = sX + (16 * m + fr) * XLD + 16 * nb + 4 * fk;
+        const double *f = sX + (16 * m + fr) * XLD + sx_col(nb, fk);
         const d2v lo = *reinterpret_cast<const d2v *>(f);
         const d2v hi = *reinterpret_cast<const d2v *>(f + 2);
         dac[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(-y[h][nb][0], lo.x, dac[m], 0, 0, 0);

@@ -179,6 +179,22 @@ def test_device_moments_over_the_prior_box():
                 assert np.array_equal(S, S.T) and np.linalg.eigvalsh(S).min() > 0
 
 
+@pytest.mark.parametrize("k", range(5))
+def test_device_moments_against_extended_precision_at_the_corners_of_the_box(k):
+    """at the corners of the prior box and at b = 0.9 the DEVICE moments are right to rounding in
+    every degree (1e-12 of max |Sigma_y|, as at the three interior points of test_ydeg15_matches_extended_precision)
+    and closer to the extended-precision arbiter than the reference's own moments are -- the distance between the two
+    log-likelihoods over the box (LNLIKE_BOX_TOL) is the reference's error, not the device's."""
+    from test_upstream_grid import extended_box_errors
+
+    x = golden("upstream_extended_box")
+    mu, S = _moments(15, (20.0, np.nan, float(x["a"][k]), float(x["b"][k]), 0.1, 10.0))
+    ab, emu, own, ref = extended_box_errors(mu, S, k)
+    assert emu[0] < 1e-12 and emu[0] <= max(emu[1], 1e-12), (ab, emu)
+    assert np.all(own < 1e-12), (ab, own)
+    assert np.all(own <= np.maximum(ref, 1e-12)), (ab, own, ref)
+
+
 @pytest.mark.parametrize("branch", [0, 1])
 def test_likelihood_over_the_prior_box(branch):
     """log_likelihood(upstream="device") against the reference's own value at the 18 grid points and on

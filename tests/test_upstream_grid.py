@@ -88,6 +88,63 @@ def test_quadrature_method_matches_reference_over_the_grid():
             assert e4 < 1e-7 * scale and e8 < 1e-5 * scale and elow < 5e-2 * scale, (a, b)
 
 
+def extended_box_errors(mu, S, k):
+    """Per degree l = 0 .. 15, against the extended-precision arbiter at corner k of the prior box
+    (tests/golden/upstream_extended_box.npz, tools/upstream_extended.py box: 80-bit arithmetic, 50-digit nodes):
+    (error of (mu, S), error of the REFERENCE's own moments at that point), each max |.| over the degree's rows
+    relative to max |Sigma_y| (mu: to max |mu_y|).  The reference's moments are the grid fixture's: rows l <= 8 in
+    full, the (l >= 9)^2 block in float32 -- its errors there are floored at the storage's 6e-8 of an entry."""
+    g, x = golden("upstream_grid"), golden("upstream_extended_box")
+    a, b = float(x["a"][k]), float(x["b"][k])
+    i, j = list(g["a"]).index(a), int(np.argmin(np.abs(g["b"] - b)))
+    assert abs(float(g["b"][j]) - b) < 1e-12
+    N = 256
+    il = np.tril_indices(N)
+    Se = np.zeros((N, N))
+    Se[il] = x["cov_ylm_lower"][k]
+    Se = Se + np.tril(Se, -1).T
+    scale = np.abs(Se).max()
+    mu_e = x["mean_ylm"][k]
+    emu = (np.abs(mu - mu_e).max() / np.abs(mu_e).max(), np.abs(g["mean_ylm"][i, j] - mu_e).max() / np.abs(mu_e).max())
+    top = g["cov_top"][i, j]
+    il2 = np.tril_indices(N - 81)
+    rows = il2[0] + 81
+    low_ref = np.abs(g["cov_low_f32"][i, j].astype(np.float64) - Se[81:, 81:][il2])
+    low_own = np.abs(S[81:, 81:][il2] - Se[81:, 81:][il2])
+    own, ref = np.zeros(16), np.zeros(16)
+    for l in range(16):
+        blk = slice(l * l, (l + 1) ** 2)
+        own[l] = np.abs(S[blk, :] - Se[blk, :]).max() / scale
+        if l <= 8:
+            ref[l] = np.abs(top[blk, :] - Se[blk, :]).max() / scale
+        else:
+            m = (rows >= l * l) & (rows < (l + 1) ** 2)
+            ref[l] = low_ref[m].max() / scale
+            own[l] = max(own[l], low_own[m].max() / scale)
+    return (a, b), emu, own, ref
+
+
+@pytest.mark.parametrize("k", range(5))
+def test_quadrature_against_extended_precision_at_the_corners_of_the_box(k):
+    """where the device upstream and the reference differ most -- the corners of the latitude prior
+    box and b = 0.9 -- the quadrature of rotations (here its CPU statement) is right to rounding in EVERY degree and
+    closer to the extended-precision value than the reference's algorithm is (whose error reaches 7.6e-3 of
+    max |Sigma_y| at a = 1, b = 0): the 1.6e-5 between the two log-likelihoods over the box is the reference's."""
+    from oracle import sp_oracle as orc
+
+    x = golden("upstream_extended_box")
+    assert np.all(x["rule_convergence"] < 1e-15)
+    s1, _ = upstream.size_moments(20.0, None, 15)
+    alpha, beta = upstream.ab_to_alphabeta(float(x["a"][k]), float(x["b"][k]))
+    mu, S = orc.ylm_moments_quadrature(s1, s1[None, :], alpha, beta, 0.1, 10.0, 15)
+    ab, emu, own, ref = extended_box_errors(mu, S, k)
+    assert emu[0] < 1e-14 and emu[0] <= max(emu[1], 1e-14), (ab, emu)
+    assert np.all(own < 1e-13), (ab, own)
+    assert np.all(own <= np.maximum(ref, 1e-13)), (ab, own, ref)
+    if ab in ((0.0, 0.0), (1.0, 0.0)):
+        assert ref[15] > 1e-3                       # (what the reference's top degree is worth there)
+
+
 def test_assembly_chunks_partition_the_tiles_by_cost():
     """The hot assembly kernel's chunks (csrc/sp_assemble.hip, asm_chunks): every tile in exactly one chunk, in order,
     and no chunk heavier than the mean by more than one tile's weight -- a function of the shape alone (host code)."""

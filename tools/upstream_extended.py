@@ -213,5 +213,37 @@ def main():
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "upstream_extended.npz"), **out)
 
 
+# the corners of the reference's latitude prior box a, b in [0, 1] (latitude.py:176-197: alpha, beta up to exp(10)) and
+# the point of the b scan where round 3 returned NaN -- where the device upstream and the reference differ most
+# (VERDICT r04 item 4); r, c, n as in tests/golden/upstream_grid.npz
+BOX = [(0.0, 0.0), (1.0, 0.0), (0.0, 1.0), (1.0, 1.0), (0.5, 0.9)]
+
+
+def main_box():
+    """python tools/upstream_extended.py box   ->  tests/golden/upstream_extended_box.npz
+    (a, b, mean_ylm [5, N], the lower triangle of cov_ylm [5, N (N + 1) / 2] rounded to double, the change under a
+    threefold rule)"""
+    lib = build_ld()
+    N = 256
+    il = np.tril_indices(N)
+    means, covs, convs = [], [], []
+    for a, b in BOX:
+        hp = dict(r=20.0, a=a, b=b, c=0.1, n=10.0)
+        mean, cov = moments_extended(lib, hp)
+        mean3, cov3 = moments_extended(lib, hp, refine=3)
+        conv = float(np.max(np.abs(cov3 - cov)) / np.max(np.abs(cov)))
+        print("a = %.2f b = %.2f: rule refinement 2x -> 3x changes Sigma by %.1e, mu by %.1e" % (
+            a, b, conv, float(np.max(np.abs(mean3 - mean)) / np.max(np.abs(mean)))))
+        means.append(mean.astype(np.float64))
+        covs.append(cov.astype(np.float64)[il])
+        convs.append(conv)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "upstream_extended_box.npz"),
+                        a=np.array([p[0] for p in BOX]), b=np.array([p[1] for p in BOX]), mean_ylm=np.array(means),
+                        cov_ylm_lower=np.array(covs), rule_convergence=np.array(convs))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "box":
+        main_box()
+    else:
+        main()
