@@ -48,7 +48,7 @@ int sp_launch_defer_finish(int S, int K, int M, int Kp, const sp_star *stars, co
 int sp_launch_assemble_planned(int S, int K, int M, int Kp, const PlanDev &plan, const double *t,
                                const sp_star *stars, int covpts, const double *tab, const double *meanvar,
                                int temporal, const double *flux, const double *diag, double *sys, int nfull,
-                               int order, double zmax, void *coef, double *rscal, double *ptab, int32_t *info,
+                               int ncolw, int order, double zmax, void *coef, double *rscal, double *ptab, int32_t *info,
                                uint32_t *status, hipStream_t st, double *img, long lts, int fuse0);
 int sp_launch_cholesky_systems(sp_handle *h, double *sys, int S, int K, int Kp,
                                int32_t *info, double *invL, hipStream_t st);
@@ -1250,16 +1250,26 @@ int sp_lnlike_ensemble_planned(sp_handle *h, const sp_plan *plan, const double *
   void *ws = workspace_dev;
   // (the stars' packed tables for the kernels that form tiles at first touch: the design-matrix region)
   double *ptab = 4 * (size_t)(covpts + 4) > (size_t)L.Kr * L.N ? nullptr : at<double>(ws, L.A);
-  int lazy_nfull = 0;
-  if (h->lazy_cov && ptab && temporal == SP_TEMPORAL_NONE && K / SP_NB >= 2 &&
-      4 * (covpts + 4) + 64 <= SP_TILE_LDS_MIN)
+  // Tiles formed at first touch.  Without a temporal kernel: everything below the diagonal (the panel launches form
+  // the first super-panel's block columns, the first trailing update the rest).  With one: the trailing update's
+  // tiles only -- an exponential per entry has no place in the panel kernel's register budget, so the assembly writes
+  // the first super-panel's block columns; every entry is still evaluated once.
+  int lazy_nfull = 0, ncolw = 0, no_panels = 0;
+  if (h->lazy_cov && ptab && K / SP_NB >= 2 && 4 * (covpts + 4) + 64 <= SP_TILE_LDS_MIN) {
     lazy_nfull = K / SP_NB;
+    if (temporal != SP_TEMPORAL_NONE) {
+      static const bool tl = !(getenv("SP_PLAN_TEMPORAL_LAZY") && atoi(getenv("SP_PLAN_TEMPORAL_LAZY")) == 0);
+      ncolw = sp_superpanel_width(h, K);
+      no_panels = 1;
+      if (!tl || ncolw * SP_NB >= K) lazy_nfull = ncolw = no_panels = 0;   // (one super-panel: no trailing update)
+    }
+  }
   // (pivot block 0 is factored by the assembly's workgroup of tile (0, 0): no launch of its own; SP_PLAN_FUSE0=0 for
   //  the separate launch)
   static const bool fuse0_env = !(getenv("SP_PLAN_FUSE0") && atoi(getenv("SP_PLAN_FUSE0")) == 0);
   const int fuse0 = (fuse0_env && K >= SP_NB) ? 1 : 0;
   int rc = sp_launch_assemble_planned(S, K, M, L.Kp, plan->dev, t_dev, stars_dev, covpts, tab_dev, meanvar_dev, temporal,
-                                      flux_dev, diag_dev, at<double>(ws, L.sys), lazy_nfull, norm_order, zmax,
+                                      flux_dev, diag_dev, at<double>(ws, L.sys), lazy_nfull, ncolw, norm_order, zmax,
                                       at<double>(ws, L.coef), at<double>(ws, L.rscal), ptab, at<int32_t>(ws, L.info),
                                       at<uint32_t>(ws, L.status), st, at<double>(ws, L.invL), sp_lt_stride(L.Kp), fuse0);
   if (rc) return rc;
@@ -1270,7 +1280,8 @@ int sp_lnlike_ensemble_planned(sp_handle *h, const sp_plan *plan, const double *
                          at<double>(ws, L.rscal), diag_dev ? 1 : 0, K, M, K + M + (diag_dev ? 2 : 1)};
   G.block0_done = fuse0 != 0;
   if (lazy_nfull)
-    G.lazy = LazyCov{plan->dev.theta, t_dev, stars_dev, ptab, K, covpts, temporal, lazy_nfull, 0, 0, 1};
+    G.lazy = LazyCov{plan->dev.theta, t_dev, stars_dev, ptab, K, covpts, temporal, lazy_nfull, 0, 0, no_panels ? 0 : 1,
+                     no_panels};
   if ((rc = sp_launch_cholesky_groups(h, 1, &G, K, L.Kp))) return rc;
   if (!fused_reduce) return lnlike_finish(L, ws, K, M, lnlike_dev, status_dev, st, stars_dev, true, diag_dev != nullptr);
   return SP_OK;

@@ -250,7 +250,7 @@ static int cholesky_panel2(sp_handle *h, int ngroups, const sp_chol_group *grp, 
         const double rows = (double)(ntile - j - 1) * SP_NB;
         for (int g = 0; g < ngroups; ++g) {
           const sp_chol_group &G = grp[g];
-          const LazyCov *lzp = (G.lazy.theta && s0 == 0) ? &G.lazy : nullptr;
+          const LazyCov *lzp = (G.lazy.theta && s0 == 0 && !G.lazy.no_panels) ? &G.lazy : nullptr;
           // algorithmic work as the per-panel drivers have always counted it: left-looking product,
           // triangular solve, eager rank-64 updates, the diagonal block
           const double fl = (double)G.S * (2.0 * rows * 64 * (q * 64.0) + rows * 64 * 64 +
@@ -328,6 +328,8 @@ static int superpanel_of(const sp_handle *h, int K) {
 
 // The last pivot block is partial and its row tile holds the rows below the matrix (nsteps == ntile), and it is
 // factored in the tail of launch nsteps - 2 (it is not the first block of a super-panel).
+int sp_superpanel_width(const sp_handle *h, int K) { return superpanel_of(h, K); }
+
 bool sp_panel_fuses_reduce(const sp_handle *h, int K, int Kp) {
   const int nsteps = (K + SP_NB - 1) / SP_NB, ntile = Kp / SP_NB;
   return h->fuse_reduce && nsteps >= 2 && nsteps == ntile && (nsteps - 1) % superpanel_of(h, K) != 0;

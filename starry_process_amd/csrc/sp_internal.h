@@ -169,6 +169,9 @@ struct LazyCov {
   int tr0, tc0;            // system tile coordinates of the launch's tile (0, 0)
   int c0lazy;              // the tiles of block column 0 are left to their first touch too (the planned step: its
                            // assembly does not write them; panel launch 0 forms them)
+  int no_panels;           // the panel launches form nothing (temporal kernels: an exponential per entry has no place
+                           // in the panel kernel): the first super-panel's block columns come from memory, only the
+                           // first trailing update forms its tiles
 };
 
 // Per-star normalisation coefficients: 8 doubles per star in the workspace (`coef`), written by
@@ -235,6 +238,8 @@ struct sp_chol_group {
 
 // does the factorisation of a (K, Kp) system by this handle end in a panel launch's tail (which can carry the reduction)?
 bool sp_panel_fuses_reduce(const sp_handle *h, int K, int Kp);
+// panels per super-panel of a K-cadence factorisation by this handle (sp_cholesky.hip)
+int sp_superpanel_width(const sp_handle *h, int K);
 
 // host-side constant builders (sp_host.cpp)
 void sp_build_index_tables(int ydeg, int32_t *l_of, int32_t *m_of,

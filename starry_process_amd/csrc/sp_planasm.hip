@@ -37,7 +37,8 @@ template <int TK>
 __global__ __launch_bounds__(256, SP_PLAN_OCC) void assemble_planned_kernel(
     int K, int M, int Kp, PlanDev plan, const double *__restrict__ t, const sp_star *__restrict__ stars, int covpts,
     const double *__restrict__ tab, const double *__restrict__ meanvar, const double *__restrict__ flux,
-    const double *__restrict__ diag, double *__restrict__ out, long ldo, long strideo, int ntr, int nfull, int order,
+    const double *__restrict__ diag, double *__restrict__ out, long ldo, long strideo, int ntr, int nfull, int ncolw,
+    int order,
     double zmax, Coef *__restrict__ coef, double *__restrict__ rscal, double *__restrict__ ptab,
     int32_t *__restrict__ info, uint32_t *__restrict__ status, int lds_phases, double *__restrict__ img, long lts,
     int fuse0, int S, int nchunk, AsmChunks chunks) {
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256, SP_PLAN_OCC) void assemble_planned_kernel(
     }
     // the next written tile of the strip, or the next strip's diagonal tile
     int nti = ti + 1;
-    if (nti < nfull) nti = nfull;
+    if (nti < nfull && tj >= ncolw) nti = nfull;
     if (nti >= ntr) {
       tile += ntr - ti;
       ++tj;
@@ -381,15 +382,15 @@ static void allow_big_lds(F f) {
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)attr_lds_limit);
 }
 
-// Chunks of the planned assembly: the WRITTEN tiles of a star (strip-major; written(a, b): a == b or
-// a >= nfull) cut into nchunk runs of equal cost.  start[c] = index of chunk c's first tile in the numbering of ALL
+// Chunks of the planned assembly: the WRITTEN tiles of a star (strip-major; written(a, b): a == b,
+// a >= nfull or b < ncolw) cut into nchunk runs of equal cost.  start[c] = index of chunk c's first tile in the numbering of ALL
 // lower tiles.  No sums are taken in this kernel: the cut has no influence on any bit of the result.
 // fuse0: chunk 0 is tile (0, 0) alone (its workgroup goes on to factor pivot block 0).
-static AsmChunks plan_chunks(int ntr, int nfull, int nchunk, int fuse0) {
-  static thread_local int have_ntr = -1, have_nfull = -1, have_nchunk = -1, have_fuse0 = -1;
+static AsmChunks plan_chunks(int ntr, int nfull, int ncolw, int nchunk, int fuse0) {
+  static thread_local int have_ntr = -1, have_nfull = -1, have_ncolw = -1, have_nchunk = -1, have_fuse0 = -1;
   static thread_local AsmChunks have;
-  if (ntr == have_ntr && nfull == have_nfull && nchunk == have_nchunk && fuse0 == have_fuse0) return have;
-  const auto written = [&](int a, int b) { return a == b || a >= nfull; };
+  if (ntr == have_ntr && nfull == have_nfull && ncolw == have_ncolw && nchunk == have_nchunk && fuse0 == have_fuse0) return have;
+  const auto written = [&](int a, int b) { return a == b || a >= nfull || b < ncolw; };
   const auto weight = [&](int a, int b) { return a == ntr - 1 ? 20 : (a == b ? 11 : 10); };
   const bool own0 = fuse0 && nchunk >= 2;       // tile (0, 0) in a chunk of its own, the others over nchunk - 1
   const int nc = own0 ? nchunk - 1 : nchunk;
@@ -411,6 +412,7 @@ static AsmChunks plan_chunks(int ntr, int nfull, int nchunk, int fuse0) {
   have = c;
   have_ntr = ntr;
   have_nfull = nfull;
+  have_ncolw = ncolw;
   have_nchunk = nchunk;
   have_fuse0 = fuse0;
   return c;
@@ -426,7 +428,7 @@ static size_t assemble_planned_lds(int Kp, int covpts, int temporal, int lds_pha
 int sp_launch_assemble_planned(int S, int K, int M, int Kp, const PlanDev &plan, const double *t,
                                const sp_star *stars, int covpts, const double *tab, const double *meanvar,
                                int temporal, const double *flux, const double *diag, double *sys, int nfull,
-                               int order, double zmax, void *coef, double *rscal, double *ptab, int32_t *info,
+                               int ncolw, int order, double zmax, void *coef, double *rscal, double *ptab, int32_t *info,
                                uint32_t *status, hipStream_t st, double *img, long lts, int fuse0) {
   const int ntr = Kp / 64, ntiles = ntr * (ntr + 1) / 2;
   if (ntiles > 65535 || !coef || !rscal || (fuse0 && (!img || K < 64))) return SP_ERR_INVALID;
@@ -439,7 +441,7 @@ int sp_launch_assemble_planned(int S, int K, int M, int Kp, const PlanDev &plan,
   }
   int nwritten = 0;
   for (int b = 0; b < ntr; ++b)
-    for (int a = b; a < ntr; ++a) nwritten += (a == b || a >= nfull) ? 1 : 0;
+    for (int a = b; a < ntr; ++a) nwritten += (a == b || a >= nfull || b < ncolw) ? 1 : 0;
   // Written tiles per workgroup: one round of two workgroups per CU where that leaves a workgroup at least four
   // tiles (cfg3: 31 tiles x 64 stars on 512 slots), never more than 24 (cfg5's shape: 1 128 tiles per star, three
   // rounds -- a workgroup's prologue copies the star's phases and times, 48 KB there).  No sums are taken here: the
@@ -454,13 +456,13 @@ int sp_launch_assemble_planned(int S, int K, int M, int Kp, const PlanDev &plan,
   if (nchunk > SP_ASM_MAX_CHUNKS) nchunk = SP_ASM_MAX_CHUNKS;
   if (nchunk < 1) nchunk = 1;
   if (fuse0 && nchunk < 2) nchunk = 2;
-  const AsmChunks chunks = plan_chunks(ntr, nfull, nchunk, fuse0);
+  const AsmChunks chunks = plan_chunks(ntr, nfull, ncolw, nchunk, fuse0);
   dim3 grid((unsigned)(nchunk * S));
 #define SP_ASMP(TK)                                                                                       \
   do {                                                                                                    \
     allow_big_lds(assemble_planned_kernel<TK>);                                                           \
     hipLaunchKernelGGL((assemble_planned_kernel<TK>), grid, dim3(256), lds, st, K, M, Kp, plan, t, stars, \
-                       covpts, tab, meanvar, flux, diag, sys, (long)Kp, (long)Kp * Kp, ntr, nfull, order, \
+                       covpts, tab, meanvar, flux, diag, sys, (long)Kp, (long)Kp * Kp, ntr, nfull, ncolw, order, \
                        zmax, (Coef *)coef, rscal, ptab, info, status, lds_phases, img, lts, fuse0, S, nchunk, chunks); \
   } while (0)
   if (temporal == SP_TEMPORAL_NONE) SP_ASMP(SP_TEMPORAL_NONE);
