@@ -229,12 +229,12 @@ KERNEL_OF_KIND = {
 
 def rocprof_average_us(kernel_prefix):
     """Average duration of a kernel in the committed rocprofv3 kernel-trace summary of THIS round's
-    one-step-at-a-time run (profiles/r04_one_kernel_stats.csv), over all its template instantiations
+    one-step-at-a-time run (profiles/r05_one_kernel_stats.csv), over all its template instantiations
     (the panel kernel is one per kind of launch), or None: printed beside the event average so that the
     two can be compared; it is a file of the repository, not of this run."""
     import csv
 
-    for name in ("r04_one_kernel_stats.csv", "r03_one_kernel_stats.csv"):
+    for name in ("r05_one_kernel_stats.csv", "r04_one_kernel_stats.csv", "r03_one_kernel_stats.csv"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -839,7 +839,7 @@ def main():
         cand = {k: v for k, v in timed_prof.items() if v["launches"] > 0}
         dom = max(cand, key=lambda k: cand[k]["ms"]) if cand else "syrk"
         traffic = traffic_source = None
-        for name in ("r04_step_traffic.json", "r03_step_traffic.json", "r02_step_traffic.json"):
+        for name in ("r05_step_traffic.json", "r04_step_traffic.json", "r03_step_traffic.json", "r02_step_traffic.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 try:

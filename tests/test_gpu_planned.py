@@ -367,3 +367,49 @@ def test_planned_bad_arguments(engines):
     plan200 = e.plan_data(t_d, f_d, s_d, covpts=200)
     assert call(plan200.ptr) == -4                        # the handle's lag grid is covpts = 300
     L.sp_plan_destroy(None)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_planned_random_configurations(seed):
+    """Randomised sweep of the planned call against the ORACLE (one star of each case) and against the unplanned call (all
+    of them): sizes around the 64-column panel boundaries, 1-4 light curves per star, both temporal kernels, limb
+    darkening, scalar / per-cadence variances, baseline mean and variance, irregular cadences, ragged light curves."""
+    from oracle import sp_oracle as orc
+    from starry_process_amd.engine import make_stars
+
+    rng = np.random.RandomState(100 + seed)
+    e = make_engine(15)
+    mom = golden("moments_L15")
+    worst_o = worst_u = 0.0
+    for case in range(10):
+        K = int(rng.choice([2, 3, 17, 63, 64, 65, 100, 127, 128, 129, 200, 257, 320, 400, 640]))
+        M = int(rng.choice([1, 1, 2, 4]))
+        S = 3
+        tau = None if rng.rand() < 0.5 else float(rng.uniform(0.5, 5.0))
+        tk = str(rng.choice(["matern32", "expsquared"]))
+        u = (0.0, 0.0) if rng.rand() < 0.5 else tuple(rng.uniform(0, 0.4, 2))
+        per = rng.uniform(0.3, 3.0, S)
+        t = np.array([np.sort(rng.uniform(0, 6, K)) if rng.rand() < 0.5 else np.linspace(0, 4, K) for _ in range(S)])
+        flux = np.array([[1e-2 * np.sin(2 * np.pi * t[s] / per[s]) * rng.rand() + 1e-3 * rng.randn(K) for _ in range(M)]
+                         for s in range(S)])
+        vec = rng.rand() < 0.5
+        diag = 1e-6 * (1 + rng.rand(S, K)) if vec else None
+        bvar = float(rng.choice([0.0, 1e-6, 1e-3]))
+        bmean = float(rng.choice([0.0, 1e-3]))
+        nobs = [0, 0, 0] if (rng.rand() < 0.6 or K < 4) else [K, int(rng.randint(2, K)), int(rng.randint(2, K))]
+        stars = make_stars(S, period=per, tau=tau or 0.0, data_var=1e-6, baseline_var=bvar, baseline_mean=bmean, nobs=nobs)
+        temporal = tk if tau else None
+        a, sa, _ = run(e, t, flux, stars, True, u=u, temporal=temporal, diag=diag)
+        b, sb, _ = run(e, t, flux, stars, False, u=u, temporal=temporal, diag=diag)
+        assert np.array_equal(sa, sb) and np.array_equal(np.isfinite(a), np.isfinite(b)), (seed, case)
+        fin = np.isfinite(a)
+        scale = np.maximum(np.abs(b[fin]), 1.0)
+        worst_u = max(worst_u, float(np.max(np.abs(a[fin] - b[fin]) / scale)) if fin.any() else 0.0)
+        okw = dict(tau=tau, temporal_kernel=orc.Matern32Kernel if tk == "matern32" else orc.ExpSquaredKernel) if tau else {}
+        o = orc.OracleProcess(mom["default_mean_ylm"], mom["default_cov_ylm"], ydeg=15, **okw)
+        ref = o.log_likelihood(t[0], flux[0, 0] if M == 1 else flux[0], diag[0] if vec else 1e-6, p=float(per[0]), u=u,
+                               baseline_mean=bmean, baseline_var=bvar)
+        assert np.isfinite(ref) == np.isfinite(a[0]), (seed, case, ref, a[0])
+        if np.isfinite(ref):
+            worst_o = max(worst_o, abs(a[0] - ref) / max(1.0, abs(ref)))
+    assert worst_u < 1e-9 and worst_o < 1e-8, (worst_u, worst_o)

@@ -14,7 +14,7 @@ prev_end = t0
 tot = 0.0
 for r in rows[a:b]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[:28]
+    name = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:28]
     print("%-28s grid %8s  start %8.1f  dur %6.1f  gap %5.1f" % (
         name, int(r["Grid_Size_X"]) // 256, (s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3))
     prev_end = e
