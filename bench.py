@@ -805,6 +805,14 @@ def main():
                 extras["cfg5_shape_unplanned"] = bench_shape(torch, dist, ydeg=20, Kc=3000, S=32, tspan=30.0, tau=3.0,
                                                              u=(0.4, 0.2), conditional=False, F=F, steps=12,
                                                              device=local_rank)
+            # BASELINE configs[1]: ONE light curve (the reference's own use: sp.log_likelihood inside a sampler), the
+            # latency of an evaluation and what four of them in flight give
+            extras["cfg2_single_star"] = bench_shape(torch, dist, ydeg=15, Kc=1000, S=1, tspan=4.0, tau=None, u=(0.0, 0.0),
+                                                     conditional=False, F=F, steps=200, device=local_rank,
+                                                     planned=plan is not None)
+            extras["cfg2_single_star_one_at_a_time"] = bench_shape(torch, dist, ydeg=15, Kc=1000, S=1, tspan=4.0, tau=None,
+                                                                   u=(0.0, 0.0), conditional=False, F=1, steps=100,
+                                                                   device=local_rank, planned=plan is not None)
             extras["cfg3_conditional"] = bench_shape(torch, dist, ydeg=15, Kc=1000, S=64, tspan=4.0, tau=None,
                                                      u=(0.0, 0.0), conditional=True, F=F, steps=24,
                                                      device=local_rank)
