@@ -1,0 +1,19 @@
+#!/bin/bash
+# kernel-time breakdown of cfg5's shape (planned), F steps in flight: bash tools/cfg5_kstats.sh [F] [steps]   (GPU box)
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT" || exit 1
+F=${1:-4}; N=${2:-16}
+O=gpurun_out/cfg5_ks_$F; rm -rf $O
+cat > /tmp/cfg5_run.py <<PY
+import json, os, sys
+sys.path.insert(0, "$ROOT")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import torch, torch.distributed as dist
+import bench
+r = bench.bench_shape(torch, dist, ydeg=20, Kc=3000, S=32, tspan=30.0, tau=3.0, u=(0.4, 0.2), conditional=False, F=$F, steps=$N, device=0, planned=True)
+print(json.dumps({k: r[k] for k in ("evals_per_s", "ms_per_step", "whole_step_frac")}))
+PY
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 /tmp/cfg5_run.py > $O.log 2>&1
+tail -1 $O.log
+python3 tools/kstats.py $O $((N + 6))
+rm -f $O/*/*kernel_trace.csv
