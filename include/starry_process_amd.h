@@ -496,6 +496,11 @@ int sp_debug_panel2_chain(long long *out);
  * 128 x 64 tiles (csrc/sp_gemm.hip, syrk128_kernel; default 17, environment SP_SYRK128_FROM; 0 = never, -1 = back to
  * the default): which kernel multiplies, never what is computed -- the results are bit-identical.        */
 int sp_debug_set_syrk128_from(int blocks);
+/* (debug, process-wide) the diagonal tiles of the symmetric trailing update on their ten lower 16 x 16 blocks, re-dealt
+ * over the workgroup's four wavefronts three / three / two / two (csrc/sp_mm.h, SymDeal; default on, environment
+ * SP_SYRK_SYMDIAG; 0 = the plain loop, all sixteen blocks; -1 = back to the default): which blocks are multiplied,
+ * never what the wanted ones hold -- identical bits below the diagonal.                                       */
+int sp_debug_set_syrk_symdiag(int on);
 /* (debug, host only) how the hot assembly kernel (csrc/sp_assemble.hip, assemble_sums_kernel) cuts a star's
  * ntr (ntr + 1) / 2 lower tiles (column-strip order) into nchunk chunks of equal COST: start_host[c] = first tile
  * of chunk c, c = 0 .. nchunk (start_host[nchunk] = the number of tiles).  A function of the shape alone.   */

@@ -21,6 +21,8 @@
 // (sp_xcd_decode, sp_tile.h).
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "sp_internal.h"
 #include "sp_tile.h"
 #include "sp_cov.h"
@@ -178,6 +180,45 @@ __global__ __launch_bounds__(256, SP_MM_WAVES) void mm_nt_kernel(
   double *Cb = C + (size_t)mtx * strideC + (size_t)ti * TM * ldc + (size_t)tj * TN;
   Core mm;
   mm.init(Ab, lda, Bb, ldb);
+  // A diagonal tile of a SYMMETRIC update (skip00 bit 2: B = A, sp_launch_syrk_diag): only its ten blocks on and
+  // below the diagonal, re-dealt over the four wavefronts three / three / two / two (sp_mm.h, SymDeal) -- the plain
+  // loop multiplies all sixteen, of which nobody reads the upper six (the eager updates, the diagonal block and the
+  // next trailing update all stay below the diagonal of a diagonal tile).  Same bits for the ten.
+  if constexpr (SGN && Core::MA == 1 && Core::NA == 4 && TM == 64 && TN == 64) {
+    if ((skip00 & 4) && lower_only && ti == tj) {
+      mm.prologue(lds, k_first, Kd);
+      const int lane = threadIdx.x & 63;
+      auto run = [&](auto wtag) {
+        constexpr int W = decltype(wtag)::value;
+        using D = typename Core::template SymDeal<W>;
+        mm_d4 a3[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          mm_d4 c = mm_d4{0.0, 0.0, 0.0, 0.0};
+          if (b < D::NB && beta) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              c[r] = Cb[(size_t)(16 * D::brow(b) + (lane >> 4) + 4 * r) * ldc + 16 * D::bcol(b) + (lane & 15)];
+          }
+          a3[b] = alpha < 0.0 ? -c : c;
+        }
+        mm.template sym_loop<W>(lds, k_first, Kd, a3);
+#pragma unroll
+        for (int b = 0; b < D::NB; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            Cb[(size_t)(16 * D::brow(b) + (lane >> 4) + 4 * r) * ldc + 16 * D::bcol(b) + (lane & 15)] =
+                alpha < 0.0 ? -a3[b][r] : a3[b][r];
+      };
+      switch (threadIdx.x >> 6) {
+        case 0: run(std::integral_constant<int, 0>{}); break;
+        case 1: run(std::integral_constant<int, 1>{}); break;
+        case 2: run(std::integral_constant<int, 2>{}); break;
+        default: run(std::integral_constant<int, 3>{}); break;
+      }
+      return;
+    }
+  }
   mm_d4 acc[Core::MA][Core::NA], cin[SGN ? 1 : Core::MA][SGN ? 1 : Core::NA];
   // (first trailing update of a factorisation whose assembly left the tiles below the diagonal
   //  to their first touch: a tile of covariance rows is evaluated, not loaded -- sp_cov.h; the
@@ -430,6 +471,19 @@ extern "C" int sp_debug_set_syrk128_from(int blocks) {
   return SP_OK;
 }
 
+static int g_syrk_symdiag = -1;
+static int syrk_symdiag() {
+  if (g_syrk_symdiag < 0) {
+    const char *e = getenv("SP_SYRK_SYMDIAG");
+    g_syrk_symdiag = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return g_syrk_symdiag;
+}
+extern "C" int sp_debug_set_syrk_symdiag(int on) {
+  g_syrk_symdiag = on < 0 ? -1 : (on ? 1 : 0);    // (-1: back to the environment / default)
+  return SP_OK;
+}
+
 // C -= X X^T on the lower 64 x 64 tiles of an n x n block, tile (0, 0) skipped -- its workgroup
 // factors the pivot block `df` describes instead (sp_cholesky.hip)
 int sp_launch_syrk_diag(const double *X, long ld, long stride, double *T, int n, int kd, int batch,
@@ -451,8 +505,11 @@ int sp_launch_syrk_diag(const double *X, long ld, long stride, double *T, int n,
     SP_LAUNCH_CHECK();
     return SP_OK;
   }
+  // (SP_SYRK_SYMDIAG=0 / sp_debug_set_syrk_symdiag(0): the diagonal tiles on the plain loop, all sixteen blocks -- the
+  //  same bits below the diagonal)
+  const int symdiag = syrk_symdiag() ? 4 : 0;
   return mm_launch<MM2<64, 64, 8, SP_MM_SYRK_NS, 4>>(X, ld, stride, X, ld, stride, T, ld, stride, n, n, kd, -1.0, 1, 1,
-                                         batch, st, 1 | (tj_limit > 0 ? tj_limit << 8 : 0),
+                                         batch, st, 1 | symdiag | (tj_limit > 0 ? tj_limit << 8 : 0),
                                          (lazy && lazy->theta) ? lazy : nullptr, df);
 }
 

@@ -229,6 +229,101 @@ struct MM2 {
     }
     __builtin_amdgcn_s_barrier();
   }
+  // ---- a DIAGONAL tile of a symmetric product X X^T (TM = TN = 64, WR = 4, B = A) ------------------------------
+  // Only the ten 16 x 16 blocks on and below the tile's diagonal are wanted.  With a wavefront per block row the
+  // last one still multiplies four blocks while the first multiplies one: nothing is gained in time (round 3 built
+  // that: +- 0).  Here the ten blocks are RE-DEALT, three / three / two / two:
+  //     wavefront 0: (0,0) (3,0) (3,1)     1: (1,0) (1,1) (3,2)     2: (2,0) (2,1)     3: (2,2) (3,3)
+  // a wavefront reads the fragments of the two to four block rows its blocks need (all from the A image: the tile's
+  // rows are its columns) and issues 3 or 2 MFMAs per k-step where the plain loop issues 4.  Same slices, same k-order
+  // per block: the blocks are the plain loop's bits.
+  template <int W>
+  struct SymDeal {
+    static constexpr int NB = W < 2 ? 3 : 2;                                     // blocks of this wavefront
+    static constexpr int NF = W == 1 ? 4 : (W == 3 ? 2 : 3);                     // block rows whose fragments it reads
+    __device__ static constexpr int frow(int f) {                                // ... which ones
+      return W == 0 ? (f == 0 ? 0 : f == 1 ? 1 : 3) : W == 1 ? f : W == 2 ? f : (f == 0 ? 2 : 3);
+    }
+    __device__ static constexpr int brow(int b) {                                // block b: its row block ...
+      return W == 0 ? (b == 0 ? 0 : 3) : W == 1 ? (b < 2 ? 1 : 3) : W == 2 ? 2 : (b == 0 ? 2 : 3);
+    }
+    __device__ static constexpr int bcol(int b) {                                // ... and column block
+      return W == 0 ? (b == 0 ? 0 : b - 1) : W == 1 ? b : W == 2 ? b : (b == 0 ? 2 : 3);
+    }
+    __device__ static constexpr int fidx(int row) {                              // position of a block row in the fragment set
+      return W == 0 ? (row == 3 ? 2 : row) : W == 1 ? row : W == 2 ? row : row - 2;
+    }
+  };
+  template <int W>
+  struct SymFrags {
+    v2 f[NC][SymDeal<W>::NF];
+  };
+  template <int W>
+  __device__ __forceinline__ void sym_fetch(const double *lds, int st, SymFrags<W> &fr) const {
+    const double *base = lds + st * STAGE + (threadIdx.x & 15) * BK;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int goff = 2 * ((4 * c + q) ^ fsw);
+#pragma unroll
+      for (int i = 0; i < SymDeal<W>::NF; ++i)
+        fr.f[c][i] = *reinterpret_cast<const v2 *>(base + SymDeal<W>::frow(i) * 16 * BK + goff);
+    }
+  }
+  template <int W>
+  __device__ __forceinline__ void sym_mul_fetch(const SymFrags<W> &cur, SymFrags<W> &nxt, const double *lds, int st,
+                                                mm_d4 (&acc)[3]) const {
+    using D = SymDeal<W>;
+    const double *base = lds + st * STAGE + (threadIdx.x & 15) * BK;
+    constexpr int NR = NC * D::NF;
+    int issued = 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int b = 0; b < D::NB; ++b) {
+          const v2 a = cur.f[c][D::fidx(D::brow(b))], bb = cur.f[c][D::fidx(D::bcol(b))];
+          acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(h ? a.y : a.x, h ? bb.y : bb.x, acc[b], 0, 0, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (issued < NR) {
+            const int rc = issued / D::NF, ri = issued % D::NF;
+            const int goff = 2 * ((4 * rc + q) ^ fsw);
+            nxt.f[rc][ri] = *reinterpret_cast<const v2 *>(base + D::frow(ri) * 16 * BK + goff);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            ++issued;
+          }
+        }
+    static_assert(NR <= NC * 2 * D::NB, "more fragment reads than MFMAs to hide them behind");
+  }
+  // the control flow of loop(), with this wavefront's share of the ten blocks
+  template <int W>
+  __device__ __forceinline__ void sym_loop(double *lds, int k_begin, int k_end, mm_d4 (&acc)[3]) const {
+    const int nsl = (k_end - k_begin) / BK;
+    if (nsl <= 0) return;
+    SymFrags<W> f0, f1;
+    if (nsl >= NS - 1) mm_wait_vmcnt<(NS - 2) * LPW>(); else mm_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    sym_fetch<W>(lds, 0, f0);
+    int st1 = 1 % NS, stn = NS - 1;
+    for (int s = 0; s < nsl; s += 2) {
+      if (s + NS - 1 < nsl) mm_wait_vmcnt<(NS - 3) * LPW>(); else mm_wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (s + NS - 1 < nsl) issue(lds, stn, k_begin + (s + NS - 1) * BK);
+      sym_mul_fetch<W>(f0, f1, lds, st1, acc);
+      st1 = st1 + 1 == NS ? 0 : st1 + 1;
+      stn = stn + 1 == NS ? 0 : stn + 1;
+      if (s + 2 < nsl) {
+        if (s + NS < nsl) mm_wait_vmcnt<(NS - 3) * LPW>(); else mm_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (s + NS < nsl) issue(lds, stn, k_begin + (s + NS) * BK);
+      }
+      sym_mul_fetch<W>(f1, f0, lds, st1, acc);
+      st1 = st1 + 1 == NS ? 0 : st1 + 1;
+      stn = stn + 1 == NS ? 0 : stn + 1;
+    }
+    __builtin_amdgcn_s_barrier();
+  }
+
   __device__ __forceinline__ int acc_row(int m, int r) const {
     const int lane = threadIdx.x & 63;
     return (wave / WC) * (TM / WR) + 16 * m + (lane >> 4) + 4 * r;

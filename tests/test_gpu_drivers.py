@@ -358,6 +358,35 @@ def test_deferred_normalisation_matches_direct():
         assert out.cpu().numpy()[0] == -np.inf and (status.cpu().numpy()[0] & 2)
 
 
+@pytest.mark.parametrize("K,M", [(1000, 1), (1345, 1), (960, 70), (700, 1)])
+def test_trailing_update_diagonal_tiles_on_their_lower_blocks_are_the_same_bits(K, M):
+    """The diagonal tiles of the symmetric trailing update multiply only their ten blocks on and below the diagonal,
+    re-dealt over the four wavefronts (csrc/sp_mm.h, SymDeal): same slices, same k-order per block as the plain loop
+    -- IDENTICAL log-likelihoods, also for the inverse's factorisation (an identity riding along)."""
+    from starry_process_amd import _lib
+
+    L = _lib.lib()
+    res, inv = [], []
+    try:
+        for on in (1, 0):
+            assert L.sp_debug_set_syrk_symdiag(on) == 0
+            e = make_engine(15)
+            v, st = lnl(e, K, range(4, 12), M=M)
+            assert not st.any() and np.all(np.isfinite(v))
+            res.append(v)
+            if M == 1 and K == 700:
+                rng = np.random.RandomState(5)
+                A = rng.randn(K, K)
+                C = A @ A.T / K + np.eye(K)
+                Ci, ld, info = e.spd_inverse(C)
+                inv.append((Ci.cpu().numpy(), float(ld)))
+    finally:
+        L.sp_debug_set_syrk_symdiag(-1)
+    assert np.array_equal(res[0], res[1])
+    if inv:
+        assert np.array_equal(inv[0][0], inv[1][0]) and inv[0][1] == inv[1][1]
+
+
 @pytest.mark.parametrize("K,kw", [(2100, {}), (2112, dict(tau=2.5)), (3000, dict(tau=3.0, u=(0.4, 0.2)))])
 def test_large_trailing_updates_on_128_row_tiles_are_the_same_bits(K, kw):
     """Remainders of 17 blocks and more take the trailing update's 128 x 64 tiles (csrc/sp_gemm.hip, syrk128_kernel;
