@@ -40,11 +40,11 @@ int sp_launch_assemble(int S, int K, int M, int Kp, int system,
 int sp_launch_assemble_sums(int S, int K, int M, int Kp, const double *theta, const double *t,
                             const sp_star *stars, int covpts, const double *ptab, const double *meanvar,
                             int temporal, const double *flux, double *sys, hipStream_t st, double *part,
-                            int lazy_nfull);
+                            int lazy_nfull, int *nflat);
 int sp_launch_defer_finish(int S, int K, int M, int Kp, const sp_star *stars, const double *meanvar,
                            const double *condmean, int order, double zmax, const double *part,
                            const double *diag, const double *flux, double *sys, void *coef, double *rscal,
-                           uint32_t *status, hipStream_t st);
+                           uint32_t *status, hipStream_t st, int nflat = 0);
 int sp_launch_assemble_planned(int S, int K, int M, int Kp, const PlanDev &plan, const double *t,
                                const sp_star *stars, int covpts, const double *tab, const double *meanvar,
                                int temporal, const double *flux, const double *diag, double *sys, int nfull,
@@ -453,16 +453,17 @@ int lnlike_assemble(sp_handle *h, const Layout &L, void *ws, int K, int M, const
     // deferred normalisation: ONE pass over the K^2 entries (raw tiles + their row / column sums),
     // then the normalisation's vectors as three more rows of the system (sp_assemble.hip)
     double *part = at<double>(ws, L.part);
+    int nflat = 0;
     if (!rawp && ptab && sp_assemble_sums_lds(L.Kp, cp, temporal) <= SP_ASM_LDS_MAX)
       rc = sp_launch_assemble_sums(S, K, M, L.Kp, theta, t_dev, stars_dev, cp, ptab, meanvar_dev, temporal,
-                                   flux_dev, sys, st, part, lazy_nfull);
+                                   flux_dev, sys, st, part, lazy_nfull, &nflat);
     else
       rc = sp_launch_assemble(S, K, M, L.Kp, 1, theta, t_dev, stars_dev, cp, tab_dev, meanvar_dev,
                               h->d_xp, temporal, rawp, 1, qv, coef, diag_dev, 1, flux_dev, sys,
                               L.Kp, (long)L.Kp * L.Kp, st, part, lazy_nfull);
     if (rc) return rc;
     return sp_launch_defer_finish(S, K, M, L.Kp, stars_dev, meanvar_dev, condmean, norm_order, zmax,
-                                  part, diag_dev, flux_dev, sys, coef, at<double>(ws, L.rscal), status, st);
+                                  part, diag_dev, flux_dev, sys, coef, at<double>(ws, L.rscal), status, st, nflat);
   }
   if (normalized)
     if ((rc = sp_launch_rowsum(S, K, theta, t_dev, stars_dev, cp, tab_dev, meanvar_dev,

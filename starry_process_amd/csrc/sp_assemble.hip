@@ -342,9 +342,11 @@ __global__ __launch_bounds__(256) void assemble_kernel(
 //   * the phases of a tile's rows are fetched one tile ahead; the tile loop has no barrier at all;
 //   * the 16 entries of a thread are evaluated as ONE batch (SplineGen::many) and the temporal kernel is a
 //     template parameter: no run-time switch (and no inlined exp) between entries.
-// Same operations per entry as the general kernel and as the tiles formed at first touch: same bits; the sums
-// land in the slots defer_finish_kernel adds up (the column sums of a strip segment in the segment's first
-// slot, zeros in its others).
+// Same operations per entry as the general kernel and as the tiles formed at first touch: same bits.
+// Round 5: the reduction needs nothing of the covariance's row sums any more (sp_reduce.h) -- only the star's TOTAL,
+// for m = mean(Sigma).  A thread adds up its entries (a tile below the diagonal counts twice: its mirror is never
+// formed), a workgroup leaves ONE number, part[s][chunk]; rounds 2-4 took row sums by DPP and column sums through LDS
+// per strip (a third of the kernel's cycles) and stored K numbers per tile row.
 #ifdef SP_ASM_STAMPS
 __device__ long long sp_asm_dbg[8 * 8192];
 #endif
@@ -368,7 +370,10 @@ __global__ __launch_bounds__(256, SP_ASM_OCC) void assemble_sums_kernel(
 #endif
   const sp_star st = stars[s];
   const int t0 = chunks.start[blockIdx.x], t1 = chunks.start[blockIdx.x + 1];
-  if (t0 >= t1) return;
+  if (t0 >= t1) {
+    if (threadIdx.x == 0) part[(size_t)s * gridDim.x + blockIdx.x] = 0.0;
+    return;
+  }
   // strip-major tile order: strip tj holds the tiles ti = tj .. ntr - 1
   int tj = 0, ti;
   {
@@ -380,8 +385,8 @@ __global__ __launch_bounds__(256, SP_ASM_OCC) void assemble_sums_kernel(
     ti = tj + rem;
   }
   double *s_tab = lds;                       // 4 np
-  double *s_col = s_tab + 4 * np;            // [16][64] column-sum partials
-  double *s_th = s_col + 16 * 64;            // [Kp] the star's phases (zero beyond K)
+  double *s_red = s_tab + 4 * np;            // 8: the workgroup's sum
+  double *s_th = s_red + 8;                  // [Kp] the star's phases (zero beyond K)
   double *s_tt = s_th + Kp;                  // [Kp] its times (temporal kernels only)
   const int nobs = star_nobs(st, K);
   const double *th = theta + (size_t)s * K, *tt = t + (size_t)s * K;
@@ -465,9 +470,7 @@ __global__ __launch_bounds__(256, SP_ASM_OCC) void assemble_sums_kernel(
   SplineGen g{s_tab, 2 * np, 6.283185307179586 / covpts, 1.0 / (6.283185307179586 / covpts), covpts};
   const double var1 = nobs == 1 ? meanvar[2 * st.table + 1] : 0.0;
   double *ob = out + (size_t)s * strideo;
-  double *ps = part + (size_t)s * ntr * K;
-  double csum[4] = {0.0, 0.0, 0.0, 0.0};
-  int seg0 = -1;                             // first row tile below the diagonal of this strip segment
+  double tsum = 0.0;                         // this thread's share of the star's total (off-diagonal tiles twice)
 #ifdef SP_ASM_STAMPS
   long long stamp_eval = 0, stamp_sums = 0, stamp_rest = 0, stamp_loop0 = __builtin_readcyclecounter();
 #define SP_STAMP(acc, since) do { const long long now_ = __builtin_readcyclecounter(); acc += now_ - since; since = now_; } while (0)
@@ -523,24 +526,19 @@ __global__ __launch_bounds__(256, SP_ASM_OCC) void assemble_sums_kernel(
     // (tiles the factorisation forms itself at first touch: sums taken, nothing written -- not the first block
     //  column: its panel launch has no product to form the tile behind)
     const bool skip_write = ti > tj && tj > 0 && ti < lazy_nfull;
-    if (ti > tj && seg0 < 0) seg0 = ti;
+    const double twice = ti > tj ? 2.0 : 1.0;
     if (i0 + 64 <= nobs && j0 + 64 <= nobs) {
       // a tile of valid cadences only (all but the last row / column tile of a system): no masks -- the general
       // form below spends five instructions on predicates and selects for every one of the evaluation
-      double rs[4];
+      double ts = 0.0;
 #pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        rs[pass] = (v[4 * pass] + v[4 * pass + 1]) + (v[4 * pass + 2] + v[4 * pass + 3]);
+      for (int pass = 0; pass < 4; ++pass)
+        ts += (v[4 * pass] + v[4 * pass + 1]) + (v[4 * pass + 2] + v[4 * pass + 3]);
+      tsum += twice * ts;
+      if (!skip_write) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) csum[e] += v[4 * pass + e];
-      }
-      row16_sum(rs);      // the 16 lanes that share a row
-#pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        const int i = i0 + ri + 16 * pass;
-        if (cl == 0) ps[(size_t)tj * K + i] = rs[pass];
-        if (!skip_write) {
-          double *dst = ob + (size_t)i * ldo + j0 + cl;
+        for (int pass = 0; pass < 4; ++pass) {
+          double *dst = ob + (size_t)(i0 + ri + 16 * pass) * ldo + j0 + cl;
 #pragma unroll
           for (int e = 0; e < 4; ++e) dst[16 * e] = v[4 * pass + e];
         }
@@ -558,7 +556,6 @@ __global__ __launch_bounds__(256, SP_ASM_OCC) void assemble_sums_kernel(
           if (i < nobs && j < nobs) {
             val = v[4 * pass + e];
             rsum += val;
-            csum[e] += val;
           } else if (i >= K && i < K + M && j < nobs) {
             val = flux[((size_t)s * M + (i - K)) * K + j] - st.baseline_mean;   // (the GP mean of the normalised process is 0)
           } else if (i == j) {
@@ -566,13 +563,7 @@ __global__ __launch_bounds__(256, SP_ASM_OCC) void assemble_sums_kernel(
           }
           w[e] = val;
         }
-        // row sum of this tile's 64 columns: the 16 lanes that share the row
-        {
-          double one[1] = {rsum};
-          row16_sum(one);
-          rsum = one[0];
-        }
-        if (cl == 0 && i < K) ps[(size_t)tj * K + i] = rsum;
+        tsum += twice * rsum;
         if (i >= Kp || skip_write) continue;
         double *dst = ob + (size_t)i * ldo + j0 + cl;
 #pragma unroll
@@ -581,37 +572,9 @@ __global__ __launch_bounds__(256, SP_ASM_OCC) void assemble_sums_kernel(
       }
     }
     SP_STAMP(stamp_sums, stamp_t);
-    if (ti == tj) {
-      // (the diagonal tile has no mirror: its entries are not column sums of anything)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) csum[e] = 0.0;
-    }
-    if (strip_ends) {
-      if (seg0 >= 0) {
-        // column sums of the segment's tiles below the diagonal = row sums of their mirror tiles (tj, ti), which are
-        // never formed: the whole segment's in the slot of its first tile, zeros in the slots of the others
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s_col[ri * 64 + cl + 16 * e] = csum[e];
-        __syncthreads();
-        if (tid < 64) {
-          double a = 0.0;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) a += s_col[r * 64 + tid];
-          const int j = j0 + tid;
-          if (j < K) {
-            ps[(size_t)seg0 * K + j] = a;
-            for (int c = seg0 + 1; c <= ti; ++c) ps[(size_t)c * K + j] = 0.0;
-          }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 4; ++e) csum[e] = 0.0;
-        seg0 = -1;
-      }
-      if (tile + 1 < t1) {
-        load_cols(tj + 1);
-        strip_factors(tj + 1);
-      }
+    if (strip_ends && tile + 1 < t1) {
+      load_cols(tj + 1);
+      strip_factors(tj + 1);
     }
     if (ti == ntr - 1) {
       ++tj;
@@ -621,6 +584,11 @@ __global__ __launch_bounds__(256, SP_ASM_OCC) void assemble_sums_kernel(
     }
     SP_STAMP(stamp_rest, stamp_t);
   }
+  // the workgroup's sum: wavefront sums, then the four of them in a fixed order
+  for (int off = 32; off > 0; off >>= 1) tsum += __shfl_down(tsum, off, 64);
+  if ((tid & 63) == 0) s_red[tid >> 6] = tsum;
+  __syncthreads();
+  if (tid == 0) part[(size_t)s * gridDim.x + blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 #ifdef SP_ASM_STAMPS
   if (tid == 0) {
     long long *o = sp_asm_dbg + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
@@ -654,8 +622,10 @@ __device__ __forceinline__ double block_sum_1024(double v, double *red) {
   return total;
 }
 
+// nflat > 0: part[s][0 .. nflat) holds partial TOTALS (assemble_sums_kernel); else part[s][column tile][row] holds
+// the tiles' row / column sums (assemble_kernel<.., DEFER>, cond_system_kernel)
 __global__ __launch_bounds__(1024) void defer_finish_kernel(
-    int K, int M, int Kp, int ntr, const sp_star *__restrict__ stars,
+    int K, int M, int Kp, int ntr, int nflat, const sp_star *__restrict__ stars,
     const double *__restrict__ meanvar, const double *__restrict__ condmean, int order, double zmax,
     const double *__restrict__ part, const double *__restrict__ diag, const double *__restrict__ flux,
     double *__restrict__ sys, Coef *__restrict__ coef, double *__restrict__ rscal,
@@ -665,9 +635,14 @@ __global__ __launch_bounds__(1024) void defer_finish_kernel(
   const sp_star st = stars[s];
   const int nobs = star_nobs(st, K);
   double *Mx = sys + (size_t)s * Kp * Kp;
-  const double *P = part + (size_t)s * ntr * K;
+  const double *P = part + (size_t)s * (nflat > 0 ? nflat : ntr * K);
   // (ragged stars: tiles beyond nobs contribute zeros)
   double mine = 0.0;
+  if (nflat > 0) {
+    // (one thread, fixed order: a few dozen numbers)
+    if (threadIdx.x == 0)
+      for (int c = 0; c < nflat; ++c) mine += P[c];
+  } else
   for (int r = threadIdx.x; r < K; r += 1024) {
     // the column tiles eight at a time: the loads of a group are independent, the sum keeps its order
     double a = 0.0;
@@ -869,13 +844,13 @@ extern "C" int sp_debug_asm_chunks(int ntr, int nchunk, int *start_host) {
 
 // LDS of the hot form: the star's table, the column-sum partials, its phases (and times); two workgroups per CU
 size_t sp_assemble_sums_lds(int Kp, int covpts, int temporal) {
-  return sizeof(double) * (4 * (size_t)(covpts + 4) + 16 * 64 + (size_t)Kp * (temporal == SP_TEMPORAL_NONE ? 1 : 2));
+  return sizeof(double) * (4 * (size_t)(covpts + 4) + 8 + (size_t)Kp * (temporal == SP_TEMPORAL_NONE ? 1 : 2));
 }
 
 int sp_launch_assemble_sums(int S, int K, int M, int Kp, const double *theta, const double *t,
                             const sp_star *stars, int covpts, const double *ptab, const double *meanvar,
                             int temporal, const double *flux, double *sys, hipStream_t st, double *part,
-                            int lazy_nfull) {
+                            int lazy_nfull, int *nflat) {
   const size_t lds = sp_assemble_sums_lds(Kp, covpts, temporal);
   if (lds > SP_ASM_LDS_MAX || !ptab || !part) return SP_ERR_INVALID;
   const int ntr = Kp / 64, ntiles = ntr * (ntr + 1) / 2;
@@ -891,6 +866,8 @@ int sp_launch_assemble_sums(int S, int K, int M, int Kp, const double *theta, co
   if (ntiles > 65535) return SP_ERR_INVALID;
   const AsmChunks chunks = asm_chunks(ntr, nchunk);
   dim3 grid(nchunk, S);
+  if ((size_t)nchunk > (size_t)ntr * K) return SP_ERR_INVALID;   // (part holds ntr K doubles per star)
+  if (nflat) *nflat = nchunk;       // part[s][0 .. nchunk): one partial total per workgroup
 #ifdef SP_PROBE
   // (what would a free assembly be worth?  results are garbage; timing probe only)
   static const bool skip = getenv("SP_PROBE_SKIP_ASM") != nullptr;
@@ -914,8 +891,8 @@ int sp_launch_assemble_sums(int S, int K, int M, int Kp, const double *theta, co
 int sp_launch_defer_finish(int S, int K, int M, int Kp, const sp_star *stars, const double *meanvar,
                            const double *condmean, int order, double zmax, const double *part,
                            const double *diag, const double *flux, double *sys, void *coef, double *rscal,
-                           uint32_t *status, hipStream_t st) {
-  hipLaunchKernelGGL(defer_finish_kernel, dim3(S), dim3(1024), 0, st, K, M, Kp, Kp / 64, stars, meanvar,
+                           uint32_t *status, hipStream_t st, int nflat) {
+  hipLaunchKernelGGL(defer_finish_kernel, dim3(S), dim3(1024), 0, st, K, M, Kp, Kp / 64, nflat, stars, meanvar,
                      condmean, order, zmax, part, diag, flux, sys, (Coef *)coef, rscal, status);
   SP_LAUNCH_CHECK();
   return SP_OK;
