@@ -49,7 +49,7 @@ int sp_launch_assemble_planned(int S, int K, int M, int Kp, const PlanDev &plan,
                                const sp_star *stars, int covpts, const double *tab, const double *meanvar,
                                int temporal, const double *flux, const double *diag, double *sys, int nfull,
                                int ncolw, int order, double zmax, void *coef, double *rscal, double *ptab, int32_t *info,
-                               uint32_t *status, hipStream_t st, double *img, long lts, int fuse0);
+                               uint32_t *status, hipStream_t st, double *img, long lts, int fuse0, double *rid);
 int sp_launch_cholesky_systems(sp_handle *h, double *sys, int S, int K, int Kp,
                                int32_t *info, double *invL, hipStream_t st);
 int sp_launch_cond_system(const double *B1, const double *A, int N, int Kr, int S, int K, int M, int Kp,
@@ -1256,13 +1256,24 @@ int sp_lnlike_ensemble_planned(sp_handle *h, const sp_plan *plan, const double *
   // tiles only -- an exponential per entry has no place in the panel kernel's register budget, so the assembly writes
   // the first super-panel's block columns; every entry is still evaluated once.
   int lazy_nfull = 0, ncolw = 0, no_panels = 0;
+  // (the row tiles that hold riding rows -- residuals, ones, variances -- are formed at first touch as well: every row
+  //  tile is formable, the assembly writes the diagonal tiles only; SP_PLAN_RIDING_LAZY=0: it writes those row tiles)
+  static const bool riding_env = !(getenv("SP_PLAN_RIDING_LAZY") && atoi(getenv("SP_PLAN_RIDING_LAZY")) == 0);
+  bool riding = false;
+  const int nrid = M + (diag_dev ? 2 : 1);
+  double *rid = at<double>(ws, L.B1);
   if (h->lazy_cov && ptab && K / SP_NB >= 2 && 4 * (covpts + 4) + 64 <= SP_TILE_LDS_MIN) {
-    lazy_nfull = K / SP_NB;
-    if (temporal != SP_TEMPORAL_NONE) {
+    // (the riding rows as the assembly would write them, [S][nrid][K], in the second design-matrix buffer)
+    riding = riding_env && (size_t)nrid * K <= (size_t)L.Kr * L.N;
+    lazy_nfull = riding ? L.Kp / SP_NB : K / SP_NB;
+    // (SP_PLAN_PANEL_LAZY=0: without a temporal kernel too, the panel launches load their tiles and only the first
+    //  trailing update forms its own -- measured, not the default: DESIGN.md 4.11)
+    static const bool panel_lazy = !(getenv("SP_PLAN_PANEL_LAZY") && atoi(getenv("SP_PLAN_PANEL_LAZY")) == 0);
+    if (temporal != SP_TEMPORAL_NONE || !panel_lazy) {
       static const bool tl = !(getenv("SP_PLAN_TEMPORAL_LAZY") && atoi(getenv("SP_PLAN_TEMPORAL_LAZY")) == 0);
       ncolw = sp_superpanel_width(h, K);
       no_panels = 1;
-      if (!tl || ncolw * SP_NB >= K) lazy_nfull = ncolw = no_panels = 0;   // (one super-panel: no trailing update)
+      if ((!tl && temporal != SP_TEMPORAL_NONE) || ncolw * SP_NB >= K) lazy_nfull = ncolw = no_panels = 0;   // (one super-panel: no trailing update)
     }
   }
   // (pivot block 0 is factored by the assembly's workgroup of tile (0, 0): no launch of its own; SP_PLAN_FUSE0=0 for
@@ -1272,7 +1283,8 @@ int sp_lnlike_ensemble_planned(sp_handle *h, const sp_plan *plan, const double *
   int rc = sp_launch_assemble_planned(S, K, M, L.Kp, plan->dev, t_dev, stars_dev, covpts, tab_dev, meanvar_dev, temporal,
                                       flux_dev, diag_dev, at<double>(ws, L.sys), lazy_nfull, ncolw, norm_order, zmax,
                                       at<double>(ws, L.coef), at<double>(ws, L.rscal), ptab, at<int32_t>(ws, L.info),
-                                      at<uint32_t>(ws, L.status), st, at<double>(ws, L.invL), sp_lt_stride(L.Kp), fuse0);
+                                      at<uint32_t>(ws, L.status), st, at<double>(ws, L.invL), sp_lt_stride(L.Kp), fuse0,
+                                      riding ? rid : nullptr);
   if (rc) return rc;
   const bool fused_reduce = sp_panel_fuses_reduce(h, K, L.Kp);
   sp_chol_group G{at<double>(ws, L.sys), at<int32_t>(ws, L.info), at<double>(ws, L.invL), S, st, LazyCov{}, SpReduceArgs{}};
@@ -1282,7 +1294,7 @@ int sp_lnlike_ensemble_planned(sp_handle *h, const sp_plan *plan, const double *
   G.block0_done = fuse0 != 0;
   if (lazy_nfull)
     G.lazy = LazyCov{plan->dev.theta, t_dev, stars_dev, ptab, K, covpts, temporal, lazy_nfull, 0, 0, no_panels ? 0 : 1,
-                     no_panels};
+                     no_panels, riding ? rid : nullptr, riding ? nrid : 0};
   if ((rc = sp_launch_cholesky_groups(h, 1, &G, K, L.Kp))) return rc;
   if (!fused_reduce) return lnlike_finish(L, ws, K, M, lnlike_dev, status_dev, st, stars_dev, true, diag_dev != nullptr);
   return SP_OK;

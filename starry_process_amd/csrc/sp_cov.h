@@ -222,6 +222,20 @@ __device__ __forceinline__ void lazy_cov_tile(const LazyCov &z, int star, const 
       out[n][r] = w;
     }
   }
+  if (z.rid) {
+    // (a row tile that holds rows below the cadences: residuals, ones, variances -- the planned step; LazyCov.rid)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = ri[r] - z.K;
+      if (m < 0 || m >= z.nrid) continue;
+      const double *src = z.rid + ((size_t)star * z.nrid + m) * z.K;
+      double x[4];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) x[n] = src[cj[n] < z.K ? cj[n] : z.K - 1];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) out[n][r] = cj[n] < z.K ? x[n] : 0.0;
+    }
+  }
   __syncthreads();   // the scratch goes back to its owner
 }
 
@@ -330,6 +344,27 @@ __device__ __forceinline__ void lazy_cov_row(const LazyCov &z, int star, int ri,
     // (one batch after the other: left to itself the scheduler starts all of them at once)
     __builtin_amdgcn_sched_barrier(0);
   }
+  }
+  if (z.rid && !oi) {
+    // (this lane's row lies below the cadences: residuals, ones, variances -- the planned step leaves the row tiles
+    //  that hold them to their first touch too, LazyCov.rid; its sixteen columns' loads all issued before the first use)
+    const int mr = ri - z.K;
+    if (mr >= 0 && mr < z.nrid) {
+      const double *src = z.rid + ((size_t)star * z.nrid + mr) * z.K;
+      double x[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int c = c0 + 16 * (e >> 2) + (e & 3);
+        x[e] = src[c < z.K ? c : z.K - 1];        // (clamped: a row tile of riding rows only may reach columns beyond K)
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        V4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = c0 + 16 * m + r < z.K ? x[4 * m + r] : 0.0;
+        out[m] = o;
+      }
+    }
   }
   __syncthreads();   // the scratch goes back to its owner
 }

@@ -172,6 +172,13 @@ struct LazyCov {
   int no_panels;           // the panel launches form nothing (temporal kernels: an exponential per entry has no place
                            // in the panel kernel): the first super-panel's block columns come from memory, only the
                            // first trailing update forms its tiles
+  // The rows BELOW the cadences of a tile left of the diagonal (rid != null: the planned step, which then leaves the
+  // row tiles that hold them to their first touch as well -- nfull = every row tile): rid[star][m][col], m < nrid, is
+  // row K + m of the star's system as the assembly would have written it (the residuals flux[m] - baseline_mean, the
+  // row of ones, the variances / c1; zero beyond the star's cadences); rows from K + nrid on are zero left of the
+  // diagonal.  One pointer and one count: the panel kernel's lazy instantiations have no scalar registers to spare.
+  const double *rid;       // [S][nrid][K]
+  int nrid;
 };
 
 // Per-star normalisation coefficients: 8 doubles per star in the workspace (`coef`), written by

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256, SP_PLAN_OCC) void assemble_planned_kernel(
     int order,
     double zmax, Coef *__restrict__ coef, double *__restrict__ rscal, double *__restrict__ ptab,
     int32_t *__restrict__ info, uint32_t *__restrict__ status, int lds_phases, double *__restrict__ img, long lts,
-    int fuse0, int S, int nchunk, AsmChunks chunks) {
+    int fuse0, int S, int nchunk, double *__restrict__ rid, AsmChunks chunks) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   // Workgroup -> (star, chunk).  The hardware deals consecutive workgroups to the 8 XCDs in turn and, inside an XCD,
   // to its 32 CUs in turn (sp_panel.hip: XCD-local indices k, k + 32, ... share a CU).  A batch that 8 divides gives
@@ -186,6 +186,24 @@ __global__ __launch_bounds__(256, SP_PLAN_OCC) void assemble_planned_kernel(
       const bool stale = !(key[0] == st.period) || (TK != SP_TEMPORAL_NONE && !(key[1] == st.tau)) || key[2] != (double)nobs;
       if (info) info[s] = 0;
       if (status) status[s] = (c.z > zmax ? SP_STAR_ZMAX : 0u) | (stale ? SP_STAR_STALE_PLAN : 0u);
+    }
+  }
+  if (rid && chunk == nchunk - 1) {
+    // The rows below the cadences as the row tiles that hold them would carry them LEFT of the diagonal --
+    // rid[s][m][col]: the residuals, the row of ones, the variances / c1 -- for the kernels that form those tiles at
+    // their first touch (LazyCov.rid).  A few K numbers per star, by the star's last workgroup (not the one that
+    // factors pivot block 0).
+    const int nrid = M + (diag ? 2 : 1);
+    double *dst = rid + (size_t)s * nrid * K;
+    for (int e = tid; e < nrid * K; e += 256) {
+      const int m = e / K, col = e - m * K;
+      double val = 0.0;
+      if (col < nobs) {
+        if (m < M) val = flux[((size_t)s * M + m) * K + col] - st.baseline_mean;
+        else if (m == M) val = 1.0;
+        else val = diag[(size_t)s * K + col] * inv_c1;
+      }
+      dst[e] = val;
     }
   }
   if (t0 >= t1) return;
@@ -429,7 +447,7 @@ int sp_launch_assemble_planned(int S, int K, int M, int Kp, const PlanDev &plan,
                                const sp_star *stars, int covpts, const double *tab, const double *meanvar,
                                int temporal, const double *flux, const double *diag, double *sys, int nfull,
                                int ncolw, int order, double zmax, void *coef, double *rscal, double *ptab, int32_t *info,
-                               uint32_t *status, hipStream_t st, double *img, long lts, int fuse0) {
+                               uint32_t *status, hipStream_t st, double *img, long lts, int fuse0, double *rid) {
   const int ntr = Kp / 64, ntiles = ntr * (ntr + 1) / 2;
   if (ntiles > 65535 || !coef || !rscal || (fuse0 && (!img || K < 64))) return SP_ERR_INVALID;
   int lds_phases = 1;
@@ -463,7 +481,7 @@ int sp_launch_assemble_planned(int S, int K, int M, int Kp, const PlanDev &plan,
     allow_big_lds(assemble_planned_kernel<TK>);                                                           \
     hipLaunchKernelGGL((assemble_planned_kernel<TK>), grid, dim3(256), lds, st, K, M, Kp, plan, t, stars, \
                        covpts, tab, meanvar, flux, diag, sys, (long)Kp, (long)Kp * Kp, ntr, nfull, ncolw, order, \
-                       zmax, (Coef *)coef, rscal, ptab, info, status, lds_phases, img, lts, fuse0, S, nchunk, chunks); \
+                       zmax, (Coef *)coef, rscal, ptab, info, status, lds_phases, img, lts, fuse0, S, nchunk, rid, chunks); \
   } while (0)
   if (temporal == SP_TEMPORAL_NONE) SP_ASMP(SP_TEMPORAL_NONE);
   else if (temporal == SP_TEMPORAL_MATERN32) SP_ASMP(SP_TEMPORAL_MATERN32);
