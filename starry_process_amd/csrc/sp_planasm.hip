@@ -460,8 +460,9 @@ int sp_launch_assemble_planned(int S, int K, int M, int Kp, const PlanDev &plan,
   int nwritten = 0;
   for (int b = 0; b < ntr; ++b)
     for (int a = b; a < ntr; ++a) nwritten += (a == b || a >= nfull || b < ncolw) ? 1 : 0;
-  // Written tiles per workgroup: one round of two workgroups per CU where that leaves a workgroup at least four
-  // tiles (cfg3: 31 tiles x 64 stars on 512 slots), never more than 24 (cfg5's shape: 1 128 tiles per star, three
+  // Written tiles per workgroup: one round of two workgroups per CU where that leaves a workgroup at least three
+  // tiles (cfg3: 16 diagonal tiles x 64 stars: 3 per workgroup, 0.755 ms per step one at a time against 0.762 with
+  // 2 or 4), never more than 24 (cfg5's shape: 1 128 tiles per star, three
   // rounds -- a workgroup's prologue copies the star's phases and times, 48 KB there).  No sums are taken here: the
   // cut changes no bit of the result.  SP_PLAN_TILES overrides.
   static const int per_env = [] {
@@ -469,7 +470,7 @@ int sp_launch_assemble_planned(int S, int K, int M, int Kp, const PlanDev &plan,
     return e ? atoi(e) : 0;
   }();
   int per = per_env > 0 ? per_env : (int)(((long)nwritten * S + 511) / 512);
-  if (per_env <= 0) per = per < 4 ? 4 : (per > 24 ? 24 : per);
+  if (per_env <= 0) per = per < 3 ? 3 : (per > 24 ? 24 : per);
   int nchunk = (nwritten + per - 1) / per;
   if (nchunk > SP_ASM_MAX_CHUNKS) nchunk = SP_ASM_MAX_CHUNKS;
   if (nchunk < 1) nchunk = 1;
