@@ -798,13 +798,14 @@ def main():
     if world == 1 and not args.no_extras:
         extras = {}
         try:
-            extras["cfg5_shape"] = bench_shape(torch, dist, ydeg=20, Kc=3000, S=32, tspan=30.0, tau=3.0,
-                                               u=(0.4, 0.2), conditional=False, F=F, steps=12, device=local_rank,
-                                               planned=plan is not None)
+            # (the unplanned form first: the first shape measured after the headline also warms this shape's buffers up)
             if plan is not None:
                 extras["cfg5_shape_unplanned"] = bench_shape(torch, dist, ydeg=20, Kc=3000, S=32, tspan=30.0, tau=3.0,
-                                                             u=(0.4, 0.2), conditional=False, F=F, steps=12,
+                                                             u=(0.4, 0.2), conditional=False, F=F, steps=24,
                                                              device=local_rank)
+            extras["cfg5_shape"] = bench_shape(torch, dist, ydeg=20, Kc=3000, S=32, tspan=30.0, tau=3.0,
+                                               u=(0.4, 0.2), conditional=False, F=F, steps=24, device=local_rank,
+                                               planned=plan is not None)
             # BASELINE configs[1]: ONE light curve (the reference's own use: sp.log_likelihood inside a sampler), the
             # latency of an evaluation and what four of them in flight give
             extras["cfg2_single_star"] = bench_shape(torch, dist, ydeg=15, Kc=1000, S=1, tspan=4.0, tau=None, u=(0.0, 0.0),
