@@ -49,7 +49,7 @@ int sp_launch_assemble_planned(int S, int K, int M, int Kp, const PlanDev &plan,
                                const sp_star *stars, int covpts, const double *tab, const double *meanvar,
                                int temporal, const double *flux, const double *diag, double *sys, int nfull,
                                int ncolw, int order, double zmax, void *coef, double *rscal, double *ptab, int32_t *info,
-                               uint32_t *status, hipStream_t st, double *img, long lts, int fuse0, double *rid);
+                               uint32_t *status, hipStream_t st, double *img, long lts, int fuse0, double *rid, int dfrom);
 int sp_launch_cholesky_systems(sp_handle *h, double *sys, int S, int K, int Kp,
                                int32_t *info, double *invL, hipStream_t st);
 int sp_launch_cond_system(const double *B1, const double *A, int N, int Kr, int S, int K, int M, int Kp,
@@ -1264,7 +1264,7 @@ int sp_lnlike_ensemble_planned(sp_handle *h, const sp_plan *plan, const double *
   double *rid = at<double>(ws, L.B1);
   if (h->lazy_cov && ptab && K / SP_NB >= 2 && 4 * (covpts + 4) + 64 <= SP_TILE_LDS_MIN) {
     // (the riding rows as the assembly would write them, [S][nrid][K], in the second design-matrix buffer)
-    riding = riding_env && (size_t)nrid * K <= (size_t)L.Kr * L.N;
+    riding = riding_env && ((size_t)nrid + 1) * K <= (size_t)L.Kr * L.N;
     lazy_nfull = riding ? L.Kp / SP_NB : K / SP_NB;
     // (SP_PLAN_PANEL_LAZY=0: without a temporal kernel too, the panel launches load their tiles and only the first
     //  trailing update forms its own -- measured, not the default: DESIGN.md 4.11)
@@ -1276,6 +1276,19 @@ int sp_lnlike_ensemble_planned(sp_handle *h, const sp_plan *plan, const double *
       if ((!tl && temporal != SP_TEMPORAL_NONE) || ncolw * SP_NB >= K) lazy_nfull = ncolw = no_panels = 0;   // (one super-panel: no trailing update)
     }
   }
+  // The diagonal tiles beyond the first super-panel's reach (those the eager updates of its launches do not touch) are
+  // formed by the first trailing update too (LazyCov.dlazy bit 1), when that update runs on the kernel that can
+  // (sp_syrk_can_form_diag) and everything else of their strips is left to its first touch; SP_PLAN_DIAG_LAZY=0: the
+  // assembly writes them.
+  static const bool dlazy_env = !(getenv("SP_PLAN_DIAG_LAZY") && atoi(getenv("SP_PLAN_DIAG_LAZY")) == 0);
+  const int ntr = L.Kp / SP_NB, wsp = sp_superpanel_width(h, K), nsteps = (K + SP_NB - 1) / SP_NB;
+  int dlazy = 0, dfrom = ntr;
+  if (dlazy_env && riding && lazy_nfull == ntr && wsp * SP_NB < K && sp_syrk_can_form_diag(ntr - wsp) &&
+      temporal == SP_TEMPORAL_NONE) {
+    const int last = wsp < nsteps - 1 ? wsp : nsteps - 1;     // (cholesky_panel2: row tiles i <= last keep their diagonal tile up to date)
+    dlazy = 2;
+    dfrom = last + 1;
+  }
   // (pivot block 0 is factored by the assembly's workgroup of tile (0, 0): no launch of its own; SP_PLAN_FUSE0=0 for
   //  the separate launch)
   static const bool fuse0_env = !(getenv("SP_PLAN_FUSE0") && atoi(getenv("SP_PLAN_FUSE0")) == 0);
@@ -1284,7 +1297,7 @@ int sp_lnlike_ensemble_planned(sp_handle *h, const sp_plan *plan, const double *
                                       flux_dev, diag_dev, at<double>(ws, L.sys), lazy_nfull, ncolw, norm_order, zmax,
                                       at<double>(ws, L.coef), at<double>(ws, L.rscal), ptab, at<int32_t>(ws, L.info),
                                       at<uint32_t>(ws, L.status), st, at<double>(ws, L.invL), sp_lt_stride(L.Kp), fuse0,
-                                      riding ? rid : nullptr);
+                                      riding ? rid : nullptr, dfrom);
   if (rc) return rc;
   const bool fused_reduce = sp_panel_fuses_reduce(h, K, L.Kp);
   sp_chol_group G{at<double>(ws, L.sys), at<int32_t>(ws, L.info), at<double>(ws, L.invL), S, st, LazyCov{}, SpReduceArgs{}};
@@ -1292,9 +1305,10 @@ int sp_lnlike_ensemble_planned(sp_handle *h, const sp_plan *plan, const double *
     G.red = SpReduceArgs{lnlike_dev, at<uint32_t>(ws, L.status), status_dev, stars_dev, (const void *)at<double>(ws, L.coef),
                          at<double>(ws, L.rscal), diag_dev ? 1 : 0, K, M, K + M + (diag_dev ? 2 : 1)};
   G.block0_done = fuse0 != 0;
+  (void)dlazy;
   if (lazy_nfull)
     G.lazy = LazyCov{plan->dev.theta, t_dev, stars_dev, ptab, K, covpts, temporal, lazy_nfull, 0, 0, no_panels ? 0 : 1,
-                     no_panels, riding ? rid : nullptr, riding ? nrid : 0};
+                     no_panels, riding ? rid : nullptr, riding ? nrid : 0, dlazy};
   if ((rc = sp_launch_cholesky_groups(h, 1, &G, K, L.Kp))) return rc;
   if (!fused_reduce) return lnlike_finish(L, ws, K, M, lnlike_dev, status_dev, st, stars_dev, true, diag_dev != nullptr);
   return SP_OK;

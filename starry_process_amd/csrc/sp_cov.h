@@ -228,7 +228,7 @@ __device__ __forceinline__ void lazy_cov_tile(const LazyCov &z, int star, const 
     for (int r = 0; r < 4; ++r) {
       const int m = ri[r] - z.K;
       if (m < 0 || m >= z.nrid) continue;
-      const double *src = z.rid + ((size_t)star * z.nrid + m) * z.K;
+      const double *src = z.rid + ((size_t)star * (z.nrid + 1) + m) * z.K;
       double x[4];
 #pragma unroll
       for (int n = 0; n < 4; ++n) x[n] = src[cj[n] < z.K ? cj[n] : z.K - 1];
@@ -237,6 +237,45 @@ __device__ __forceinline__ void lazy_cov_tile(const LazyCov &z, int star, const 
     }
   }
   __syncthreads();   // the scratch goes back to its owner
+}
+
+// One 16 x 16 block of a DIAGONAL tile of the system in the accumulator layout (rows ri[r], column cj), formed at
+// first touch (the planned step, LazyCov.dlazy): covariance entries + D / c1 on the diagonal (the row dd behind the
+// riding rows of LazyCov.rid), the riding rows themselves where the tile holds them, identity on the padding.  The
+// caller has the star's table in LDS (g) and every index < the padded size; loads are clamped to the light curve.
+template <typename V4>
+__device__ __forceinline__ void lazy_diag_block(const LazyCov &z, int star, const SplineGen &g, const sp_star &st,
+                                                int nobs, const int (&ri)[4], int cj, V4 &out) {
+  const double *th = z.theta + (size_t)star * z.K, *tt = z.t + (size_t)star * z.K;
+  const double *rb = z.rid + (size_t)star * (z.nrid + 1) * z.K;
+  const bool tk = z.temporal != SP_TEMPORAL_NONE;
+  const int cc = cj < z.K ? cj : z.K - 1;
+  const double thj = th[cc], tj = tk ? tt[cc] : 0.0;
+  double thi[4], ti[4], dd[4], rv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int rc = ri[r] < z.K ? ri[r] : z.K - 1;
+    thi[r] = th[rc];
+    ti[r] = tk ? tt[rc] : 0.0;
+    dd[r] = rb[(size_t)z.nrid * z.K + rc];
+    const int m = ri[r] - z.K;
+    rv[r] = rb[(size_t)((m >= 0 && m < z.nrid) ? m : 0) * z.K + cc];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = ri[r] - z.K;
+    double v;
+    if (ri[r] < nobs && cj < nobs) {
+#pragma clang fp contract(off)
+      v = g(thi[r], thj) * temporal_factor(z.temporal, ti[r], tj, st.tau);
+      if (ri[r] == cj) v += dd[r];
+    } else if (m >= 0 && m < z.nrid && cj < z.K) {
+      v = rv[r];
+    } else {
+      v = ri[r] == cj ? 1.0 : 0.0;
+    }
+    out[r] = v;
+  }
 }
 
 // the same for a lane that holds ONE row and four groups of four consecutive columns (the panel
@@ -350,7 +389,7 @@ __device__ __forceinline__ void lazy_cov_row(const LazyCov &z, int star, int ri,
     //  that hold them to their first touch too, LazyCov.rid; its sixteen columns' loads all issued before the first use)
     const int mr = ri - z.K;
     if (mr >= 0 && mr < z.nrid) {
-      const double *src = z.rid + ((size_t)star * z.nrid + mr) * z.K;
+      const double *src = z.rid + ((size_t)star * (z.nrid + 1) + mr) * z.K;
       double x[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {

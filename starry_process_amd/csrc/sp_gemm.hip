@@ -186,8 +186,21 @@ __global__ __launch_bounds__(256, SP_MM_WAVES) void mm_nt_kernel(
   // next trailing update all stay below the diagonal of a diagonal tile).  Same bits for the ten.
   if constexpr (SGN && Core::MA == 1 && Core::NA == 4 && TM == 64 && TN == 64) {
     if ((skip00 & 4) && lower_only && ti == tj) {
-      mm.prologue(lds, k_first, Kd);
+      // (the planned step: a diagonal tile of the FIRST trailing update is formed here, not loaded -- LazyCov.dlazy;
+      //  the star's table passes through the LDS stages before the product claims them, as for the tiles below)
+      const bool dform = beta && lz.theta && (lz.dlazy & 2);
       const int lane = threadIdx.x & 63;
+      sp_star dst{};
+      int dnobs = 0;
+      if (dform) {
+        dst = lz.stars[mtx];
+        dnobs = star_nobs(dst, lz.K);
+        spline_table_to_lds(lz.ptab + (size_t)mtx * 4 * (lz.covpts + 4), lds, lz.covpts + 4, threadIdx.x);
+        __syncthreads();
+      }
+      const SplineGen dg{lds, 2 * (lz.covpts + 4), 6.283185307179586 / lz.covpts, 1.0 / (6.283185307179586 / lz.covpts),
+                         lz.covpts};
+      if (!dform) mm.prologue(lds, k_first, Kd);
       auto run = [&](auto wtag) {
         constexpr int W = decltype(wtag)::value;
         using D = typename Core::template SymDeal<W>;
@@ -195,12 +208,21 @@ __global__ __launch_bounds__(256, SP_MM_WAVES) void mm_nt_kernel(
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
           mm_d4 c = mm_d4{0.0, 0.0, 0.0, 0.0};
-          if (b < D::NB && beta) {
+          if (b < D::NB && dform) {
+            int ri[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ri[r] = 64 * (lz.tr0 + ti) + 16 * D::brow(b) + (lane >> 4) + 4 * r;
+            lazy_diag_block(lz, mtx, dg, dst, dnobs, ri, 64 * (lz.tc0 + tj) + 16 * D::bcol(b) + (lane & 15), c);
+          } else if (b < D::NB && beta) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
               c[r] = Cb[(size_t)(16 * D::brow(b) + (lane >> 4) + 4 * r) * ldc + 16 * D::bcol(b) + (lane & 15)];
           }
           a3[b] = alpha < 0.0 ? -c : c;
+        }
+        if (dform) {
+          __syncthreads();                  // (every wavefront has read the table: the stages are the product's now)
+          mm.prologue(lds, k_first, Kd);
         }
         mm.template sym_loop<W>(lds, k_first, Kd, a3);
 #pragma unroll
@@ -478,6 +500,10 @@ static int syrk_symdiag() {
     g_syrk_symdiag = (e && atoi(e) == 0) ? 0 : 1;
   }
   return g_syrk_symdiag;
+}
+int sp_syrk_can_form_diag(int nb) {
+  const int big_from = syrk128_from();
+  return (syrk_symdiag() && !(big_from > 0 && nb >= big_from)) ? 1 : 0;
 }
 extern "C" int sp_debug_set_syrk_symdiag(int on) {
   g_syrk_symdiag = on < 0 ? -1 : (on ? 1 : 0);    // (-1: back to the environment / default)

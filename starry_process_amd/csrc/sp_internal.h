@@ -177,9 +177,17 @@ struct LazyCov {
   // row K + m of the star's system as the assembly would have written it (the residuals flux[m] - baseline_mean, the
   // row of ones, the variances / c1; zero beyond the star's cadences); rows from K + nrid on are zero left of the
   // diagonal.  One pointer and one count: the panel kernel's lazy instantiations have no scalar registers to spare.
-  const double *rid;       // [S][nrid][K]
+  // Behind a star's riding rows the block holds one more row: dd[col] = D_col / c1, what the DIAGONAL gets on top of
+  // the covariance (sp_reduce.h: B = Sigma + D / c1) -- for the kernels that form diagonal tiles (dlazy).
+  const double *rid;       // [S][nrid + 1][K]
   int nrid;
+  int dlazy;               // bit 1: the first trailing update forms its diagonal tiles (all but its tile (0, 0), which the
+                           // eager updates of the first super-panel keep in memory) instead of loading them
 };
+
+// does the symmetric trailing update of a remainder of nb 64-column blocks run on the 64 x 64 kernel whose diagonal
+// tiles can be formed at first touch (sp_gemm.hip: not the 128 x 64 tiles of large remainders, not with SP_SYRK_SYMDIAG=0)?
+int sp_syrk_can_form_diag(int nb);
 
 // Per-star normalisation coefficients: 8 doubles per star in the workspace (`coef`), written by
 // norm_coef_kernel (direct form) or defer_finish_kernel (deferred form) of sp_assemble.hip, read

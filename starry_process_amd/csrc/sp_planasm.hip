@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256, SP_PLAN_OCC) void assemble_planned_kernel(
     int order,
     double zmax, Coef *__restrict__ coef, double *__restrict__ rscal, double *__restrict__ ptab,
     int32_t *__restrict__ info, uint32_t *__restrict__ status, int lds_phases, double *__restrict__ img, long lts,
-    int fuse0, int S, int nchunk, double *__restrict__ rid, AsmChunks chunks) {
+    int fuse0, int S, int nchunk, double *__restrict__ rid, int dfrom, AsmChunks chunks) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   // Workgroup -> (star, chunk).  The hardware deals consecutive workgroups to the 8 XCDs in turn and, inside an XCD,
   // to its 32 CUs in turn (sp_panel.hip: XCD-local indices k, k + 32, ... share a CU).  A batch that 8 divides gives
@@ -193,20 +193,28 @@ __global__ __launch_bounds__(256, SP_PLAN_OCC) void assemble_planned_kernel(
     // rid[s][m][col]: the residuals, the row of ones, the variances / c1 -- for the kernels that form those tiles at
     // their first touch (LazyCov.rid).  A few K numbers per star, by the star's last workgroup (not the one that
     // factors pivot block 0).
+    // One more row behind them: dd[col] = D_col / c1, what the diagonal carries on top of the covariance -- for the
+    // kernels that form DIAGONAL tiles (LazyCov.dlazy).
     const int nrid = M + (diag ? 2 : 1);
-    double *dst = rid + (size_t)s * nrid * K;
-    for (int e = tid; e < nrid * K; e += 256) {
+    double *dst = rid + (size_t)s * (nrid + 1) * K;
+    for (int e = tid; e < (nrid + 1) * K; e += 256) {
       const int m = e / K, col = e - m * K;
       double val = 0.0;
       if (col < nobs) {
         if (m < M) val = flux[((size_t)s * M + m) * K + col] - st.baseline_mean;
         else if (m == M) val = 1.0;
-        else val = diag[(size_t)s * K + col] * inv_c1;
+        else {
+#pragma clang fp contract(off)
+          val = (diag ? diag[(size_t)s * K + col] : st.data_var) * inv_c1;     // (rows M + 1 with variances, and dd)
+        }
       }
       dst[e] = val;
     }
   }
   if (t0 >= t1) return;
+#ifdef P_PLAN_NOTILES
+  if (chunk != 0) return;                                      // (timing probe: only pivot block 0's workgroups work)
+#endif
   // strip-major tile order: strip tj holds the tiles ti = tj .. ntr - 1; of those only the WRITTEN ones are visited
   int tj = 0, ti;
   {
@@ -280,19 +288,25 @@ __global__ __launch_bounds__(256, SP_PLAN_OCC) void assemble_planned_kernel(
       }
     }
     double v[16];
-    {
-      double a[16], b[16];
+#ifndef SP_PLAN_BATCH
+#define SP_PLAN_BATCH 16     // entries per SplineGen::many batch (4, 8 or 16)
+#endif
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        a[k] = thi[k >> 2];
+    for (int p0 = 0; p0 < 4; p0 += SP_PLAN_BATCH / 4) {
+      double a[SP_PLAN_BATCH], b[SP_PLAN_BATCH], o[SP_PLAN_BATCH];
+#pragma unroll
+      for (int k = 0; k < SP_PLAN_BATCH; ++k) {
+        a[k] = thi[p0 + (k >> 2)];
         b[k] = thj[k & 3];
       }
 #ifdef P_PLAN_NOEVAL
 #pragma unroll
-      for (int k = 0; k < 16; ++k) v[k] = a[k] - b[k];        // (timing probe: results are garbage)
+      for (int k = 0; k < SP_PLAN_BATCH; ++k) o[k] = a[k] - b[k];        // (timing probe: results are garbage)
 #else
-      g.many<16>(a, b, v);
+      g.many<SP_PLAN_BATCH>(a, b, o);
 #endif
+#pragma unroll
+      for (int k = 0; k < SP_PLAN_BATCH; ++k) v[4 * p0 + k] = o[k];
     }
     if (nobs == 1) {
 #pragma unroll
@@ -315,9 +329,6 @@ __global__ __launch_bounds__(256, SP_PLAN_OCC) void assemble_planned_kernel(
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[4 * pass + e] *= temporal_factor(TK, tmi[pass], tmj[e], st.tau);
     }
-#ifdef P_PLAN_NOSTORE
-    if (v[3] == 1.2345e300)                                    // (timing probe: nothing is stored)
-#endif
     double w[16];
     if (i0 + 64 <= nobs && j0 + 64 <= nobs) {
       // a tile of valid cadences only: no masks
@@ -325,8 +336,14 @@ __global__ __launch_bounds__(256, SP_PLAN_OCC) void assemble_planned_kernel(
       for (int k = 0; k < 16; ++k) w[k] = v[k];
       if (ti == tj && ri == cl) {
         // the diagonal entries of the tile are this thread's (pass, pass): B = Sigma + D / c1
+        // (product rounded, then added -- no contraction: the kernels that form a diagonal tile at its first touch add
+        //  the same rounded D / c1, LazyCov.rid's last row, and a tile must carry the same bits either way)
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) w[5 * pass] += dvp[pass] * inv_c1;
+        for (int pass = 0; pass < 4; ++pass) {
+#pragma clang fp contract(off)
+          const double dc = dvp[pass] * inv_c1;
+          w[5 * pass] = w[5 * pass] + dc;
+        }
       }
     } else {
 #pragma unroll
@@ -337,8 +354,10 @@ __global__ __launch_bounds__(256, SP_PLAN_OCC) void assemble_planned_kernel(
           const int j = j0 + cl + 16 * e;
           double val = 0.0;
           if (i < nobs && j < nobs) {
+#pragma clang fp contract(off)
+            const double dc = dvp[pass] * inv_c1;
             val = v[4 * pass + e];
-            if (i == j) val += dvp[pass] * inv_c1;
+            if (i == j) val = val + dc;
           } else if (below && i >= K && i < K + M && j < nobs) {
             val = fl[4 * pass + e] - st.baseline_mean;      // (the GP mean of the normalised process is 0)
           } else if (i == K + M && j < nobs) {
@@ -369,6 +388,9 @@ __global__ __launch_bounds__(256, SP_PLAN_OCC) void assemble_planned_kernel(
       panel_diag_core(ob, ldo, 64, img + (size_t)s * lts + sp_img_off(0), info ? info + s : nullptr, lds, tid);
       return;
     }
+#ifdef P_PLAN_NOSTORE
+    if (w[3] == 1.2345e300)                                    // (timing probe: nothing is stored)
+#endif
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       double *dst = ob + (size_t)(i0 + ri + 16 * pass) * ldo + j0 + cl;
@@ -382,6 +404,12 @@ __global__ __launch_bounds__(256, SP_PLAN_OCC) void assemble_planned_kernel(
       tile += ntr - ti;
       ++tj;
       ti = tj;
+      // (diagonal tiles from dfrom on are formed by the first trailing update: strips that hold nothing else are skipped)
+      while (tj >= dfrom && tj >= ncolw && nfull >= ntr && tj < ntr) {
+        tile += ntr - tj;
+        ++tj;
+        ti = tj;
+      }
       if (tile < t1) load_cols(tj);
     } else {
       tile += nti - ti;
@@ -404,11 +432,13 @@ static void allow_big_lds(F f) {
 // a >= nfull or b < ncolw) cut into nchunk runs of equal cost.  start[c] = index of chunk c's first tile in the numbering of ALL
 // lower tiles.  No sums are taken in this kernel: the cut has no influence on any bit of the result.
 // fuse0: chunk 0 is tile (0, 0) alone (its workgroup goes on to factor pivot block 0).
-static AsmChunks plan_chunks(int ntr, int nfull, int ncolw, int nchunk, int fuse0) {
-  static thread_local int have_ntr = -1, have_nfull = -1, have_ncolw = -1, have_nchunk = -1, have_fuse0 = -1;
+static AsmChunks plan_chunks(int ntr, int nfull, int ncolw, int nchunk, int fuse0, int dfrom) {
+  static thread_local int have_ntr = -1, have_nfull = -1, have_ncolw = -1, have_nchunk = -1, have_fuse0 = -1, have_dfrom = -1;
   static thread_local AsmChunks have;
-  if (ntr == have_ntr && nfull == have_nfull && ncolw == have_ncolw && nchunk == have_nchunk && fuse0 == have_fuse0) return have;
-  const auto written = [&](int a, int b) { return a == b || a >= nfull || b < ncolw; };
+  if (ntr == have_ntr && nfull == have_nfull && ncolw == have_ncolw && nchunk == have_nchunk && fuse0 == have_fuse0 &&
+      dfrom == have_dfrom)
+    return have;
+  const auto written = [&](int a, int b) { return (a == b && a < dfrom) || a >= nfull || b < ncolw; };
   const auto weight = [&](int a, int b) { return a == ntr - 1 ? 20 : (a == b ? 11 : 10); };
   const bool own0 = fuse0 && nchunk >= 2;       // tile (0, 0) in a chunk of its own, the others over nchunk - 1
   const int nc = own0 ? nchunk - 1 : nchunk;
@@ -433,6 +463,7 @@ static AsmChunks plan_chunks(int ntr, int nfull, int ncolw, int nchunk, int fuse
   have_ncolw = ncolw;
   have_nchunk = nchunk;
   have_fuse0 = fuse0;
+  have_dfrom = dfrom;
   return c;
 }
 
@@ -447,7 +478,7 @@ int sp_launch_assemble_planned(int S, int K, int M, int Kp, const PlanDev &plan,
                                const sp_star *stars, int covpts, const double *tab, const double *meanvar,
                                int temporal, const double *flux, const double *diag, double *sys, int nfull,
                                int ncolw, int order, double zmax, void *coef, double *rscal, double *ptab, int32_t *info,
-                               uint32_t *status, hipStream_t st, double *img, long lts, int fuse0, double *rid) {
+                               uint32_t *status, hipStream_t st, double *img, long lts, int fuse0, double *rid, int dfrom) {
   const int ntr = Kp / 64, ntiles = ntr * (ntr + 1) / 2;
   if (ntiles > 65535 || !coef || !rscal || (fuse0 && (!img || K < 64))) return SP_ERR_INVALID;
   int lds_phases = 1;
@@ -459,7 +490,7 @@ int sp_launch_assemble_planned(int S, int K, int M, int Kp, const PlanDev &plan,
   }
   int nwritten = 0;
   for (int b = 0; b < ntr; ++b)
-    for (int a = b; a < ntr; ++a) nwritten += (a == b || a >= nfull || b < ncolw) ? 1 : 0;
+    for (int a = b; a < ntr; ++a) nwritten += ((a == b && a < dfrom) || a >= nfull || b < ncolw) ? 1 : 0;
   // Written tiles per workgroup: one round of two workgroups per CU where that leaves a workgroup at least three
   // tiles (cfg3: 16 diagonal tiles x 64 stars: 3 per workgroup, 0.755 ms per step one at a time against 0.762 with
   // 2 or 4), never more than 24 (cfg5's shape: 1 128 tiles per star, three
@@ -475,14 +506,17 @@ int sp_launch_assemble_planned(int S, int K, int M, int Kp, const PlanDev &plan,
   if (nchunk > SP_ASM_MAX_CHUNKS) nchunk = SP_ASM_MAX_CHUNKS;
   if (nchunk < 1) nchunk = 1;
   if (fuse0 && nchunk < 2) nchunk = 2;
-  const AsmChunks chunks = plan_chunks(ntr, nfull, ncolw, nchunk, fuse0);
+  // (dfrom < ntr: the diagonal tiles from dfrom on are left to the first trailing update -- only with every other
+  //  tile of their strips left to its first touch too)
+  if (dfrom < ntr && (nfull < ntr || !rid)) return SP_ERR_INVALID;
+  const AsmChunks chunks = plan_chunks(ntr, nfull, ncolw, nchunk, fuse0, dfrom);
   dim3 grid((unsigned)(nchunk * S));
 #define SP_ASMP(TK)                                                                                       \
   do {                                                                                                    \
     allow_big_lds(assemble_planned_kernel<TK>);                                                           \
     hipLaunchKernelGGL((assemble_planned_kernel<TK>), grid, dim3(256), lds, st, K, M, Kp, plan, t, stars, \
                        covpts, tab, meanvar, flux, diag, sys, (long)Kp, (long)Kp * Kp, ntr, nfull, ncolw, order, \
-                       zmax, (Coef *)coef, rscal, ptab, info, status, lds_phases, img, lts, fuse0, S, nchunk, rid, chunks); \
+                       zmax, (Coef *)coef, rscal, ptab, info, status, lds_phases, img, lts, fuse0, S, nchunk, rid, dfrom, chunks); \
   } while (0)
   if (temporal == SP_TEMPORAL_NONE) SP_ASMP(SP_TEMPORAL_NONE);
   else if (temporal == SP_TEMPORAL_MATERN32) SP_ASMP(SP_TEMPORAL_MATERN32);

@@ -1,6 +1,9 @@
 #!/bin/bash
 # Where the planned assembly's time goes: its average duration (one step at a time, rocprofv3 kernel trace) in the
 # shipped library and in probe variants (tools/ab_build.sh <name> -DP_PLAN_...; garbage results, timing only).
+# ONLY the probed kernel's own duration means anything: a probe leaves NaNs in the systems, and the factorisation of
+# matrices full of NaNs runs 5 % FASTER with steps in flight (less switching, higher clocks) -- an in-flight rate
+# measured with a probe build says nothing (round 5 fell for it once more: DESIGN.md 4.11).
 #   bash tools/plan_asm_probe.sh "" noeval nostore ...        (on the GPU box)
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT" || exit 1
