@@ -405,6 +405,13 @@ int sp_latitude_integrals(int ydeg, double alpha, double beta, double *q_host,
  * Golub-Welsch on the Jacobi matrix, so the zeroth moment that overflows in the textbook
  * normalisation never appears.  Host only, no handle.                                       */
 int sp_gauss_jacobi(int n, double a, double b, double *nodes_host, double *weights_host);
+/* The same rule with the derivatives of its nodes and weights with respect to a and b: the rule is exact for
+ * the polynomials it integrates whatever (a, b), so sum_k dw_k F(t_k) + w_k F'(t_k) dt_k is the exact derivative
+ * of the expectation -- the quadrature's counterpart of the analytic d/d alpha, d/d beta of the reference's
+ * latitude integrals (ops/include/latitude.h:21-173, tests/test_latitude.py:90-129).  Host only, no handle. */
+int sp_gauss_jacobi_grad(int n, double a, double b, double *nodes_host, double *weights_host,
+                         double *dnodes_da_host, double *dweights_da_host, double *dnodes_db_host,
+                         double *dweights_db_host);
 
 /* ---- upstream of the path, on the device ---------------------------
  * (mu_y [N], Sigma_y [N, N]) on the device from the host-side pieces of the hyperparameters, by
@@ -421,6 +428,20 @@ int sp_ylm_moments_quadrature(sp_handle *h, const double *vecs_host, int mv, int
                               const double *phi_host, const double *w_host, int P, int Q, double g,
                               double sqrt_n, double epsy, double epsy15, double *mean_dev,
                               double *cov_dev, void *stream);
+/* The same moments with their EXACT derivatives with respect to the spot radius and the Beta shape parameters
+ * (one radius: dr = None) -- what the reference differentiates analytically (ops/include/latitude.h:21-173 returns
+ * d/d alpha, d/d beta; size.py:92-101 through the graph): the tangents ride through the same rotations as three more
+ * rows per latitude, three cross products beside the value's (csrc/sp_upstream.hip).
+ *   s_host, ds_dr_host [N]       the size vector and its derivative with respect to r;
+ *   phi_host, w_host [P]         as above, the second half the mirror image of the first (-phi_k, the same w_k);
+ *   dphi_host, dw_host [2][P]    derivatives of the angles and weights with respect to alpha and beta
+ *                                (sp_gauss_jacobi_grad through x = cos(phi));
+ *   dmean_dev [3][N], dcov_dev [3][N][N]   d/dr, d/dalpha, d/dbeta of (mu_y, Sigma_y).                         */
+int sp_ylm_moments_quadrature_grad(sp_handle *h, const double *s_host, const double *ds_dr_host,
+                                   const double *phi_host, const double *w_host, const double *dphi_host,
+                                   const double *dw_host, int P, int Q, double g, double sqrt_n, double epsy,
+                                   double epsy15, double *mean_dev, double *cov_dev, double *dmean_dev,
+                                   double *dcov_dev, void *stream);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------ */
 /* Between begin and end every launch of the trailing-update kernel (the

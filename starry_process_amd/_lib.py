@@ -77,6 +77,7 @@ PROTOTYPES = {
     "sp_rTA1L": (_I, [_V, _V, _I, _V]),
     "sp_latitude_integrals": (_I, [_I, _D, _D, _V, _V]),
     "sp_gauss_jacobi": (_I, [_I, _D, _D, _V, _V]),
+    "sp_gauss_jacobi_grad": (_I, [_I, _D, _D, _V, _V, _V, _V, _V, _V]),
     "sp_allgather_lnlike": (_I, [_V, _V, _V, _I, _V, _V]),
     "sp_tensordotRz_rev": (_I, [_V, _V, _V, _I, _V, _V, _V, _V]),
     "sp_special_tensordotRz_rev": (_I, [_V, _V, _V, _V, _I, _V, _V, _V, _V]),
@@ -94,6 +95,8 @@ PROTOTYPES = {
     "sp_get_polar_moments": (_I, [_V, _V, _V]),
     "sp_ylm_moments_quadrature": (_I, [_V, _V, _I, _I, _V, _V, _I, _I, _D, _D, _D, _D,
                                        _V, _V, _V]),
+    "sp_ylm_moments_quadrature_grad": (_I, [_V, _V, _V, _V, _V, _V, _V, _I, _I, _D, _D, _D, _D,
+                                            _V, _V, _V, _V, _V]),
     "sp_debug_panel2_trace": (_I, [_V]),
     "sp_debug_panel2_chain": (_I, [_V]),
     "sp_debug_asm_chunks": (_I, [_I, _I, _V]),

@@ -576,3 +576,87 @@ extern "C" int sp_gauss_jacobi(int n, double a, double b, double *nodes, double 
   }
   return SP_OK;
 }
+
+
+// ---------------------------------------------------------------------------
+// The same rule WITH its derivatives with respect to the two exponents: what the reference gets from the
+// analytic d/d alpha, d/d beta of its latitude integrals (ops/include/latitude.h:21-173) the quadrature of
+// rotations gets from here -- an n-point rule is exact for the polynomials it integrates WHATEVER (a, b), so
+//   d/da sum_k w_k F(t_k)  =  sum_k dw_k/da F(t_k) + w_k F'(t_k) dt_k/da
+// is the exact derivative of the expectation.  First-order perturbation of the symmetric eigenproblem J = V L V^T:
+//   dt_i = v_i^T dJ v_i,      dv_i = sum_{j != i} v_j (v_j^T dJ v_i) / (t_i - t_j),      dw_i = 2 v_i[0] dv_i[0],
+// with the eigenvectors rebuilt from the nodes by the orthonormal three-term recurrence (v_i[k] = sqrt(w_i) p_k(t_i))
+// and dJ/da, dJ/db from the closed forms of the recurrence coefficients (carried as value + two derivatives).
+// ---------------------------------------------------------------------------
+namespace {
+struct D2 {          // value and its derivatives with respect to a and b
+  double v, a, b;
+};
+inline D2 operator+(D2 x, D2 y) { return {x.v + y.v, x.a + y.a, x.b + y.b}; }
+inline D2 operator-(D2 x, D2 y) { return {x.v - y.v, x.a - y.a, x.b - y.b}; }
+inline D2 operator*(D2 x, D2 y) { return {x.v * y.v, x.a * y.v + x.v * y.a, x.b * y.v + x.v * y.b}; }
+inline D2 operator/(D2 x, D2 y) {
+  const double q = x.v / y.v;
+  return {q, (x.a - q * y.a) / y.v, (x.b - q * y.b) / y.v};
+}
+inline D2 konst(double c) { return {c, 0.0, 0.0}; }
+inline D2 d2sqrt(D2 x) {
+  const double r = std::sqrt(x.v);
+  return {r, 0.5 * x.a / r, 0.5 * x.b / r};
+}
+}  // namespace
+
+extern "C" int sp_gauss_jacobi_grad(int n, double a, double b, double *nodes, double *weights,
+                                    double *dnodes_da, double *dweights_da, double *dnodes_db,
+                                    double *dweights_db) {
+  if (!dnodes_da || !dweights_da || !dnodes_db || !dweights_db) return SP_ERR_INVALID;
+  int rc = sp_gauss_jacobi(n, a, b, nodes, weights);
+  if (rc) return rc;
+  const D2 A{a, 1.0, 0.0}, B{b, 0.0, 1.0}, AB = A + B;
+  std::vector<D2> d(n), e(n > 1 ? n - 1 : 0);
+  d[0] = (B - A) / (AB + konst(2.0));
+  for (int k = 1; k < n; ++k) {
+    const D2 s = konst(2.0 * k) + AB, kk = konst((double)k);
+    d[k] = (B - A) * (B + A) / (s * (s + konst(2.0)));
+    const D2 num = (k == 1) ? konst(4.0) * (konst(1.0) + A) * (konst(1.0) + B) / (s * s * (s + konst(1.0)))
+                            : konst(4.0) * kk * (kk + A) * (kk + B) * (kk + AB) /
+                                  (s * s * (s + konst(1.0)) * (s - konst(1.0)));
+    e[k - 1] = d2sqrt(num);
+  }
+  // eigenvectors, column i = node i: forward recurrence, normalised
+  std::vector<double> V((size_t)n * n);
+  for (int i = 0; i < n; ++i) {
+    double *v = &V[(size_t)i * n];
+    const double x = nodes[i];
+    v[0] = 1.0;
+    if (n > 1) v[1] = (x - d[0].v) * v[0] / e[0].v;
+    for (int k = 1; k + 1 < n; ++k) v[k + 1] = ((x - d[k].v) * v[k] - e[k - 1].v * v[k - 1]) / e[k].v;
+    double nn = 0.0;
+    for (int k = 0; k < n; ++k) nn += v[k] * v[k];
+    nn = 1.0 / std::sqrt(nn);
+    for (int k = 0; k < n; ++k) v[k] *= nn;
+  }
+  for (int which = 0; which < 2; ++which) {
+    double *dt = which ? dnodes_db : dnodes_da, *dw = which ? dweights_db : dweights_da;
+    auto dd = [&](int k) { return which ? d[k].b : d[k].a; };
+    auto de = [&](int k) { return which ? e[k].b : e[k].a; };
+    auto form = [&](const double *vj, const double *vi) {      // v_j^T dJ v_i
+      double acc = 0.0;
+      for (int k = 0; k < n; ++k) acc += dd(k) * vj[k] * vi[k];
+      for (int k = 0; k + 1 < n; ++k) acc += de(k) * (vj[k] * vi[k + 1] + vj[k + 1] * vi[k]);
+      return acc;
+    };
+    for (int i = 0; i < n; ++i) {
+      const double *vi = &V[(size_t)i * n];
+      dt[i] = form(vi, vi);
+      double dv0 = 0.0;
+      for (int j = 0; j < n; ++j) {
+        if (j == i) continue;
+        const double *vj = &V[(size_t)j * n];
+        dv0 += vj[0] * form(vj, vi) / (nodes[i] - nodes[j]);
+      }
+      dw[i] = 2.0 * vi[0] * dv0;
+    }
+  }
+  return SP_OK;
+}

@@ -235,3 +235,231 @@ extern "C" int sp_ylm_moments_quadrature(sp_handle *h, const double *vecs_host, 
   SP_LAUNCH_CHECK();
   return SP_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------
+// The same moments WITH their exact derivatives with respect to the spot radius and the two Beta shape parameters
+// (one radius, dr = None): the tangents ride through the same rotations as extra rows.  With the rows
+//     A_kq = g sqrt(W_kq) Ry(lam_q) Rx(phi_k) s           (m1 = sum sqrt(W) A,   Sigma = sum A A^T - m1 m1^T + eps)
+// a parameter x in {r, alpha, beta} moves
+//     dA_kq = g sqrt(W) Ry Rx (ds/dx)  +  g (d sqrt(W)/dx) Ry Rx s  +  g sqrt(W) (d phi_k/dx) Ry Rx'(phi_k) s,
+// the first term for r (size.py:92-101: the sigmoid profile's own derivative), the other two for alpha and beta
+// (sp_gauss_jacobi_grad: the rule is exact whatever the exponents, so this IS the derivative of the expectation --
+// the reference's analytic d/d alpha, d/d beta, ops/include/latitude.h:21-173).  Everything behind Rx(phi_k) is
+// linear, so the four rows (A, dA_r, dA_alpha, dA_beta) of a latitude go through Rx(pi/2) Rz(lam) Rx(-pi/2)
+// together, and
+//     dm1 = sum sqrt(W) dA + (d sqrt(W)) A,       dSigma = sum (dA A^T + A dA^T) - dm1 m1^T - m1 dm1^T:
+// three cross products on the matrix cores beside the one of the value.
+namespace {
+constexpr int UPG = 4;     // rows per rotation: value, d/dr, d/dalpha, d/dbeta
+
+// V[k][tau][n] = sum_i (c0[k][tau] s[i] + c1[k][tau] ds[i]) R_k[i][n] + c2[k][tau] s[i] R'_k[i][n]
+// (row vector times the l-block of the rotation; the second half of the latitudes, -phi_k, takes the TRANSPOSED
+//  blocks of its partner: R(-phi) = R(phi)^T and d/dx R(-phi_k) = R'(phi_k)^T dphi_k/dx)
+__global__ __launch_bounds__(256) void up_tangent_rows_kernel(int N, int Ph, const int32_t *__restrict__ l_of,
+                                                              const int32_t *__restrict__ blk, int nwig,
+                                                              const double *__restrict__ coef /* [P][UPG][3] */,
+                                                              const double *__restrict__ sv /* [2][N]: s, ds/dr */,
+                                                              const double *__restrict__ Rpk, const double *__restrict__ dRpk,
+                                                              double *__restrict__ V) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x, tau = blockIdx.y, k = blockIdx.z;
+  if (n >= N) return;
+  const int l = l_of[n], w = 2 * l + 1, base = l * l;
+  const bool rt = k >= Ph;
+  const int kr = rt ? k - Ph : k;
+  const double *B = Rpk + (size_t)kr * nwig + blk[l] + (rt ? (n - base) * w : (n - base));
+  const double *dB = dRpk + (size_t)kr * nwig + blk[l] + (rt ? (n - base) * w : (n - base));
+  const int bs = rt ? 1 : w;
+  const double c0 = coef[((size_t)k * UPG + tau) * 3], c1 = coef[((size_t)k * UPG + tau) * 3 + 1],
+               c2 = coef[((size_t)k * UPG + tau) * 3 + 2];
+  double acc = 0.0;
+  for (int i = 0; i < w; ++i) {
+    const double s0 = sv[base + i], s1 = sv[N + base + i];
+    acc += (c0 * s0 + c1 * s1) * B[i * bs] + (c2 * s0) * dB[i * bs];
+  }
+  V[((size_t)k * UPG + tau) * N + n] = acc;
+}
+
+// part[q][tau][n] = sum_k sqw[k] A[(q P + k) UPG + tau][n] + dsqw[tau][k] A[(q P + k) UPG][n]      (dsqw[0] = 0)
+__global__ __launch_bounds__(256) void up_first_moment_grad_kernel(int N, int P, const double *__restrict__ sqw,
+                                                                   const double *__restrict__ dsqw /* [UPG][P] */,
+                                                                   const double *__restrict__ A,
+                                                                   double *__restrict__ part) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y, tau = blockIdx.z;
+  if (n >= N) return;
+  double acc = 0.0;
+  for (int k = 0; k < P; ++k) {
+    const double *row = A + ((size_t)(q * P + k) * UPG) * N + n;
+    acc += sqw[k] * row[(size_t)tau * N];
+    if (tau) acc += dsqw[(size_t)tau * P + k] * row[0];
+  }
+  part[((size_t)q * UPG + tau) * N + n] = acc;
+}
+__global__ __launch_bounds__(256) void up_first_moment_grad_sum_kernel(int N, int Q, const double *__restrict__ part,
+                                                                       double *__restrict__ m1 /* [UPG][N] */) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x, tau = blockIdx.y;
+  if (n >= N) return;
+  double acc = 0.0;
+  for (int q = 0; q < Q; ++q) acc += part[((size_t)q * UPG + tau) * N + n];
+  m1[(size_t)tau * N + n] = acc;
+}
+
+// value: cov = sum_c C0[c] - m1 m1^T + diag(eps), mean = sqrt(n) m1;
+// tangents: dcov_x = sum_c (C_x[c] + C_x[c]^T) - dm1 m1^T - m1 dm1^T, dmean_x = sqrt(n) dm1
+__global__ void up_finish_grad_kernel(int N, int nc, const double *__restrict__ parts /* [UPG][nc][N][N] */,
+                                      const double *__restrict__ m1 /* [UPG][N] */, double sqrt_n, double epsy,
+                                      double epsy15, double *__restrict__ cov, double *__restrict__ mean,
+                                      double *__restrict__ dcov /* [3][N][N] */, double *__restrict__ dmean /* [3][N] */) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int tau = blockIdx.y;
+  if (e >= (long)N * N) return;
+  const int i = (int)(e / N), j = (int)(e - (long)i * N);
+  const double *pt = parts + (size_t)tau * nc * N * N;
+  double acc = 0.0;
+  if (tau == 0) {
+    for (int c = 0; c < nc; ++c) acc += pt[(size_t)c * N * N + e];
+    double v = acc - m1[i] * m1[j];
+    if (i == j) v += i >= 15 * 15 ? epsy15 : epsy;
+    cov[e] = v;
+    if (j == 0) mean[i] = sqrt_n * m1[i];
+  } else {
+    const long et = (long)j * N + i;
+    for (int c = 0; c < nc; ++c) acc += pt[(size_t)c * N * N + e] + pt[(size_t)c * N * N + et];
+    const double *d1 = m1 + (size_t)tau * N;
+    // (symmetric to the bit: the two products in the order of the smaller index, whatever the compiler fuses)
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    dcov[(size_t)(tau - 1) * N * N + e] = acc - (d1[lo] * m1[hi] + m1[lo] * d1[hi]);
+    if (j == 0) dmean[(size_t)(tau - 1) * N + i] = sqrt_n * d1[i];
+  }
+}
+}  // namespace
+
+extern "C" int sp_ylm_moments_quadrature_grad(sp_handle *h, const double *s_host, const double *ds_dr_host,
+                                              const double *phi_host, const double *w_host,
+                                              const double *dphi_host, const double *dw_host, int P, int Q, double g,
+                                              double sqrt_n, double epsy, double epsy15, double *mean_dev,
+                                              double *cov_dev, double *dmean_dev, double *dcov_dev, void *stream) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || !s_host || !ds_dr_host || !phi_host || !w_host || !dphi_host || !dw_host || !mean_dev || !cov_dev ||
+      !dmean_dev || !dcov_dev || P < 2 || (P & 1) || Q < 1)
+    return SP_ERR_INVALID;
+  const int Ph = P / 2;
+  for (int k = 0; k < Ph; ++k)
+    if (phi_host[k + Ph] != -phi_host[k] || w_host[k + Ph] != w_host[k]) return SP_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const int N = h->N, NWIG = h->NWIG, nm = h->ydeg + 1;
+  const long R = (long)P * UPG, RR = (long)Q * R, R2 = (long)Q * P;
+  if (RR > 65535) return SP_ERR_INVALID;
+  const int KC = 128;
+  const int ld2 = (int)((R2 + KC - 1) / KC * KC), nchunk = ld2 / KC;
+  SP_HIP(hipSetDevice(h->device));
+  if (!h->d_Rxm90) {
+    SP_HIP(hipMalloc((void **)&h->d_Rxm90, sizeof(double) * NWIG));
+    const double th = -0.5 * M_PI;
+    int rc = sp_Rx(h, &th, 1, h->d_Rxm90, nullptr, stream);
+    if (rc) return rc;
+  }
+  if (h->lamcs_Q != Q) {
+    if (h->d_lamcs) {
+      SP_HIP(hipStreamSynchronize(st));
+      SP_HIP(hipFree(h->d_lamcs));
+      h->d_lamcs = nullptr;
+    }
+    std::vector<double> tab((size_t)Q * 2 * nm);
+    for (int q = 0; q < Q; ++q) {
+      const double lam = 2.0 * M_PI * q / Q;
+      for (int k = 0; k < nm; ++k) {
+        tab[(size_t)q * 2 * nm + k] = std::cos(k * lam);
+        tab[(size_t)q * 2 * nm + nm + k] = std::sin(k * lam);
+      }
+    }
+    SP_HIP(hipMalloc((void **)&h->d_lamcs, sizeof(double) * tab.size()));
+    SP_HIP(hipMemcpy(h->d_lamcs, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
+    h->lamcs_Q = Q;
+  }
+  // scratch: Rphi, dRphi [Ph, NWIG] | V, U [R, N] | U2, A [RR, N] | T [UPG][N, ld2] | m1 [UPG][N] | part | C [UPG][nchunk][N][N]
+  size_t off = 0;
+  auto take = [&](size_t doubles) { size_t o = off; off += up_align(sizeof(double) * doubles); return o; };
+  const size_t oR = take((size_t)Ph * NWIG), odR = take((size_t)Ph * NWIG), oV = take((size_t)R * N),
+               oU = take((size_t)R * N), oU2 = take((size_t)RR * N), oA = take((size_t)RR * N),
+               oT = take((size_t)UPG * N * ld2), om1 = take((size_t)UPG * N), opart = take((size_t)Q * UPG * N),
+               oC = take((size_t)UPG * nchunk * N * N);
+  void *ws = nullptr;
+  int rc = ensure_big_scratch(h, off, &ws);
+  if (rc) return rc;
+  auto at = [&](size_t o) { return reinterpret_cast<double *>(reinterpret_cast<char *>(ws) + o); };
+  double *Rphi = at(oR), *dRphi = at(odR), *V = at(oV), *U = at(oU), *U2 = at(oU2), *A = at(oA), *T = at(oT),
+         *m1 = at(om1), *part = at(opart), *Cp = at(oC);
+
+  // ONE staged upload: cos / sin of the Ph latitudes | coefficients [P][UPG][3] | sqrt weights [P] | their
+  // derivatives [UPG][P] | s, ds/dr [2][N]
+  sp_handle::CsSlot &c = h->cs_ring[h->cs_next];
+  h->cs_next = (h->cs_next + 1) & 3;
+  const size_t need = 2 * (size_t)Ph + (size_t)P * UPG * 3 + (size_t)P + (size_t)UPG * P + 2 * (size_t)N;
+  if (c.used) SP_HIP(hipEventSynchronize(c.done));
+  if (c.cap < need) {
+    if (c.host) SP_HIP(hipHostFree(c.host));
+    if (c.dev) SP_HIP(hipFree(c.dev));
+    c.host = c.dev = nullptr;
+    c.cap = 0;
+    SP_HIP(hipHostMalloc((void **)&c.host, sizeof(double) * need, hipHostMallocDefault));
+    SP_HIP(hipMalloc((void **)&c.dev, sizeof(double) * need));
+    c.cap = need;
+  }
+  if (!c.done) SP_HIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+  double *hcs = c.host, *hco = hcs + 2 * Ph, *hsq = hco + (size_t)P * UPG * 3, *hdsq = hsq + P, *hsv = hdsq + (size_t)UPG * P;
+  for (int k = 0; k < Ph; ++k) {
+    hcs[2 * k] = std::cos(phi_host[k]);
+    hcs[2 * k + 1] = std::sin(phi_host[k]);
+  }
+  for (int k = 0; k < P; ++k) {
+    const int kr = k < Ph ? k : k - Ph;
+    const double sq = std::sqrt(w_host[k] / Q);                 // sqrt(W_kq)
+    hsq[k] = sq;
+    hdsq[k] = hdsq[P + k] = 0.0;
+    double *co = hco + (size_t)k * UPG * 3;
+    co[0] = g * sq; co[1] = 0.0; co[2] = 0.0;                    // the value
+    co[3] = 0.0; co[4] = g * sq; co[5] = 0.0;                    // d/dr
+    for (int x = 0; x < 2; ++x) {                                // d/dalpha, d/dbeta
+      const double dsq = 0.5 * dw_host[(size_t)x * P + k] / (Q * sq);
+      hdsq[(size_t)(2 + x) * P + k] = dsq;
+      co[3 * (2 + x)] = g * dsq;
+      co[3 * (2 + x) + 1] = 0.0;
+      co[3 * (2 + x) + 2] = g * sq * dphi_host[(size_t)x * P + kr];   // (the partner's: see the kernel)
+    }
+  }
+  memcpy(hsv, s_host, sizeof(double) * N);
+  memcpy(hsv + N, ds_dr_host, sizeof(double) * N);
+  SP_HIP(hipMemcpyAsync(c.dev, c.host, sizeof(double) * need, hipMemcpyHostToDevice, st));
+  const double *dcs = c.dev, *dco = dcs + 2 * Ph, *dsq = dco + (size_t)P * UPG * 3, *ddsq = dsq + P,
+               *dsv = ddsq + (size_t)UPG * P;
+  if ((rc = sp_launch_Rx(h, dcs, Ph, Rphi, dRphi, st))) return rc;
+  hipLaunchKernelGGL(up_tangent_rows_kernel, dim3((N + 255) / 256, UPG, P), dim3(256), 0, st, N, Ph, h->d_l_of, h->d_blk,
+                     NWIG, dco, dsv, Rphi, dRphi, V);
+  SP_LAUNCH_CHECK();
+  if ((rc = sp_launch_dotRx(h, V, 0, N, 1, (int)R, h->d_Rx90, 0, U, 1, st))) return rc;
+  hipLaunchKernelGGL(up_rz_repeat_kernel, dim3((unsigned)RR), dim3(256), 0, st, N, (int)R, nm, h->d_m_of,
+                     h->d_mirror, h->d_lamcs, U, U2);
+  SP_LAUNCH_CHECK();
+  if ((rc = sp_launch_dotRx(h, U2, 0, N, 1, (int)RR, h->d_Rxm90, 0, A, 1, st))) return rc;
+  hipLaunchKernelGGL(up_first_moment_grad_kernel, dim3((N + 255) / 256, Q, UPG), dim3(256), 0, st, N, P, dsq, ddsq, A,
+                     part);
+  SP_LAUNCH_CHECK();
+  SP_HIP(hipEventRecord(c.done, st));
+  c.used = true;
+  hipLaunchKernelGGL(up_first_moment_grad_sum_kernel, dim3((N + 255) / 256, UPG), dim3(256), 0, st, N, Q, part, m1);
+  SP_LAUNCH_CHECK();
+  for (int tau = 0; tau < UPG; ++tau) {
+    hipLaunchKernelGGL(up_transpose_kernel, dim3(ld2 / 32, (N + 31) / 32), dim3(32, 8), 0, st, N, (int)R2, ld2, UPG,
+                       tau, 1, A, T + (size_t)tau * N * ld2);
+    SP_LAUNCH_CHECK();
+  }
+  for (int tau = 0; tau < UPG; ++tau)
+    if ((rc = sp_launch_gemm_nt(T + (size_t)tau * N * ld2, ld2, KC, T, ld2, KC, Cp + (size_t)tau * nchunk * N * N, N,
+                                (long)N * N, N, N, KC, 1.0, 0, 0, nchunk, st)))
+      return rc;
+  hipLaunchKernelGGL(up_finish_grad_kernel, dim3((unsigned)(((long)N * N + 255) / 256), UPG), dim3(256), 0, st, N,
+                     nchunk, Cp, m1, sqrt_n, epsy, epsy15, cov_dev, mean_dev, dcov_dev, dmean_dev);
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}

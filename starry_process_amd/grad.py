@@ -250,7 +250,8 @@ def log_likelihood_with_grad(mean_ylm, cov_ylm, t, flux, data_var, i=defaults["i
 
 
 def hyper_gradient(t, flux, data_var, r=defaults["r"], dr=defaults["dr"], a=defaults["a"], b=defaults["b"],
-                   c=defaults["c"], n=defaults["n"], h=1e-4, upstream_kwargs=None, moments0=None, **kwargs):
+                   c=defaults["c"], n=defaults["n"], h=1e-4, upstream_kwargs=None, moments0=None, exact=True,
+                   **kwargs):
     """(lnL, {"r": ., "a": ., "b": ., "c": ., "n": ., "p": ., ...}): the log-likelihood of one light curve and its
     gradient with respect to the spot hyperparameters (moments by the device quadrature, upstream_device.py;
     "dr" too when a spread of radii is given) and whatever else ``log_likelihood_with_grad`` differentiates
@@ -259,8 +260,11 @@ def hyper_gradient(t, flux, data_var, r=defaults["r"], dr=defaults["dr"], a=defa
     moments0: (mu_y, Sigma_y) the value and the moment gradient are taken at, when they are not the device
     quadrature's own (a process built with upstream="reference": same integrals, the reference's rounding);
     upstream_kwargs: the constructor's numerical keywords of the moment integrals (epsy, epsy15, sfac, ...).
-    a and b are differentiated by central differences of the moments, one-sided within a step of the bounds
-    [0, 1] (ops/exceptions.py:30-48 raises outside); c = 0 or n = 0 (no spots: Sigma_y = diag(eps), mu_y = 0)
+    r, a and b: with one radius (dr = None) the moments' EXACT tangents (the quadrature rule differentiated with
+    respect to its exponents, the sigmoid profile with respect to its radius: ylm_moments_device_grad -- what the
+    reference's analytic latitude derivatives are, ops/include/latitude.h:21-173); with a spread of radii, or
+    exact=False, central differences of the moments, one-sided within a step of the bounds [0, 1]
+    (ops/exceptions.py:30-48 raises outside); c = 0 or n = 0 (no spots: Sigma_y = diag(eps), mu_y = 0)
     has a zero gradient in the other of the two and is returned as such."""
     from .upstream_device import ylm_moments_device
 
@@ -295,6 +299,15 @@ def hyper_gradient(t, flux, data_var, r=defaults["r"], dr=defaults["dr"], a=defa
                     "n": float(gmu @ m1 + np.sum(gSig * S1)) if (n == 0 and c != 0) else 0.0})
     x0 = {"r": r, "dr": dr, "a": a, "b": b}
     bounds = {"r": (0.0, 90.0), "dr": (0.0, 90.0), "a": (0.0, 1.0), "b": (0.0, 1.0)}
+    if dr is None and exact:
+        # one radius: the moments' exact tangents (upstream_device.ylm_moments_device_grad)
+        from .upstream_device import ylm_moments_device_grad
+
+        _, _, dmu, dSig = ylm_moments_device_grad(e, r=r, a=a, b=b, c=c, n=n, **ukw)
+        dmu, dSig = dmu.cpu().numpy(), dSig.cpu().numpy()
+        for k, name in enumerate(("r", "a", "b")):
+            out[name] = float(gmu @ dmu[k] + np.sum(gSig * dSig[k]))
+        return lnl, out
     for name in ("r", "dr", "a", "b"):
         if x0[name] is None:
             continue
@@ -325,12 +338,16 @@ class EnsembleGradient(object):
     normalisation and the cubic interpolation to the adjoint of each star's kernel TABLE (304 numbers) and flux mean
     (sp_lnlike_grad_marginal).  The chain from the hyperparameters to the table is short and cheap -- moments by the
     device quadrature, then the table kernels -- and is differentiated there: exactly in c and n (the moments are
-    mu_y = c n m, Sigma_y = c^2 n S + eps, contrast.py:21-33, and the table is linear in Sigma_y + mu_y mu_y^T), by
-    central differences of the table in r, a, b (and dr), evaluated on three more streams while the sweep runs."""
+    mu_y = c n m, Sigma_y = c^2 n S + eps, contrast.py:21-33, and the table is linear in Sigma_y + mu_y mu_y^T), and
+    since round 5 exactly in r, a, b too: the moments come with their tangents (ylm_moments_device_grad: the
+    quadrature rule differentiated with respect to its exponents -- the reference's analytic latitude derivatives,
+    ops/include/latitude.h:21-173), and one table evaluation per parameter turns a tangent of the moments into the
+    tangent of the table, on two more streams while the sweep runs.  With a spread of radii (dr) or exact=False:
+    central differences of the table (step h), as in round 4."""
 
     def __init__(self, t, flux, ferr=1.0e-3, p=1.0, u=None, ydeg=15, baseline_var=0.0, baseline_mean=0.0,
                  normalized=True, covpts=None, tau=None, temporal_kernel="matern32", device=None, h=1.0e-4,
-                 upstream_kwargs=None):
+                 upstream_kwargs=None, exact=True):
         import torch
 
         from .engine import engine_slots, make_stars
@@ -371,6 +388,7 @@ class EnsembleGradient(object):
         self._covpts = int(defaults["covpts"] if covpts is None else covpts)
         self._temporal = (temporal_kernel if isinstance(temporal_kernel, str) else kernel_id(temporal_kernel)) if tau else None
         self._normalized, self._h, self._ukw = bool(normalized), float(h), dict(upstream_kwargs or {})
+        self._exact = bool(exact)
         self._ws = e.grad_workspace(S, K, self._covpts)
         self.lnlike = None
         torch.cuda.synchronize(e.device)
@@ -391,9 +409,19 @@ class EnsembleGradient(object):
         x0 = {"r": float(r), "dr": dr, "a": float(a), "b": float(b)}
         hp0 = dict(x0, c=float(c), n=float(n))
         torch.cuda.synchronize(e.device)
+        exact = self._exact and dr is None
         # main stream: the tables at the point, then the sweep
         with torch.cuda.stream(self._stream):
-            yp0, mean0, (mu, Sig, tab, mv) = self._tables(e, **hp0)
+            if exact:
+                from .upstream_device import ylm_moments_device_grad
+
+                mu, Sig, dmu, dSig = ylm_moments_device_grad(e, r=float(r), a=float(a), b=float(b), c=float(c),
+                                                             n=float(n), **self._ukw)
+                e.set_moments_dev(mu, Sig)
+                tab, mv = e.kernel_table(self._rta1, self._covpts)
+                yp0, mean0 = tab[:, 0, :], mv[:, 0]
+            else:
+                yp0, mean0, (mu, Sig, tab, mv) = self._tables(e, **hp0)
             at_point = torch.cuda.Event()
             at_point.record(self._stream)
             lnl, ybar, mbar, status = e.lnlike_grad_marginal(
@@ -412,16 +440,37 @@ class EnsembleGradient(object):
             yh, mh, _ = self._tables(eng, **dict(hp0, **{name: xh}))
             dy[name], dm[name] = (yh - yl) / (xh - xl), (mh - ml) / (xh - xl)
 
+        def tangent(eng, k, name):
+            # The table is linear in Sigma_y + mu_y mu_y^T and its mean in mu_y (flux.py:297-320): with the moments
+            # (dmu, X - dmu dmu^T), X = dSigma + dmu mu^T + mu dmu^T, the table kernels return f[X] - dmean^2 and
+            # dmean, and d yp = f[X] - 2 mean dmean.  One table evaluation per parameter, no step size.
+            d1 = dmu[k]
+            cross = torch.outer(d1, mu)
+            eng.set_moments_dev(d1, dSig[k] + cross + cross.t() - torch.outer(d1, d1))
+            tk, mk = eng.kernel_table(self._rta1, self._covpts)
+            dmean = mk[:, 0]
+            dy[name] = tk[:, 0, :] + (dmean * (dmean - 2.0 * mean0))[:, None]
+            dm[name] = dmean
+
         (e1, s1), (e2, s2), (e3, s3) = self._side
         with torch.cuda.stream(s1):
-            central(e1, "r")
-            if x0["dr"] is not None:
-                central(e1, "dr")
+            if exact:
+                s1.wait_event(at_point)
+                tangent(e1, 0, "r")
+                tangent(e1, 1, "a")
+            else:
+                central(e1, "r")
+                if x0["dr"] is not None:
+                    central(e1, "dr")
             events.append(torch.cuda.Event())
             events[-1].record(s1)
         with torch.cuda.stream(s2):
-            central(e2, "a")
-            central(e2, "b")
+            if exact:
+                s2.wait_event(at_point)
+                tangent(e2, 2, "b")
+            else:
+                central(e2, "a")
+                central(e2, "b")
             events.append(torch.cuda.Event())
             events[-1].record(s2)
         with torch.cuda.stream(s3):

@@ -70,6 +70,12 @@ def size_moments(r_deg, dr_deg, ydeg, sfac=300, cutoff=1.5, **kw):
         b = 1 / (1 + np.exp(-sfac * (theta - r))) - 1
         q = np.zeros(N)
         q[idx] = Bp @ b
+        if kw.get("deriv"):
+            # d/dr [degrees] of the sigmoid profile (size.py:92-101), for the exact gradient (upstream_device.py)
+            sg = b + 1.0
+            dq = np.zeros(N)
+            dq[idx] = Bp @ (-sfac * sg * (1.0 - sg)) * _ANG
+            return q, dq
         return q, q.reshape(-1, 1)
     dr = CheckBoundsOp(name="dr", lower=0, upper=0.5 * np.pi)(dr_deg * _ANG)
     with np.errstate(over="ignore", invalid="ignore", divide="ignore"):

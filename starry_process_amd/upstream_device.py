@@ -38,7 +38,7 @@ from .defaults import defaults
 from .ops import CheckBoundsOp
 from .upstream import ab_to_alphabeta, size_moments
 
-__all__ = ["ylm_moments_device", "quadrature_nodes"]
+__all__ = ["ylm_moments_device", "ylm_moments_device_grad", "quadrature_nodes", "quadrature_nodes_grad"]
 
 
 def gauss_jacobi(n, a, b):
@@ -80,6 +80,68 @@ def _quadrature_nodes(ydeg, alpha, beta):
     nl = 2 * ydeg + 3
     return (np.concatenate([phi, -phi]), 0.5 * np.concatenate([w, w]),
             2.0 * np.pi * np.arange(nl) / nl)
+
+
+def gauss_jacobi_grad(n, a, b):
+    """(nodes, weights, d nodes/da, d weights/da, d nodes/db, d weights/db) of the same rule: sp_gauss_jacobi_grad."""
+    out = [np.empty(n) for _ in range(6)]
+    _lib.check(_lib.lib().sp_gauss_jacobi_grad(int(n), float(a), float(b), *[_lib.hptr(x) for x in out]))
+    return out
+
+
+def quadrature_nodes_grad(ydeg, alpha, beta):
+    """(phi [P], w_phi [P], dphi [2, P], dw [2, P], lam [Q]): the nodes of ``quadrature_nodes`` with the derivatives
+    of the latitude angles and weights with respect to (alpha, beta)."""
+    # weight (1 - t)^(beta-1) (1 + t)^(alpha-1): the rule's first exponent is beta's, its second alpha's
+    t, w, t_b, w_b, t_a, w_a = gauss_jacobi_grad(ydeg + 2, beta - 1.0, alpha - 1.0)
+    x = 0.5 * (1.0 + t)
+    phi = np.arccos(x)
+    # phi = arccos((1 + t) / 2):  dphi = -dt / (2 sin(phi))
+    sn = np.sqrt((1.0 - x) * (1.0 + x))
+    dphi = np.stack([-0.5 * t_a / sn, -0.5 * t_b / sn])
+    dw = 0.5 * np.stack([w_a, w_b])
+    nl = 2 * ydeg + 3
+    return (np.concatenate([phi, -phi]), 0.5 * np.concatenate([w, w]), np.concatenate([dphi, -dphi], axis=1),
+            np.concatenate([dw, dw], axis=1), 2.0 * np.pi * np.arange(nl) / nl)
+
+
+def ylm_moments_device_grad(engine, r=defaults["r"], a=defaults["a"], b=defaults["b"], c=defaults["c"],
+                            n=defaults["n"], **kwargs):
+    """(mu_y [N], Sigma_y [N, N], dmu [3, N], dSigma [3, N, N]): the moments of ``ylm_moments_device`` (one radius,
+    dr = None) and their EXACT derivatives with respect to (r [degrees], a, b), as device tensors -- one library
+    call, sp_ylm_moments_quadrature_grad (csrc/sp_upstream.hip): the tangents ride through the same rotations.
+    The reference differentiates the same integrals analytically (ops/include/latitude.h:21-173 returns d/d alpha,
+    d/d beta; tests/test_latitude.py:90-129 checks them).  The derivatives with respect to c and n are closed forms
+    of the moments themselves (mu ~ c n, Sigma - eps ~ c^2 n: contrast.py:21-33)."""
+    from ._lib import check, hptr
+
+    e = engine
+    ydeg, N = e.ydeg, e.N
+    n = CheckBoundsOp(name="n", lower=0, upper=np.inf)(n)
+    skw = {k: kwargs[k] for k in ("spts", "eps4", "smoothing", "sfac", "cutoff") if k in kwargs}
+    s, ds = size_moments(r, None, ydeg, deriv=True, **skw)
+    alpha, beta = ab_to_alphabeta(a, b, **kwargs)
+    # alpha = exp(a log_alpha_max), beta = exp(log(1/2) + b (log_beta_max - log(1/2))) (latitude.py:176-197);
+    # below abmin the parameter is clamped: no dependence
+    abmin = kwargs.get("abmin", defaults["abmin"])
+    lam_a = kwargs.get("log_alpha_max", defaults["log_alpha_max"])
+    lam_b = kwargs.get("log_beta_max", defaults["log_beta_max"]) - np.log(0.5)
+    da = lam_a * alpha if a >= abmin else 0.0
+    db = lam_b * beta if b >= abmin else 0.0
+    phi, wphi, dphi, dw, lam = quadrature_nodes_grad(ydeg, alpha, beta)
+    P, Q = phi.shape[0], lam.shape[0]
+    mean, cov, dmean, dcov = e.empty(N), e.empty(N, N), e.empty(3, N), e.empty(3, N, N)
+    arrs = [np.ascontiguousarray(x, dtype=np.float64) for x in (s, ds, phi, wphi, dphi, dw)]
+    check(e._L.sp_ylm_moments_quadrature_grad(
+        e._h, *[hptr(x) for x in arrs], int(P), int(Q), float(np.pi * float(c) * np.sqrt(float(n))),
+        float(np.sqrt(float(n))), float(kwargs.get("epsy", defaults["epsy"])),
+        float(kwargs.get("epsy15", defaults["epsy15"])), e._p(mean), e._p(cov), e._p(dmean), e._p(dcov), e._stream()))
+    # (alpha, beta) -> (a, b)
+    dmean[1] *= da
+    dcov[1] *= da
+    dmean[2] *= db
+    dcov[2] *= db
+    return mean, cov, dmean, dcov
 
 
 def ylm_moments_device(engine, r=defaults["r"], dr=defaults["dr"], a=defaults["a"],

@@ -407,3 +407,28 @@ def test_gradient_sweep_refuses_ragged_stars_loudly():
     lg, lb = good[0].cpu().numpy(), bad[0].cpu().numpy()
     assert np.isnan(lb[1]) and (bad[3].cpu().numpy()[1] & 4)
     assert lb[0] == lg[0] and lb[2] == lg[2] and not good[3].cpu().numpy().any()
+
+
+def test_exact_upstream_derivatives_against_the_differenced_tables():
+    """r, a, b through the EXACT tangents of the moments (the default since round 5) against round 4's central
+    differences of the kernel table (exact=False): the same gradient to the differences' O(h^2), for the ensemble
+    sweep and for the one-star chain; c and n do not change."""
+    from starry_process_amd.grad import EnsembleGradient, hyper_gradient
+
+    S, K = 4, 150
+    t, flux, p, sts = _ensemble(S, K, seed0=3)
+    for hp in (dict(r=20.0, a=0.40, b=0.27, c=0.10, n=10.0), dict(r=12.0, a=0.8, b=0.6, c=0.2, n=3.0)):
+        tot_e, g_e = EnsembleGradient(t, flux, ferr=1e-3, p=p)(**hp)
+        tot_f, g_f = EnsembleGradient(t, flux, ferr=1e-3, p=p, exact=False)(**hp)
+        assert abs(tot_e - tot_f) < 1e-11 * abs(tot_f)
+        scale = max(abs(v) for v in g_f.values())
+        for k in ("r", "a", "b"):
+            assert abs(g_e[k] - g_f[k]) < 3e-6 * max(abs(g_f[k]), 1e-3 * scale), (k, g_e[k], g_f[k])
+        for k in ("c", "n"):
+            assert abs(g_e[k] - g_f[k]) < 1e-10 * max(abs(g_f[k]), 1e-3 * scale), (k, g_e[k], g_f[k])
+        l_e, h_e = hyper_gradient(t[0], flux[0], 1e-6, p=float(p[0]), **hp)
+        l_f, h_f = hyper_gradient(t[0], flux[0], 1e-6, p=float(p[0]), exact=False, **hp)
+        assert abs(l_e - l_f) < 1e-11 * abs(l_f)
+        scale = max(abs(v) for v in h_f.values())
+        for k in ("r", "a", "b"):
+            assert abs(h_e[k] - h_f[k]) < 3e-6 * max(abs(h_f[k]), 1e-3 * scale), (k, h_e[k], h_f[k])

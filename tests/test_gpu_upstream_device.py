@@ -267,3 +267,41 @@ def test_ensemble_log_prob_is_finite_at_high_b():
         got = many(samples[:4])
     assert np.all(np.isfinite(got)) and np.all(np.isfinite(ref))
     assert np.abs(got - ref).max() < 1e-8 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("L,hp", [(15, dict(r=20.0, a=0.40, b=0.27, c=0.1, n=10.0)),
+                                  (15, dict(r=12.0, a=0.85, b=0.60, c=0.2, n=3.0)),
+                                  (15, dict(r=30.0, a=0.05, b=0.95, c=0.05, n=20.0)),
+                                  (20, dict(r=15.0, a=0.62, b=0.11, c=0.2, n=5.0)),
+                                  (5, dict(r=25.0, a=0.3, b=0.5, c=0.1, n=1.0))])
+def test_exact_tangents_of_the_moments(L, hp):
+    """ylm_moments_device_grad: the value is ylm_moments_device's, and d(mu_y, Sigma_y)/d(r, a, b) -- the tangents
+    that ride through the rotations, with the quadrature rule differentiated with respect to its exponents -- agree
+    with Richardson-extrapolated central differences of the device moments to the differences' own noise.  The
+    reference has these derivatives analytically (ops/include/latitude.h:21-173, tests/test_latitude.py:90-129)."""
+    from starry_process_amd.engine import get_engine
+    from starry_process_amd.upstream_device import ylm_moments_device, ylm_moments_device_grad
+
+    e = get_engine(L, 2)
+    mu, Sig, dmu, dSig = [x.cpu().numpy() for x in ylm_moments_device_grad(e, **hp)]
+    m0, S0 = [x.cpu().numpy() for x in ylm_moments_device(e, **hp)]
+    assert np.abs(mu - m0).max() <= 1e-14 * np.abs(m0).max()
+    assert np.abs(Sig - S0).max() <= 1e-14 * np.abs(S0).max()
+    for k, (name, h) in enumerate((("r", 2e-2), ("a", 2e-3), ("b", 2e-3))):
+        def at(d):
+            q = dict(hp)
+            q[name] = hp[name] + d
+            return [x.cpu().numpy() for x in ylm_moments_device(e, **q)]
+
+        def central(step):
+            (m1, S1), (m2, S2) = at(step), at(-step)
+            return (m1 - m2) / (2 * step), (S1 - S2) / (2 * step)
+
+        (ma, Sa), (mb, Sb) = central(h), central(h / 2)
+        fm, fS = (4 * mb - ma) / 3, (4 * Sb - Sa) / 3
+        # (the differences carry the moments' rounding divided by the step: 1e-14 max|.| / h -- what decides where the
+        #  derivative is small, a = 0.05 in the third case)
+        em, eS = np.abs(dmu[k] - fm).max(), np.abs(dSig[k] - fS).max()
+        assert em < 1e-7 * np.abs(fm).max() + 1e-14 * np.abs(m0).max() / h, (name, em, np.abs(fm).max())
+        assert eS < 1e-7 * np.abs(fS).max() + 1e-14 * np.abs(S0).max() / h, (name, eS, np.abs(fS).max())
+        assert np.array_equal(dSig[k], dSig[k].T)

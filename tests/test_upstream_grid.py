@@ -165,3 +165,48 @@ def test_assembly_chunks_partition_the_tiles_by_cost():
     bad = np.zeros(4, dtype=np.int32)
     assert L.sp_debug_asm_chunks(0, 1, _lib.hptr(bad)) != 0
     assert L.sp_debug_asm_chunks(16, 600, _lib.hptr(bad)) != 0
+
+
+def _gj_mp(n, a, b):
+    """The rule at 60 digits: eigen-decomposition of the Jacobi matrix in mpmath."""
+    import mpmath as mp
+
+    a, b = mp.mpf(a), mp.mpf(b)
+    J, ab = mp.zeros(n, n), a + b
+    J[0, 0] = (b - a) / (ab + 2)
+    for k in range(1, n):
+        s = 2 * k + ab
+        J[k, k] = (b - a) * (b + a) / (s * (s + 2))
+        num = 4 * (1 + a) * (1 + b) / (s * s * (s + 1)) if k == 1 else \
+            4 * k * (k + a) * (k + b) * (k + ab) / (s * s * (s + 1) * (s - 1))
+        J[k - 1, k] = J[k, k - 1] = mp.sqrt(num)
+    E, Q = mp.eigsy(J)
+    idx = sorted(range(n), key=lambda i: E[i])
+    return [E[i] for i in idx], [Q[0, i] ** 2 for i in idx]
+
+
+@pytest.mark.parametrize("a,b", [(0.4, 0.27), (0.0, 0.0), (1.0, 1.0), (0.5, 0.9), (0.0, 1.0), (1.0, 0.0)])
+def test_gauss_jacobi_derivatives_against_60_digit_differences(a, b):
+    """sp_gauss_jacobi_grad (first-order perturbation of the Jacobi matrix's eigenproblem) against central
+    differences of the rule evaluated at 60 digits (step 1e-20: no rounding, no truncation to speak of), at the
+    default and at the corners of the prior box.  These derivatives are what makes the device upstream's gradient
+    exact (the reference: analytic d/d alpha, d/d beta, ops/include/latitude.h:21-173)."""
+    mp = pytest.importorskip("mpmath")
+    from starry_process_amd.upstream_device import gauss_jacobi_grad
+
+    mp.mp.dps = 60
+    alpha, beta = upstream.ab_to_alphabeta(a, b)
+    n, h = 17, mp.mpf(10) ** -20
+    t, w, t_a, w_a, t_b, w_b = gauss_jacobi_grad(n, beta - 1.0, alpha - 1.0)
+    t0, w0 = gauss_jacobi(n, beta - 1.0, alpha - 1.0)
+    assert np.array_equal(t, t0) and np.array_equal(w, w0)
+    for dw in (w_a, w_b):                       # the weights keep summing to 1
+        assert abs(dw.sum()) < 1e-10 * np.abs(dw).max() + 1e-15
+    ja, jb = mp.mpf(beta) - 1, mp.mpf(alpha) - 1
+    for which, (dt, dw) in enumerate(((t_a, w_a), (t_b, w_b))):
+        hi = _gj_mp(n, ja + h, jb) if which == 0 else _gj_mp(n, ja, jb + h)
+        lo = _gj_mp(n, ja - h, jb) if which == 0 else _gj_mp(n, ja, jb - h)
+        ft = np.array([float((x - y) / (2 * h)) for x, y in zip(hi[0], lo[0])])
+        fw = np.array([float((x - y) / (2 * h)) for x, y in zip(hi[1], lo[1])])
+        assert np.abs(dt - ft).max() < 1e-9 * np.abs(ft).max(), (which, np.abs(dt - ft).max() / np.abs(ft).max())
+        assert np.abs(dw - fw).max() < 1e-6 * np.abs(fw).max(), (which, np.abs(dw - fw).max() / np.abs(fw).max())
