@@ -412,16 +412,7 @@ class EnsembleGradient(object):
         exact = self._exact and dr is None
         # main stream: the tables at the point, then the sweep
         with torch.cuda.stream(self._stream):
-            if exact:
-                from .upstream_device import ylm_moments_device_grad
-
-                mu, Sig, dmu, dSig = ylm_moments_device_grad(e, r=float(r), a=float(a), b=float(b), c=float(c),
-                                                             n=float(n), **self._ukw)
-                e.set_moments_dev(mu, Sig)
-                tab, mv = e.kernel_table(self._rta1, self._covpts)
-                yp0, mean0 = tab[:, 0, :], mv[:, 0]
-            else:
-                yp0, mean0, (mu, Sig, tab, mv) = self._tables(e, **hp0)
+            yp0, mean0, (mu, Sig, tab, mv) = self._tables(e, **hp0)
             at_point = torch.cuda.Event()
             at_point.record(self._stream)
             lnl, ybar, mbar, status = e.lnlike_grad_marginal(
@@ -440,24 +431,33 @@ class EnsembleGradient(object):
             yh, mh, _ = self._tables(eng, **dict(hp0, **{name: xh}))
             dy[name], dm[name] = (yh - yl) / (xh - xl), (mh - ml) / (xh - xl)
 
-        def tangent(eng, k, name):
+        def tangent(eng, stream, tang, k, name):
             # The table is linear in Sigma_y + mu_y mu_y^T and its mean in mu_y (flux.py:297-320): with the moments
             # (dmu, X - dmu dmu^T), X = dSigma + dmu mu^T + mu dmu^T, the table kernels return f[X] - dmean^2 and
             # dmean, and d yp = f[X] - 2 mean dmean.  One table evaluation per parameter, no step size.
+            mu1, dmu, dSig = tang
             d1 = dmu[k]
-            cross = torch.outer(d1, mu)
+            cross = torch.outer(d1, mu1)
             eng.set_moments_dev(d1, dSig[k] + cross + cross.t() - torch.outer(d1, d1))
             tk, mk = eng.kernel_table(self._rta1, self._covpts)
             dmean = mk[:, 0]
+            stream.wait_event(at_point)         # (mean0 is the main stream's; recorded before the sweep was enqueued)
             dy[name] = tk[:, 0, :] + (dmean * (dmean - 2.0 * mean0))[:, None]
             dm[name] = dmean
 
         (e1, s1), (e2, s2), (e3, s3) = self._side
         with torch.cuda.stream(s1):
             if exact:
-                s1.wait_event(at_point)
-                tangent(e1, 0, "r")
-                tangent(e1, 1, "a")
+                # the moments again, with their tangents, beside the main stream (which only waits for the value)
+                from .upstream_device import ylm_moments_device_grad
+
+                mu1, _, dmu, dSig = ylm_moments_device_grad(e1, r=float(r), a=float(a), b=float(b), c=float(c),
+                                                            n=float(n), **self._ukw)
+                tang = (mu1, dmu, dSig)
+                have_tangents = torch.cuda.Event()
+                have_tangents.record(s1)
+                tangent(e1, s1, tang, 0, "r")
+                tangent(e1, s1, tang, 1, "a")
             else:
                 central(e1, "r")
                 if x0["dr"] is not None:
@@ -466,8 +466,8 @@ class EnsembleGradient(object):
             events[-1].record(s1)
         with torch.cuda.stream(s2):
             if exact:
-                s2.wait_event(at_point)
-                tangent(e2, 2, "b")
+                s2.wait_event(have_tangents)
+                tangent(e2, s2, tang, 2, "b")
             else:
                 central(e2, "a")
                 central(e2, "b")

@@ -65,7 +65,18 @@ print("forward step (moments -> table -> lnL of %d stars), one at a time:   %.3f
 print("ensemble gradient, device sweep alone (C, C^-1, adjoints):           %.3f ms  = %.2f x forward; "
       "%.1f TFLOP/s of the 3.5 K^3/3 flops of factor + triangular inverse + L^-T L^-1" %
       (ms_sweep, ms_sweep / ms_fwd, 3.5 * fl / (ms_sweep * 1e-3) / 1e12))
-print("ensemble gradient, whole call (tables, nine table evaluations on three more streams, sweep): %.3f ms = %.2f x forward"
-      % (ms_grad, ms_grad / ms_fwd))
+print("ensemble gradient, whole call (moments with their exact tangents, 3 + 2 table evaluations on three more streams, "
+      "sweep): %.3f ms = %.2f x forward" % (ms_grad, ms_grad / ms_fwd))
+eg_fd = EnsembleGradient(t, flux, ferr=1e-3, p=p, exact=False)
+for _ in range(3):
+    eg_fd()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for k in range(n):
+    total_fd, g_fd = eg_fd(r=20.0 + 0.01 * k)
+torch.cuda.synchronize()
+ms_fd = 1e3 * (time.perf_counter() - t0) / n
+print("   ... with round 4's central differences of the table in r, a, b (exact=False: nine table evaluations): %.3f ms; "
+      "largest relative difference of the two gradients %.1e" % (ms_fd, max(abs(g[k] - g_fd[k]) / abs(g_fd[k]) for k in g)))
 print("round 3: hyper_gradient, ONE star per call:                          %.3f ms  (x %d stars = %.0f ms)" % (ms_one, S, ms_one * S))
 print("gradient:", {k: float("%.6g" % v) for k, v in g.items()}, " lnL = %.6f" % total)
