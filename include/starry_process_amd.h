@@ -351,6 +351,16 @@ int sp_lnlike_grad_marginal(sp_handle *h, int S, int K, const double *t_dev, con
                             const double *meanvar_dev, int temporal, int normalized, int norm_order, double zmax,
                             void *workspace_dev, double *lnlike_dev, double *ybar_dev, double *meanbar_dev,
                             uint32_t *status_dev, void *stream);
+/* The same for M light curves per star on ONE covariance (flux_dev [S, M, K]; the shared-covariance multi-RHS form of
+ * sp.py:1162-1171, what calibrate.get_log_prob evaluates: calibrate/log_prob.py:7-106):
+ *   lnL_s = sum_m -1/2 r_m^T C^-1 r_m - M/2 log det C - M K/2 log 2 pi,   d lnL / dC = (sum_m alpha_m alpha_m^T - M C^-1) / 2.
+ * One factorisation and one inverse per star whatever M; workspace: sp_lnlike_grad_workspace_bytes_multi.        */
+size_t sp_lnlike_grad_workspace_bytes_multi(sp_handle *h, int S, int K, int M, int covpts);
+int sp_lnlike_grad_marginal_multi(sp_handle *h, int S, int K, int M, const double *t_dev, const double *flux_dev,
+                                  const double *diag_dev, const sp_star *stars_dev, int covpts, const double *tab_dev,
+                                  const double *meanvar_dev, int temporal, int normalized, int norm_order, double zmax,
+                                  void *workspace_dev, double *lnlike_dev, double *ybar_dev, double *meanbar_dev,
+                                  uint32_t *status_dev, void *stream);
 
 /* ---- fp64 NT product on the matrix cores (the kernel behind a13 / a17, exposed) -------
  *   C[b] = beta * C[b] + alpha * A[b] . B[b]^T,   beta in {0, 1}

@@ -87,6 +87,9 @@ PROTOTYPES = {
     "sp_spd_inverse_batched": (_I, [_V, _I, _I, _V, _L, _L, _V, _V, _V, _V, _V]),
     "sp_lnlike_grad_workspace_bytes": (ctypes.c_size_t, [_V, _I, _I, _I]),
     "sp_lnlike_grad_marginal": (_I, [_V, _I, _I, _V, _V, _V, _V, _I, _V, _V, _I, _I, _I, _D, _V, _V, _V, _V, _V, _V]),
+    "sp_lnlike_grad_workspace_bytes_multi": (ctypes.c_size_t, [_V, _I, _I, _I, _I]),
+    "sp_lnlike_grad_marginal_multi": (_I, [_V, _I, _I, _I, _V, _V, _V, _V, _I, _V, _V, _I, _I, _I, _D, _V, _V, _V, _V,
+                                           _V, _V]),
     "sp_gp_condition": (_I, [_V, _I, _I, _V, _V, _V, _V, _V, _V, _V]),
     "sp_alpha_beta": (_I, [_D, _I, c_double_p, c_double_p, c_double_p, c_double_p]),
     "sp_set_marginal_constants": (_I, [_V, _V, _V]),

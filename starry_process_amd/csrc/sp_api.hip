@@ -1440,9 +1440,9 @@ int sp_spd_inverse_batched(sp_handle *h, int S, int K, const double *C_dev, long
 // ---- the ensemble gradient's device half (sp_grad.hip; grad.py chains the table to the hyperparameters) ----
 namespace {
 struct GradLayout {
-  size_t inv, cinv, vec, hcoef, logdet, partial, total;
+  size_t inv, cinv, vec, dots, hcoef, logdet, partial, total;
 };
-GradLayout grad_layout(sp_handle *h, int S, int K, int covpts) {
+GradLayout grad_layout(sp_handle *h, int S, int K, int M, int covpts) {
   const int Kr = sp_roundup(K, SP_NB);
   GradLayout G;
   size_t off = 0;
@@ -1454,7 +1454,8 @@ GradLayout grad_layout(sp_handle *h, int S, int K, int covpts) {
   const size_t d = sizeof(double);
   G.inv = take(make_layout(h, S, K, Kr, true, true).total);
   G.cinv = take(d * (size_t)S * Kr * Kr);
-  G.vec = take(d * (size_t)S * 4 * K);
+  G.vec = take(d * (size_t)S * (M + 3) * K);       // C^-1 [p, q, 1, r_0 .. r_{M-1}]
+  G.dots = take(d * (size_t)S * M * 2);
   G.hcoef = take(d * S);
   G.logdet = take(d * S);
   {
@@ -1467,9 +1468,12 @@ GradLayout grad_layout(sp_handle *h, int S, int K, int covpts) {
 }
 }  // namespace
 
+size_t sp_lnlike_grad_workspace_bytes_multi(sp_handle *h, int S, int K, int M, int covpts) {
+  if (!h || S < 0 || K < 2 || M < 1 || covpts < 1) return 0;
+  return grad_layout(h, S, K, M, covpts).total;
+}
 size_t sp_lnlike_grad_workspace_bytes(sp_handle *h, int S, int K, int covpts) {
-  if (!h || S < 0 || K < 2 || covpts < 1) return 0;
-  return grad_layout(h, S, K, covpts).total;
+  return sp_lnlike_grad_workspace_bytes_multi(h, S, K, 1, covpts);
 }
 
 int sp_lnlike_grad_marginal(sp_handle *h, int S, int K, const double *t_dev, const double *flux_dev,
@@ -1477,15 +1481,26 @@ int sp_lnlike_grad_marginal(sp_handle *h, int S, int K, const double *t_dev, con
                             const double *meanvar_dev, int temporal, int normalized, int norm_order, double zmax,
                             void *workspace_dev, double *lnlike_dev, double *ybar_dev, double *meanbar_dev,
                             uint32_t *status_dev, void *stream) {
+  return sp_lnlike_grad_marginal_multi(h, S, K, 1, t_dev, flux_dev, diag_dev, stars_dev, covpts, tab_dev, meanvar_dev,
+                                       temporal, normalized, norm_order, zmax, workspace_dev, lnlike_dev, ybar_dev,
+                                       meanbar_dev, status_dev, stream);
+}
+
+int sp_lnlike_grad_marginal_multi(sp_handle *h, int S, int K, int M, const double *t_dev, const double *flux_dev,
+                                  const double *diag_dev, const sp_star *stars_dev, int covpts, const double *tab_dev,
+                                  const double *meanvar_dev, int temporal, int normalized, int norm_order, double zmax,
+                                  void *workspace_dev, double *lnlike_dev, double *ybar_dev, double *meanbar_dev,
+                                  uint32_t *status_dev, void *stream) {
   if (h && h->device < 0) return SP_ERR_NO_DEVICE;
   if (!h || !t_dev || !flux_dev || !stars_dev || !tab_dev || !meanvar_dev || !workspace_dev || !lnlike_dev ||
-      !ybar_dev || !meanbar_dev || S < 0 || K < 2 || covpts < 1 || norm_order < 0 || norm_order > SP_NORM_MAXORDER)
+      !ybar_dev || !meanbar_dev || S < 0 || K < 2 || M < 1 || covpts < 1 || norm_order < 0 ||
+      norm_order > SP_NORM_MAXORDER)
     return SP_ERR_INVALID;
   if (h->xp_covpts != covpts) return SP_ERR_STATE;
   if (S == 0) return SP_OK;
   hipStream_t st = (hipStream_t)stream;
   const int Kr = sp_roundup(K, SP_NB);
-  const GradLayout G = grad_layout(h, S, K, covpts);
+  const GradLayout G = grad_layout(h, S, K, M, covpts);
   char *base = static_cast<char *>(workspace_dev);
   void *ws = base + G.inv;
   Layout L = make_layout(h, S, K, Kr, true, true);
@@ -1511,8 +1526,9 @@ int sp_lnlike_grad_marginal(sp_handle *h, int S, int K, const double *t_dev, con
                                nullptr, normalized, qv, coef, diag_dev, 1, nullptr, sys, L.Kp, (long)L.Kp * L.Kp, st)))
     return rc;
   if ((rc = spd_inverse_in_place(h, S, K, L, ws, Cinv, logdet, st))) return rc;
-  return sp_launch_grad_sweep(S, K, Kr, Cinv, theta, t_dev, flux_dev, stars_dev, coef, qv, diag_dev, logdet, info,
-                              covpts, temporal, normalized, norm_order, zmax, vec, hcoef, partial, lnlike_dev, ybar_dev,
+  return sp_launch_grad_sweep(S, K, Kr, M, Cinv, theta, t_dev, flux_dev, stars_dev, coef, qv, diag_dev, logdet, info,
+                              covpts, temporal, normalized, norm_order, zmax, vec,
+                              reinterpret_cast<double *>(base + G.dots), hcoef, partial, lnlike_dev, ybar_dev,
                               meanbar_dev, status_dev, st);
 }
 

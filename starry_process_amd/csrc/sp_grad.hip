@@ -40,24 +40,35 @@ __global__ __launch_bounds__(256) void mirror_lower_kernel(double *__restrict__ 
   for (int r = r4; r < 64; r += 4) M[(size_t)(64 * tj + r) * Kr + 64 * ti + c] = tile[c][r];
 }
 
-// C^-1 [r, p, q, 1] per star (C^-1 symmetric: thread i sums over the ROWS j of its column, coalesced).
-// vec[s][0..3][K].  grid (Kr / 64, S)
+// C^-1 [p, q, 1, r_0 .. r_{M-1}] per star (C^-1 symmetric: thread i sums over the ROWS j of its column, coalesced),
+// four vectors per pass over the inverse: vec[s][0..M+2][K] = C^-1 p, C^-1 q, C^-1 1, alpha_m = C^-1 r_m.
+// grid (Kr / 64, S, ceil((M + 3) / 4)); one light curve per star is one pass, as before.
 __global__ __launch_bounds__(256) void grad_matvec_kernel(
-    int K, int Kr, const double *__restrict__ Cinv, const double *__restrict__ flux,
+    int K, int Kr, int M, const double *__restrict__ Cinv, const double *__restrict__ flux,
     const sp_star *__restrict__ stars, const SpCoef *__restrict__ coef, const double *__restrict__ qv,
     int normalized, double *__restrict__ vec) {
   __shared__ double red[4][4][64];
   const int s = blockIdx.y, i = blockIdx.x * 64 + (threadIdx.x & 63), jq = threadIdx.x >> 6;
+  const int v0 = 4 * blockIdx.z, NV = M + 3;
   const double *Ci = Cinv + (size_t)s * Kr * Kr;
   const double shift = coef[s].gpmean + stars[s].baseline_mean;
+  // (vector v of this pass: 0 p, 1 q, 2 ones, 3 + m the residuals of light curve m; past the last: skipped)
+  const double *fl[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int v = v0 + k;
+    fl[k] = (v >= 3 && v < NV) ? flux + ((size_t)s * M + (v - 3)) * K : nullptr;
+  }
   double a[4] = {0.0, 0.0, 0.0, 0.0};
   for (int j = jq; j < K; j += 4) {
     const double c = Ci[(size_t)j * Kr + i];
     const double q = normalized ? qv[(size_t)s * K + j] : 0.0;
-    a[0] += c * (flux[(size_t)s * K + j] - shift);
-    a[1] += c * (1.0 - q);
-    a[2] += c * q;
-    a[3] += c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int v = v0 + k;
+      const double x = v == 0 ? 1.0 - q : v == 1 ? q : v == 2 ? 1.0 : (fl[k] ? fl[k][j] - shift : 0.0);
+      a[k] += c * x;
+    }
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) red[k][jq][threadIdx.x & 63] = a[k];
@@ -65,58 +76,88 @@ __global__ __launch_bounds__(256) void grad_matvec_kernel(
   if (jq == 0 && i < K) {
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      vec[((size_t)s * 4 + k) * K + i] = (red[k][0][threadIdx.x] + red[k][1][threadIdx.x]) +
-                                        (red[k][2][threadIdx.x] + red[k][3][threadIdx.x]);
+      if (v0 + k < NV)
+        vec[((size_t)s * NV + v0 + k) * K + i] = (red[k][0][threadIdx.x] + red[k][1][threadIdx.x]) +
+                                                 (red[k][2][threadIdx.x] + red[k][3][threadIdx.x]);
   }
 }
 
-// one workgroup per star: the dot products, lnL, the scalar adjoints and the vector w (into vec[s][1]); alpha
-// stays in vec[s][0]
+// one workgroup per star: the dot products, lnL, the scalar adjoints and the vector w (into vec[s][0], over C^-1 p);
+// the alpha_m stay in vec[s][3 + m].  With M light curves on one covariance (sp.py:1162-1171)
+//   lnL = sum_m -1/2 r_m^T C^-1 r_m - M/2 log det C - M K/2 log 2 pi,      G = (sum_m alpha_m alpha_m^T - M C^-1) / 2:
+// every quadratic form in alpha below is summed over m, every term of C^-1 alone counts M times.
 __global__ __launch_bounds__(256) void grad_scalars_kernel(
-    int K, int Kr, const double *__restrict__ Cinv, const double *__restrict__ flux,
+    int K, int Kr, int M, const double *__restrict__ Cinv, const double *__restrict__ flux,
     const sp_star *__restrict__ stars, const SpCoef *__restrict__ coef, const double *__restrict__ qv,
     const double *__restrict__ diag, const double *__restrict__ logdet, const int32_t *__restrict__ info,
-    int normalized, int order, double zmax, double *__restrict__ vec, double *__restrict__ lnlike,
-    double *__restrict__ meanbar, double *__restrict__ hcoef, uint32_t *__restrict__ status) {
-  __shared__ double red[12][4];
-  const int s = blockIdx.x, tid = threadIdx.x;
+    int normalized, int order, double zmax, double *__restrict__ vec, double *__restrict__ dots /* [S][M][2] */,
+    double *__restrict__ lnlike, double *__restrict__ meanbar, double *__restrict__ hcoef, uint32_t *__restrict__ status) {
+  __shared__ double red[5][4];
+  const int s = blockIdx.x, tid = threadIdx.x, NV = M + 3;
   const sp_star st = stars[s];
   const SpCoef c = coef[s];
   const double shift = c.gpmean + st.baseline_mean;
-  double *V = vec + (size_t)s * 4 * K;
+  double *V = vec + (size_t)s * NV * K;
   const double *Ci = Cinv + (size_t)s * Kr * Kr;
-  // 0 r.a  1 a.p  2 a.q  3 a.1  4 p.Cp  5 q.Cq  6 q.Cp  7 1.C1  8 a.D.a  9 tr(Cinv D)
-  double d[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  auto block_sums = [&](double (&d)[5]) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const double v = wsum(d[k]);
+      if ((tid & 63) == 0) red[k][tid >> 6] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 5; ++k) d[k] = (red[k][0] + red[k][1]) + (red[k][2] + red[k][3]);
+  };
+  // the matrix's own: 0 p.Cp  1 q.Cq  2 q.Cp  3 1.C1  4 tr(Cinv D)
+  double mt[5] = {0, 0, 0, 0, 0};
   for (int i = tid; i < K; i += 256) {
-    const double al = V[i], cp = V[K + i], cq = V[2 * K + i], c1v = V[3 * K + i];
+    const double cp = V[i], cq = V[K + i], c1v = V[2 * K + i];
     const double q = normalized ? qv[(size_t)s * K + i] : 0.0, p = 1.0 - q;
-    const double r = flux[(size_t)s * K + i] - shift;
     const double D = diag ? diag[(size_t)s * K + i] : st.data_var;
-    d[0] += r * al;
-    d[1] += al * p;
-    d[2] += al * q;
-    d[3] += al;
-    d[4] += p * cp;
-    d[5] += q * cq;
-    d[6] += q * cp;
-    d[7] += c1v;
-    d[8] += al * al * D;
-    d[9] += Ci[(size_t)i * Kr + i] * D;
+    mt[0] += p * cp;
+    mt[1] += q * cq;
+    mt[2] += q * cp;
+    mt[3] += c1v;
+    mt[4] += Ci[(size_t)i * Kr + i] * D;
   }
-#pragma unroll
-  for (int k = 0; k < 10; ++k) {
-    const double v = wsum(d[k]);
-    if ((tid & 63) == 0) red[k][tid >> 6] = v;
+  block_sums(mt);
+  // per light curve: r.a, a.p, a.q, a.1, a.D.a -- summed as the forms the adjoints need
+  double R = 0.0, P2 = 0.0, Q2 = 0.0, PQ = 0.0, O2 = 0.0, O1 = 0.0, AD = 0.0;
+  for (int m = 0; m < M; ++m) {
+    const double *al = V + (size_t)(3 + m) * K, *f = flux + ((size_t)s * M + m) * K;
+    double d[5] = {0, 0, 0, 0, 0};
+    for (int i = tid; i < K; i += 256) {
+      const double a = al[i];
+      const double q = normalized ? qv[(size_t)s * K + i] : 0.0;
+      const double D = diag ? diag[(size_t)s * K + i] : st.data_var;
+      d[0] += (f[i] - shift) * a;
+      d[1] += a * (1.0 - q);
+      d[2] += a * q;
+      d[3] += a;
+      d[4] += a * a * D;
+    }
+    block_sums(d);
+    R += d[0];
+    P2 += d[1] * d[1];
+    Q2 += d[2] * d[2];
+    PQ += d[1] * d[2];
+    O2 += d[3] * d[3];
+    O1 += d[3];
+    AD += d[4];
+    if (tid == 0) {
+      dots[((size_t)s * M + m) * 2] = d[1];
+      dots[((size_t)s * M + m) * 2 + 1] = d[2];
+    }
   }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 10; ++k) d[k] = (red[k][0] + red[k][1]) + (red[k][2] + red[k][3]);
-  const double Kd = (double)K;
+  __syncthreads();       // (dots: written by thread 0, read by all below -- through memory, same workgroup)
+  const double Kd = (double)K, Md = (double)M;
   // (the sweep takes every cadence as valid: a ragged star -- 0 < nobs < K -- would get a silently wrong value from
   //  the K-long products above; it gets NaN and SP_STAR_NAN instead)
   const bool ragged = st.nobs > 0 && st.nobs < K;
   const bool bad = (info && info[s] != 0) || (normalized && c.z > zmax) || ragged;
-  double c1 = 1.0, wconst = 0.0, gscale_u = 0.0, gscale_v = 0.0, mbar = d[3];
+  double c1 = 1.0, wconst = 0.0, gscale_u = 0.0, gscale_v = 0.0, mbar = O1;
   if (normalized) {
     const double z = c.z, mu = c.mu, m = c.m;
     // alpha_n(z), beta_n(z) and their derivatives (ops/norm/norm.py:26-44): f_0 = 1, f_{n+1} = f_n z (2 n + 3)
@@ -132,11 +173,11 @@ __global__ __launch_bounds__(256) void grad_scalars_kernel(
     }
     c1 = an / (mu * mu);
     const double ab = an + bn, s1 = z * ab, s2 = z * an, b = st.baseline_var;
-    const double A1 = 0.5 * (d[1] * d[1] - d[4]), A2 = 0.5 * (d[2] * d[2] - d[5]);
-    const double aSa = (d[0] - s1 * d[1] * d[1] + s2 * d[2] * d[2] - d[8] - b * d[3] * d[3]) / c1;
-    const double CiS = (Kd - s1 * d[4] + s2 * d[5] - d[9] - b * d[7]) / c1;
-    const double A0 = 0.5 * (aSa - CiS);
-    const double uq = 0.5 * (d[1] * d[2] - d[6]);
+    const double A1 = 0.5 * (P2 - Md * mt[0]), A2 = 0.5 * (Q2 - Md * mt[1]);
+    const double aSa = (R - s1 * P2 + s2 * Q2 - AD - b * O2) / c1;
+    const double CiS = (Kd - s1 * mt[0] + s2 * mt[1] - mt[4] - b * mt[3]) / c1;
+    const double A0 = 0.5 * (aSa - Md * CiS);
+    const double uq = 0.5 * (PQ - Md * mt[2]);
     const double gq = -2.0 * (s1 * uq + s2 * A2);
     const double kz = A0 * dan / (mu * mu) + A1 * (ab + z * (dan + dbn)) - A2 * (an + z * dan);
     const double km = kz / (mu * mu) - gq / m;
@@ -145,14 +186,22 @@ __global__ __launch_bounds__(256) void grad_scalars_kernel(
     gscale_u = -2.0 * s1 / (2.0 * Kd * m);
     gscale_v = -2.0 * s2 / (2.0 * Kd * m);
   }
-  // w_i = g_i / (2 K m) + kappa_m / (2 K^2),  g = -2 (s1 u + s2 v),  u = (alpha (a.p) - C^-1 p) / 2,  v likewise
+  // w_i = g_i / (2 K m) + kappa_m / (2 K^2),  g = -2 (s1 u + s2 v),  u = G p = (sum_m alpha_m (a_m.p) - M C^-1 p) / 2,
+  // v = G q likewise
+  const double *dt = dots + (size_t)s * M * 2;
   for (int i = tid; i < K; i += 256) {
-    const double al = V[i], cp = V[K + i], cq = V[2 * K + i];
-    const double u = 0.5 * (al * d[1] - cp), v = 0.5 * (al * d[2] - cq);
-    V[K + i] = bad ? 0.0 : gscale_u * u + gscale_v * v + wconst;
+    const double cp = V[i], cq = V[K + i];
+    double up = 0.0, vq = 0.0;
+    for (int m = 0; m < M; ++m) {
+      const double al = V[(size_t)(3 + m) * K + i];
+      up += al * dt[2 * m];
+      vq += al * dt[2 * m + 1];
+    }
+    const double u = 0.5 * (up - Md * cp), v = 0.5 * (vq - Md * cq);
+    V[i] = bad ? 0.0 : gscale_u * u + gscale_v * v + wconst;
   }
   if (tid == 0) {
-    const double ll = -0.5 * d[0] - 0.5 * logdet[s] - 0.5 * Kd * 1.8378770664093453;   // log(2 pi)
+    const double ll = -0.5 * R - 0.5 * Md * logdet[s] - 0.5 * Md * Kd * 1.8378770664093453;   // log(2 pi)
     const bool dead = bad || !(ll == ll);
     lnlike[s] = ragged ? __builtin_nan("") : (dead ? -INFINITY : ll);
     meanbar[s] = dead ? 0.0 : mbar;
@@ -167,7 +216,7 @@ __global__ __launch_bounds__(256) void grad_scalars_kernel(
 // bins in LDS (ds_add_f64), one partial table per workgroup (grad_bins_reduce_kernel adds them in a fixed order)
 template <int TK>
 __global__ __launch_bounds__(256) void grad_scatter_kernel(
-    int K, int Kr, const double *__restrict__ Cinv, const double *__restrict__ theta, const double *__restrict__ t,
+    int K, int Kr, int M, const double *__restrict__ Cinv, const double *__restrict__ theta, const double *__restrict__ t,
     const sp_star *__restrict__ stars, int covpts, const double *__restrict__ vec, const double *__restrict__ hcoef,
     double *__restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) double bins[];   // covpts + 4
@@ -183,15 +232,17 @@ __global__ __launch_bounds__(256) void grad_scatter_kernel(
   const double c1 = hcoef[s];
   const sp_star st = stars[s];
   if (i < K && c1 != 0.0) {
-    const double *V = vec + (size_t)s * 4 * K;
+    const double *V = vec + (size_t)s * (M + 3) * K, *Al = V + 3 * (size_t)K;     // w in V[0], alpha_m in V[3 + m]
     const double *Ci = Cinv + (size_t)s * Kr * Kr;
-    const double thi = theta[(size_t)s * K + i], ai = V[i], wi = V[K + i];
+    const double thi = theta[(size_t)s * K + i], ai = Al[i], wi = V[i], Md = (double)M;
     const double ti = TK != SP_TEMPORAL_NONE ? t[(size_t)s * K + i] : 0.0;
     const double dx = 6.283185307179586 / covpts, inv_dx = 1.0 / dx;
     const double mult = ta > tb ? 2.0 : 1.0;
     const int jend = ta * 64 + 64 < K ? ta * 64 + 64 : K;
     for (int j = ta * 64 + rq; j < jend; j += 4) {
-      const double H = mult * (c1 * 0.5 * (ai * V[j] - Ci[(size_t)j * Kr + i]) + wi + V[K + j]);
+      double aa = ai * Al[j];
+      for (int m = 1; m < M; ++m) aa += Al[(size_t)m * K + i] * Al[(size_t)m * K + j];
+      const double H = mult * (c1 * 0.5 * (aa - Md * Ci[(size_t)j * Kr + i]) + wi + V[j]);
       const double T = temporal_factor(TK, ti, TK != SP_TEMPORAL_NONE ? t[(size_t)s * K + j] : 0.0, st.tau);
       // the segment of the lag and the position inside it: SplineGen's index (flux.py:262-265)
       int idx;
@@ -241,33 +292,34 @@ __global__ __launch_bounds__(256) void grad_bins_reduce_kernel(int np, int nwg, 
 
 }  // namespace
 
-int sp_launch_grad_sweep(int S, int K, int Kr, double *Cinv, const double *theta, const double *t,
+int sp_launch_grad_sweep(int S, int K, int Kr, int M, double *Cinv, const double *theta, const double *t,
                          const double *flux, const sp_star *stars, const void *coef, const double *qv,
                          const double *diag, const double *logdet, const int32_t *info, int covpts, int temporal,
-                         int normalized, int order, double zmax, double *vec, double *hcoef, double *partial,
-                         double *lnlike, double *ybar, double *meanbar, uint32_t *status, hipStream_t st) {
+                         int normalized, int order, double zmax, double *vec, double *dots, double *hcoef,
+                         double *partial, double *lnlike, double *ybar, double *meanbar, uint32_t *status,
+                         hipStream_t st) {
   const int ntr = Kr / 64, np = covpts + 4;
   if (ntr > 1) {
     hipLaunchKernelGGL(mirror_lower_kernel, dim3(ntr * (ntr - 1) / 2, S), dim3(256), 0, st, Cinv, Kr);
     SP_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(grad_matvec_kernel, dim3(ntr, S), dim3(256), 0, st, K, Kr, Cinv, flux, stars,
+  hipLaunchKernelGGL(grad_matvec_kernel, dim3(ntr, S, (M + 3 + 3) / 4), dim3(256), 0, st, K, Kr, M, Cinv, flux, stars,
                      (const SpCoef *)coef, qv, normalized, vec);
   SP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(grad_scalars_kernel, dim3(S), dim3(256), 0, st, K, Kr, Cinv, flux, stars, (const SpCoef *)coef,
-                     qv, diag, logdet, info, normalized, order, zmax, vec, lnlike, meanbar, hcoef, status);
+  hipLaunchKernelGGL(grad_scalars_kernel, dim3(S), dim3(256), 0, st, K, Kr, M, Cinv, flux, stars, (const SpCoef *)coef,
+                     qv, diag, logdet, info, normalized, order, zmax, vec, dots, lnlike, meanbar, hcoef, status);
   SP_LAUNCH_CHECK();
   const size_t lds = sizeof(double) * np;
   if (lds > 60 * 1024) return SP_ERR_INVALID;
   dim3 grid(ntr * (ntr + 1) / 2, S);
   if (temporal == SP_TEMPORAL_NONE)
-    hipLaunchKernelGGL((grad_scatter_kernel<SP_TEMPORAL_NONE>), grid, dim3(256), lds, st, K, Kr, Cinv, theta, t, stars,
+    hipLaunchKernelGGL((grad_scatter_kernel<SP_TEMPORAL_NONE>), grid, dim3(256), lds, st, K, Kr, M, Cinv, theta, t, stars,
                        covpts, vec, hcoef, partial);
   else if (temporal == SP_TEMPORAL_MATERN32)
-    hipLaunchKernelGGL((grad_scatter_kernel<SP_TEMPORAL_MATERN32>), grid, dim3(256), lds, st, K, Kr, Cinv, theta, t,
+    hipLaunchKernelGGL((grad_scatter_kernel<SP_TEMPORAL_MATERN32>), grid, dim3(256), lds, st, K, Kr, M, Cinv, theta, t,
                        stars, covpts, vec, hcoef, partial);
   else if (temporal == SP_TEMPORAL_EXPSQUARED)
-    hipLaunchKernelGGL((grad_scatter_kernel<SP_TEMPORAL_EXPSQUARED>), grid, dim3(256), lds, st, K, Kr, Cinv, theta, t,
+    hipLaunchKernelGGL((grad_scatter_kernel<SP_TEMPORAL_EXPSQUARED>), grid, dim3(256), lds, st, K, Kr, M, Cinv, theta, t,
                        stars, covpts, vec, hcoef, partial);
   else
     return SP_ERR_INVALID;

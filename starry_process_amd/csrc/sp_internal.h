@@ -307,11 +307,12 @@ int sp_launch_syrk_diag(const double *X, long ld, long stride, double *T, int n,
 // LDS the hot form of the assembly needs (sp_assemble.hip, assemble_sums_kernel) and the most it may ask for
 #define SP_ASM_LDS_MAX (80 * 1024)
 size_t sp_assemble_sums_lds(int Kp, int covpts, int temporal);
-int sp_launch_grad_sweep(int S, int K, int Kr, double *Cinv, const double *theta, const double *t,
+int sp_launch_grad_sweep(int S, int K, int Kr, int M, double *Cinv, const double *theta, const double *t,
                          const double *flux, const sp_star *stars, const void *coef, const double *qv,
                          const double *diag, const double *logdet, const int32_t *info, int covpts, int temporal,
-                         int normalized, int order, double zmax, double *vec, double *hcoef, double *partial,
-                         double *lnlike, double *ybar, double *meanbar, uint32_t *status, hipStream_t st);
+                         int normalized, int order, double zmax, double *vec, double *dots, double *hcoef,
+                         double *partial, double *lnlike, double *ybar, double *meanbar, uint32_t *status,
+                         hipStream_t st);
 
 // per-star scratch of the factorisation: three image slots + the chain words (sp_tile.h).  Doubles.
 static inline long sp_lt_stride(int) { return 2 * 4096L; }

@@ -536,27 +536,29 @@ class Engine(object):
 
     def lnlike_grad_marginal(self, t, flux, stars_dev, tab, meanvar, diag=None, covpts=300, temporal=None,
                              normalized=True, norm_order=20, zmax=0.023, workspace=None):
-        """Device half of the ensemble gradient (sp_lnlike_grad_marginal): t [S, K], flux [S, K] or [S, 1, K] ->
-        (lnlike [S], ybar [S, covpts + 4], meanbar [S], status [S]): the log-likelihoods and their derivatives with
-        respect to each star's kernel table and flux mean (grad.py chains them to the hyperparameters)."""
+        """Device half of the ensemble gradient (sp_lnlike_grad_marginal_multi): t [S, K], flux [S, K] or [S, M, K]
+        (M light curves per star on one covariance) -> (lnlike [S], ybar [S, covpts + 4], meanbar [S], status [S]):
+        the log-likelihoods (summed over a star's light curves) and their derivatives with respect to each star's
+        kernel table and flux mean (grad.py chains them to the hyperparameters)."""
         torch = _torch()
         S, K = t.shape
-        flux = flux.reshape(S, K)
-        nbytes = int(self._L.sp_lnlike_grad_workspace_bytes(self._h, S, K, int(covpts)))
+        flux = flux.reshape(S, -1, K)
+        M = flux.shape[1]
+        nbytes = int(self._L.sp_lnlike_grad_workspace_bytes_multi(self._h, S, K, M, int(covpts)))
         ws = workspace
         if ws is None or ws.numel() < nbytes:
             ws = self._grad_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         out, ybar, mbar = self.empty(S), self.empty(S, covpts + 4), self.empty(S)
         status = torch.zeros(S, dtype=torch.int32, device=self.device)
-        check(self._L.sp_lnlike_grad_marginal(
-            self._h, S, K, self._p(t), self._p(flux), self._p(diag), self._p(stars_dev), int(covpts), self._p(tab),
+        check(self._L.sp_lnlike_grad_marginal_multi(
+            self._h, S, K, M, self._p(t), self._p(flux), self._p(diag), self._p(stars_dev), int(covpts), self._p(tab),
             self._p(meanvar), TEMPORAL[temporal], int(bool(normalized)), int(norm_order), float(zmax), self._p(ws),
             self._p(out), self._p(ybar), self._p(mbar), self._p(status), self._stream()))
         return out, ybar, mbar, status
 
-    def grad_workspace(self, S, K, covpts):
+    def grad_workspace(self, S, K, covpts, M=1):
         torch = _torch()
-        nbytes = int(self._L.sp_lnlike_grad_workspace_bytes(self._h, S, K, int(covpts)))
+        nbytes = int(self._L.sp_lnlike_grad_workspace_bytes_multi(self._h, S, K, int(M), int(covpts)))
         return torch.empty(nbytes, dtype=torch.uint8, device=self.device)
 
     def cholesky_lnlike(self, cov, resid):

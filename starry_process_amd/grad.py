@@ -327,7 +327,9 @@ class EnsembleGradient(object):
     """Log-likelihood of an ENSEMBLE of light curves and its gradient with respect to the spot hyperparameters
     (r, a, b, c, n[, dr]) in ONE device sweep per evaluation -- what ``theano.grad`` of the summed
     ``sp.log_likelihood`` is in the reference (tests/test_lnlike.py:100-136, calibrate/log_prob.py:53-91), for every
-    star of the batch at once.  Marginal branch, one light curve per star, scalar or per-cadence data variance.
+    star of the batch at once.  Marginal branch, scalar or per-cadence data variance; one light curve per star
+    (flux [S, K]) or M of them on the star's one covariance (flux [S, M, K]: the shared-covariance form of
+    sp.py:1162-1171 -- with S = 1 the gradient of what ``calibrate.get_log_prob`` evaluates).
 
         eg = EnsembleGradient(t, flux, ferr=1e-3, p=periods)       # data -> GPU, once
         lnl, grad = eg(r=20., a=.4, b=.27, c=.1, n=10.)             # lnl: sum over stars; grad: dict
@@ -353,9 +355,10 @@ class EnsembleGradient(object):
         from .engine import engine_slots, make_stars
 
         flux = np.asarray(flux, dtype=np.float64)
-        if flux.ndim != 2:
-            raise ValueError("flux must be (S, K)")
-        S, K = flux.shape
+        if flux.ndim not in (2, 3):
+            raise ValueError("flux must be (S, K) or (S, M, K)")
+        S, K = flux.shape[0], flux.shape[-1]
+        M = flux.shape[1] if flux.ndim == 3 else 1
         if K < 2:
             raise ValueError("at least two cadences")
         t = np.asarray(t, dtype=np.float64)
@@ -389,7 +392,7 @@ class EnsembleGradient(object):
         self._temporal = (temporal_kernel if isinstance(temporal_kernel, str) else kernel_id(temporal_kernel)) if tau else None
         self._normalized, self._h, self._ukw = bool(normalized), float(h), dict(upstream_kwargs or {})
         self._exact = bool(exact)
-        self._ws = e.grad_workspace(S, K, self._covpts)
+        self._ws = e.grad_workspace(S, K, self._covpts, M)
         self.lnlike = None
         torch.cuda.synchronize(e.device)
 
