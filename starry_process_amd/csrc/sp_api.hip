@@ -1308,7 +1308,7 @@ int sp_lnlike_ensemble_planned(sp_handle *h, const sp_plan *plan, const double *
   (void)dlazy;
   if (lazy_nfull)
     G.lazy = LazyCov{plan->dev.theta, t_dev, stars_dev, ptab, K, covpts, temporal, lazy_nfull, 0, 0, no_panels ? 0 : 1,
-                     no_panels, riding ? rid : nullptr, riding ? nrid : 0, dlazy};
+                     no_panels, riding ? rid : nullptr, riding ? nrid : 0, dlazy, plan->dev.inorder};
   if ((rc = sp_launch_cholesky_groups(h, 1, &G, K, L.Kp))) return rc;
   if (!fused_reduce) return lnlike_finish(L, ws, K, M, lnlike_dev, status_dev, st, stars_dev, true, diag_dev != nullptr);
   return SP_OK;

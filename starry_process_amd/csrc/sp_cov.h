@@ -181,59 +181,105 @@ __device__ __forceinline__ void spline_table_to_lds(const double *__restrict__ s
 #ifndef SP_LAZY_BATCH
 #define SP_LAZY_BATCH 8
 #endif
-template <typename V4>
-__device__ __forceinline__ void lazy_cov_tile(const LazyCov &z, int star, const int (&ri)[4],
-                                              const int (&cj)[4], V4 (&out)[4], double *stage) {
+// MA row groups at once (the 128 x 64 tiles of large remainders: two; the 64 x 64 tiles: one): the table is copied and
+// the column side is prepared once.
+//
+// The Matern-3/2 factor (1 + x) exp(-x), x = sqrt(3) |t_i - t_j| / tau (temporal.py:8-11), SEPARATES in a tile below
+// the diagonal of a light curve whose cadences are in order (LazyCov.inorder, from the data plan):
+//     exp(-c (t_i - t_j)) = exp(-c (t_i - b)) exp(c (t_j - b)),      c = sqrt(3) / tau,  b = the tile's first cadence
+// -- 4 (MA + 1) exponentials per lane instead of 16 MA, and no division.  One exponential, one division and the
+// polynomial per entry were three times the spline's own cost: the first trailing update of cfg5's shape ran at 0.70
+// of the fp64 peak where the later ones, which load their tiles, reach 0.78.  A column whose factor would overflow
+// (c (t_j - b) >= 600: a gap of years inside 64 cadences at a tau of hours), a star out of order, every other kernel:
+// the entry-by-entry form.  The two forms agree to a few ulp (as in the assembly, sp_assemble.hip).
+template <int MA, typename V4>
+__device__ __forceinline__ void lazy_cov_tiles(const LazyCov &z, int star, const int (&ri)[MA][4],
+                                               const int (&cj)[4], V4 (&out)[MA][4], double *stage) {
   const sp_star st = z.stars[star];
   const int nobs = star_nobs(st, z.K), np = z.covpts + 4;
   const double *th = z.theta + (size_t)star * z.K, *tt = z.t + (size_t)star * z.K;
   const bool tk = z.temporal != SP_TEMPORAL_NONE;
-  double thi[4], thj[4], ti[4], tj[4];
+#ifdef SP_LAZY_NO_SEP
+  const bool sep = false;      // (A/B: every entry its own exponential)
+#else
+  const bool sep = z.temporal == SP_TEMPORAL_MATERN32 && z.inorder && z.inorder[star] != 0.0;
+#endif
+  double thi[MA][4], ti[MA][4], thj[4], tj[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const bool oi = ri[k] < nobs, oj = cj[k] < nobs;
-    thi[k] = oi ? th[ri[k]] : 0.0;
+    const bool oj = cj[k] < nobs;
     thj[k] = oj ? th[cj[k]] : 0.0;
-    ti[k] = (oi && tk) ? tt[ri[k]] : 0.0;
     tj[k] = (oj && tk) ? tt[cj[k]] : 0.0;
+#pragma unroll
+    for (int m = 0; m < MA; ++m) {
+      const bool oi = ri[m][k] < nobs;
+      thi[m][k] = oi ? th[ri[m][k]] : 0.0;
+      ti[m][k] = (oi && tk) ? tt[ri[m][k]] : 0.0;
+    }
   }
+  const int c0 = cj[0] & ~63;                                    // (tiles are aligned to 64 columns)
+  const double tb = sep ? tt[c0 < nobs ? c0 : nobs - 1] : 0.0;
   spline_table_to_lds(z.ptab + (size_t)star * 4 * np, stage, np, threadIdx.x);
   __syncthreads();
   SplineGen g{stage, 2 * np, 6.283185307179586 / z.covpts,
               1.0 / (6.283185307179586 / z.covpts), z.covpts};
-  // (eight entries per batch: sixteen take the trailing update from 163 registers -- three workgroups per CU -- to 204)
+  const double cm = sep ? 1.7320508075688772 / st.tau : 0.0;
+  double fc[4] = {1.0, 1.0, 1.0, 1.0};
+  bool fok[4] = {false, false, false, false};
+  if (sep) {
 #pragma unroll
-  for (int n0 = 0; n0 < 4; n0 += SP_LAZY_BATCH / 4) {
-    double a[SP_LAZY_BATCH], b[SP_LAZY_BATCH], v[SP_LAZY_BATCH];
-#pragma unroll
-    for (int e = 0; e < SP_LAZY_BATCH; ++e) {
-      a[e] = thi[e & 3];
-      b[e] = thj[n0 + (e >> 2)];
-    }
-    g.many<SP_LAZY_BATCH>(a, b, v);
-#pragma unroll
-    for (int e = 0; e < SP_LAZY_BATCH; ++e) {
-      const int n = n0 + (e >> 2), r = e & 3;
-      double w = 0.0;
-      if (ri[r] < nobs && cj[n] < nobs) {
-#pragma clang fp contract(off)
-        w = v[e] * temporal_factor(z.temporal, ti[r], tj[n], st.tau);
-      }
-      out[n][r] = w;
+    for (int n = 0; n < 4; ++n) {
+      const double a = cm * (tj[n] - tb);
+      fok[n] = a < 600.0 && a >= 0.0;                             // (false for a NaN: tau = 0)
+      fc[n] = exp(fok[n] ? a : 0.0);
     }
   }
-  if (z.rid) {
-    // (a row tile that holds rows below the cadences: residuals, ones, variances -- the planned step; LazyCov.rid)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = ri[r] - z.K;
-      if (m < 0 || m >= z.nrid) continue;
-      const double *src = z.rid + ((size_t)star * (z.nrid + 1) + m) * z.K;
-      double x[4];
+  for (int m = 0; m < MA; ++m) {
+    double er[4] = {1.0, 1.0, 1.0, 1.0};
+    if (sep) {
 #pragma unroll
-      for (int n = 0; n < 4; ++n) x[n] = src[cj[n] < z.K ? cj[n] : z.K - 1];
+      for (int r = 0; r < 4; ++r) er[r] = exp(-(cm * (ti[m][r] - tb)));
+    }
+    // (eight entries per batch: sixteen take the trailing update from 163 registers -- three workgroups per CU -- to 204)
 #pragma unroll
-      for (int n = 0; n < 4; ++n) out[n][r] = cj[n] < z.K ? x[n] : 0.0;
+    for (int n0 = 0; n0 < 4; n0 += SP_LAZY_BATCH / 4) {
+      double a[SP_LAZY_BATCH], b[SP_LAZY_BATCH], v[SP_LAZY_BATCH];
+#pragma unroll
+      for (int e = 0; e < SP_LAZY_BATCH; ++e) {
+        a[e] = thi[m][e & 3];
+        b[e] = thj[n0 + (e >> 2)];
+      }
+      g.many<SP_LAZY_BATCH>(a, b, v);
+#pragma unroll
+      for (int e = 0; e < SP_LAZY_BATCH; ++e) {
+        const int n = n0 + (e >> 2), r = e & 3;
+        double w = 0.0;
+        if (ri[m][r] < nobs && cj[n] < nobs) {
+#pragma clang fp contract(off)
+          if (sep && fok[n]) {
+            const double x = cm * (ti[m][r] - tj[n]);             // (rows below columns, cadences in order: >= 0)
+            w = v[e] * ((1.0 + x) * (er[r] * fc[n]));
+          } else {
+            w = v[e] * temporal_factor(z.temporal, ti[m][r], tj[n], st.tau);
+          }
+        }
+        out[m][n][r] = w;
+      }
+    }
+    if (z.rid) {
+      // (a row tile that holds rows below the cadences: residuals, ones, variances -- the planned step; LazyCov.rid)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mr = ri[m][r] - z.K;
+        if (mr < 0 || mr >= z.nrid) continue;
+        const double *src = z.rid + ((size_t)star * (z.nrid + 1) + mr) * z.K;
+        double x[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) x[n] = src[cj[n] < z.K ? cj[n] : z.K - 1];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) out[m][n][r] = cj[n] < z.K ? x[n] : 0.0;
+      }
     }
   }
   __syncthreads();   // the scratch goes back to its owner

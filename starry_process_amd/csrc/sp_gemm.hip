@@ -248,16 +248,17 @@ __global__ __launch_bounds__(256, SP_MM_WAVES) void mm_nt_kernel(
   constexpr bool CAN_LAZY = Core::MA == 1 && Core::NA == 4 && TM == 64 && TN == 64;
   const bool lazy = CAN_LAZY && beta && lz.theta && lz.tr0 + ti > lz.tc0 + tj && lz.tc0 + tj > 0 &&
                     lz.tr0 + ti < lz.nfull;
-  mm_d4 cz[4];
+  mm_d4 cz1[1][4];
+  mm_d4 (&cz)[4] = cz1[0];
   if (!lazy) mm.prologue(lds, k_first, Kd);   // the first slices are on their way while the C tile is fetched
   if (lazy) {
-    int ri[4], cj[4];
+    int ri[1][4], cj[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      ri[k] = 64 * (lz.tr0 + ti) + mm.acc_row(0, k);
+      ri[0][k] = 64 * (lz.tr0 + ti) + mm.acc_row(0, k);
       cj[k] = 64 * (lz.tc0 + tj) + mm.acc_col(k < Core::NA ? k : 0);
     }
-    lazy_cov_tile(lz, mtx, ri, cj, cz, lds);
+    lazy_cov_tiles<1>(lz, mtx, ri, cj, cz1, lds);
     mm.prologue(lds, k_first, Kd);
   }
 #pragma unroll
@@ -361,16 +362,14 @@ __global__ __launch_bounds__(256) void syrk128_kernel(const double *__restrict__
   const bool any_lazy = is_lazy(R0) || is_lazy(R0 + 1), my_lazy = is_lazy(R);
   mm_d4 acc[Core::MA][Core::NA];
   if (any_lazy) {
+    int ri[Core::MA][4], cj[4];
 #pragma unroll
-    for (int m = 0; m < Core::MA; ++m) {
-      int ri[4], cj[4];
+    for (int k = 0; k < 4; ++k) {
+      cj[k] = 64 * (lz.tc0 + J) + mm.acc_col(k);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        ri[k] = 64 * (lz.tr0 + R0) + mm.acc_row(m, k);
-        cj[k] = 64 * (lz.tc0 + J) + mm.acc_col(k);
-      }
-      lazy_cov_tile(lz, mtx, ri, cj, acc[m], lds);
+      for (int m = 0; m < Core::MA; ++m) ri[m][k] = 64 * (lz.tr0 + R0) + mm.acc_row(m, k);
     }
+    lazy_cov_tiles<Core::MA>(lz, mtx, ri, cj, acc, lds);
   }
   mm.prologue(lds, 0, Kd);
 #pragma unroll

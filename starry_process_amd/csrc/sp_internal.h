@@ -183,6 +183,8 @@ struct LazyCov {
   int nrid;
   int dlazy;               // bit 1: the first trailing update forms its diagonal tiles (all but its tile (0, 0), which the
                            // eager updates of the first super-panel keep in memory) instead of loading them
+  const double *inorder;   // [S] (or null) 1.0: the star's cadences are in non-decreasing order (the data plan knows) -- the
+                           // Matern-3/2 factor of a tile below the diagonal then separates into row and column factors
 };
 
 // does the symmetric trailing update of a remainder of nb 64-column blocks run on the 64 x 64 kernel whose diagonal
@@ -212,6 +214,7 @@ struct PlanDev {
   const double *sflux;     // [S][M] sums of the light curves over the valid cadences
   const double *sdv;       // [S] sum of the per-cadence variances over the valid cadences (0 without them)
   const double *key;       // [S][3] period, tau, nobs as planned
+  const double *inorder;   // [S] 1.0: cadences in non-decreasing order over the valid ones, else 0.0
 };
 struct sp_plan {
   int device, S, K, M, covpts, temporal, has_diag;

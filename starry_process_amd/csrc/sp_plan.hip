@@ -106,8 +106,8 @@ __global__ __launch_bounds__(256) void plan_wbar_reduce_kernel(int np, int nwg, 
 // sums of the data and the planned fields of the stars: one workgroup per star
 __global__ __launch_bounds__(256) void plan_scalars_kernel(
     int K, int M, const double *__restrict__ flux, const double *__restrict__ diag,
-    const sp_star *__restrict__ stars, double *__restrict__ sflux, double *__restrict__ sdv,
-    double *__restrict__ key) {
+    const sp_star *__restrict__ stars, const double *__restrict__ t, double *__restrict__ sflux,
+    double *__restrict__ sdv, double *__restrict__ key, double *__restrict__ inorder) {
   __shared__ double red[4];
   const int s = blockIdx.x, tid = threadIdx.x;
   const sp_star st = stars[s];
@@ -131,7 +131,13 @@ __global__ __launch_bounds__(256) void plan_scalars_kernel(
       else sdv[s] = total;
     }
   }
+  // are the cadences in order?  (what lets a Matern factor below the diagonal separate: sp_cov.h, lazy_cov_tiles)
+  int unsorted = 0;
+  for (int i = tid; i + 1 < nobs; i += 256)
+    if (!(t[(size_t)s * K + i + 1] >= t[(size_t)s * K + i])) unsorted = 1;
+  unsorted = __syncthreads_or(unsorted);
   if (tid == 0) {
+    inorder[s] = unsorted ? 0.0 : 1.0;
     key[3 * s] = st.period;
     key[3 * s + 1] = st.tau;
     key[3 * s + 2] = (double)nobs;
@@ -170,7 +176,8 @@ int sp_plan_data(sp_handle *h, int S, int K, int M, const double *t_dev, const d
   const size_t d = sizeof(double);
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t o_theta = 0, o_wbar = o_theta + up(d * S * K), o_sflux = o_wbar + up(d * S * np),
-               o_sdv = o_sflux + up(d * S * M), o_key = o_sdv + up(d * S), total = o_key + up(d * S * 3);
+               o_sdv = o_sflux + up(d * S * M), o_key = o_sdv + up(d * S), o_ord = o_key + up(d * S * 3),
+               total = o_ord + up(d * S);
   p->bytes = total;
   hipError_t e = hipMalloc(&p->buf, total);
   if (e != hipSuccess) {
@@ -181,8 +188,8 @@ int sp_plan_data(sp_handle *h, int S, int K, int M, const double *t_dev, const d
   char *base = static_cast<char *>(p->buf);
   double *theta = reinterpret_cast<double *>(base + o_theta), *wbar = reinterpret_cast<double *>(base + o_wbar);
   double *sflux = reinterpret_cast<double *>(base + o_sflux), *sdv = reinterpret_cast<double *>(base + o_sdv);
-  double *key = reinterpret_cast<double *>(base + o_key);
-  p->dev = PlanDev{theta, wbar, sflux, sdv, key};
+  double *key = reinterpret_cast<double *>(base + o_key), *inorder = reinterpret_cast<double *>(base + o_ord);
+  p->dev = PlanDev{theta, wbar, sflux, sdv, key, inorder};
   auto fail = [&](int rc) {
     (void)hipFree(p->buf);
     delete p;
@@ -190,8 +197,8 @@ int sp_plan_data(sp_handle *h, int S, int K, int M, const double *t_dev, const d
   };
   int rc = sp_launch_theta(S, K, t_dev, stars_dev, theta, st);
   if (rc) return fail(rc);
-  hipLaunchKernelGGL(plan_scalars_kernel, dim3(S), dim3(256), 0, st, K, M, flux_dev, diag_dev, stars_dev, sflux, sdv,
-                     key);
+  hipLaunchKernelGGL(plan_scalars_kernel, dim3(S), dim3(256), 0, st, K, M, flux_dev, diag_dev, stars_dev, t_dev, sflux,
+                     sdv, key, inorder);
   dim3 grid(ntl, S);
 #define SP_PLAN_WBAR(TK)                                                                                          \
   do {                                                                                                            \
