@@ -320,7 +320,10 @@ __global__ __launch_bounds__(256, SP_MM_WAVES) void mm_nt_kernel(
 // product of the size (tools/mm_tile_bench.py); for small remainders the wasted blocks weigh more than that
 // (nb = 8: 40 blocks executed for 35) and the 64 x 64 kernel stays (sp_launch_syrk_diag).
 using Syrk128Core = MM2<128, 64, 8, 4, 4>;
-__global__ __launch_bounds__(256) void syrk128_kernel(const double *__restrict__ X, long ld, long stride,
+#ifndef SP_SYRK128_WGS
+#define SP_SYRK128_WGS 1     // (probe: 3 = a register budget for three workgroups per CU)
+#endif
+__global__ __launch_bounds__(256, SP_SYRK128_WGS) void syrk128_kernel(const double *__restrict__ X, long ld, long stride,
                                                       double *__restrict__ T, int Kd, int batch, int nb, int ntiles,
                                                       LazyCov lz, DiagFuse df) {
   using Core = Syrk128Core;
