@@ -52,22 +52,30 @@ __global__ __launch_bounds__(256) void grad_matvec_kernel(
   const int v0 = 4 * blockIdx.z, NV = M + 3;
   const double *Ci = Cinv + (size_t)s * Kr * Kr;
   const double shift = coef[s].gpmean + stars[s].baseline_mean;
-  // (vector v of this pass: 0 p, 1 q, 2 ones, 3 + m the residuals of light curve m; past the last: skipped)
-  const double *fl[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int v = v0 + k;
-    fl[k] = (v >= 3 && v < NV) ? flux + ((size_t)s * M + (v - 3)) * K : nullptr;
-  }
   double a[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int j = jq; j < K; j += 4) {
-    const double c = Ci[(size_t)j * Kr + i];
-    const double q = normalized ? qv[(size_t)s * K + j] : 0.0;
+  if (v0 == 0) {
+    // the first pass: p, q, ones and the first light curve's residuals -- all there is with one light curve per star
+    const double *f0 = flux + (size_t)s * M * K;
+    for (int j = jq; j < K; j += 4) {
+      const double c = Ci[(size_t)j * Kr + i];
+      const double q = normalized ? qv[(size_t)s * K + j] : 0.0;
+      a[0] += c * (1.0 - q);
+      a[1] += c * q;
+      a[2] += c;
+      a[3] += c * (f0[j] - shift);
+    }
+  } else {
+    // further passes: the residuals of light curves v0 - 3 .. v0 (past the last: the last one again, not stored)
+    const double *fl[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int v = v0 + k;
-      const double x = v == 0 ? 1.0 - q : v == 1 ? q : v == 2 ? 1.0 : (fl[k] ? fl[k][j] - shift : 0.0);
-      a[k] += c * x;
+      const int m = v0 + k - 3;
+      fl[k] = flux + ((size_t)s * M + (m < M ? m : M - 1)) * K;
+    }
+    for (int j = jq; j < K; j += 4) {
+      const double c = Ci[(size_t)j * Kr + i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a[k] += c * (fl[k][j] - shift);
     }
   }
 #pragma unroll
@@ -214,12 +222,13 @@ __global__ __launch_bounds__(256) void grad_scalars_kernel(
 // scatter of H_ij T_ij c_m(x0_ij) into the table's adjoint: one workgroup per LOWER 64 x 64 tile (C^-1 and H are
 // symmetric: the tiles below the diagonal count twice; the lower storage is read along its rows: coalesced), the
 // bins in LDS (ds_add_f64), one partial table per workgroup (grad_bins_reduce_kernel adds them in a fixed order)
-template <int TK>
+template <int TK, bool ONE>     // ONE: one light curve per star (M == 1: no loop over them per entry)
 __global__ __launch_bounds__(256) void grad_scatter_kernel(
-    int K, int Kr, int M, const double *__restrict__ Cinv, const double *__restrict__ theta, const double *__restrict__ t,
+    int K, int Kr, int Mrt, const double *__restrict__ Cinv, const double *__restrict__ theta, const double *__restrict__ t,
     const sp_star *__restrict__ stars, int covpts, const double *__restrict__ vec, const double *__restrict__ hcoef,
     double *__restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) double bins[];   // covpts + 4
+  const int M = ONE ? 1 : Mrt;
   const int s = blockIdx.y, np = covpts + 4, tid = threadIdx.x;
   for (int k = tid; k < np; k += 256) bins[k] = 0.0;
   __syncthreads();
@@ -312,17 +321,20 @@ int sp_launch_grad_sweep(int S, int K, int Kr, int M, double *Cinv, const double
   const size_t lds = sizeof(double) * np;
   if (lds > 60 * 1024) return SP_ERR_INVALID;
   dim3 grid(ntr * (ntr + 1) / 2, S);
-  if (temporal == SP_TEMPORAL_NONE)
-    hipLaunchKernelGGL((grad_scatter_kernel<SP_TEMPORAL_NONE>), grid, dim3(256), lds, st, K, Kr, M, Cinv, theta, t, stars,
-                       covpts, vec, hcoef, partial);
-  else if (temporal == SP_TEMPORAL_MATERN32)
-    hipLaunchKernelGGL((grad_scatter_kernel<SP_TEMPORAL_MATERN32>), grid, dim3(256), lds, st, K, Kr, M, Cinv, theta, t,
-                       stars, covpts, vec, hcoef, partial);
-  else if (temporal == SP_TEMPORAL_EXPSQUARED)
-    hipLaunchKernelGGL((grad_scatter_kernel<SP_TEMPORAL_EXPSQUARED>), grid, dim3(256), lds, st, K, Kr, M, Cinv, theta, t,
-                       stars, covpts, vec, hcoef, partial);
-  else
-    return SP_ERR_INVALID;
+#define SP_SCATTER(TK)                                                                                               \
+  do {                                                                                                               \
+    if (M == 1)                                                                                                      \
+      hipLaunchKernelGGL((grad_scatter_kernel<TK, true>), grid, dim3(256), lds, st, K, Kr, M, Cinv, theta, t, stars,  \
+                         covpts, vec, hcoef, partial);                                                               \
+    else                                                                                                             \
+      hipLaunchKernelGGL((grad_scatter_kernel<TK, false>), grid, dim3(256), lds, st, K, Kr, M, Cinv, theta, t, stars, \
+                         covpts, vec, hcoef, partial);                                                               \
+  } while (0)
+  if (temporal == SP_TEMPORAL_NONE) SP_SCATTER(SP_TEMPORAL_NONE);
+  else if (temporal == SP_TEMPORAL_MATERN32) SP_SCATTER(SP_TEMPORAL_MATERN32);
+  else if (temporal == SP_TEMPORAL_EXPSQUARED) SP_SCATTER(SP_TEMPORAL_EXPSQUARED);
+  else return SP_ERR_INVALID;
+#undef SP_SCATTER
   SP_LAUNCH_CHECK();
   hipLaunchKernelGGL(grad_bins_reduce_kernel, dim3((np + 63) / 64, S), dim3(256), 0, st, np, ntr * (ntr + 1) / 2, partial, ybar);
   SP_LAUNCH_CHECK();
