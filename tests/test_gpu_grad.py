@@ -513,3 +513,66 @@ def test_conditional_ensemble_gradient_against_finite_differences_of_the_oracle(
         assert abs(g["i"][s] - fd) < 2e-5 * max(abs(fd), 1.0), ("i", s, g["i"][s], fd)
         fd = _central(f_of("p", s), 1e-6)
         assert abs(g["p"][s] - fd) < 2e-5 * max(abs(fd), 1.0), ("p", s, g["p"][s], fd)
+
+
+def test_new_entry_points_refuse_bad_arguments():
+    """The C ABI does not throw (include/starry_process_amd.h): the round's new entry points -- the moments with their
+    tangents, the rule's derivatives, the gradient sweep for M light curves -- hand bad arguments back as status codes."""
+    import ctypes
+    import torch
+    from starry_process_amd import _lib
+    from starry_process_amd.engine import get_engine, make_stars
+    from starry_process_amd.upstream_device import quadrature_nodes_grad
+
+    e = get_engine(5, 2)
+    L, N = _lib.lib(), e.N
+    hp = _lib.hptr
+    # sp_gauss_jacobi_grad
+    buf = [np.empty(7) for _ in range(6)]
+    assert L.sp_gauss_jacobi_grad(7, 0.5, 0.5, *[hp(x) for x in buf]) == 0
+    assert L.sp_gauss_jacobi_grad(0, 0.5, 0.5, *[hp(x) for x in buf]) == -1
+    assert L.sp_gauss_jacobi_grad(7, -1.5, 0.5, *[hp(x) for x in buf]) == -1
+    assert L.sp_gauss_jacobi_grad(7, 0.5, 0.5, hp(buf[0]), hp(buf[1]), None, hp(buf[3]), hp(buf[4]), hp(buf[5])) == -1
+    # sp_ylm_moments_quadrature_grad: odd P, latitudes that are not mirror pairs, null outputs
+    phi, w, dphi, dw, lam = quadrature_nodes_grad(5, 3.0, 2.0)
+    s0, ds = np.ones(N), np.zeros(N)
+    mean, cov, dmean, dcov = e.empty(N), e.empty(N, N), e.empty(3, N), e.empty(3, N, N)
+    arrs = [np.ascontiguousarray(x) for x in (s0, ds, phi, w, dphi, dw)]
+
+    def call(P=len(phi), arrays=arrs, cov_p=e._p(cov)):
+        return L.sp_ylm_moments_quadrature_grad(e._h, *[hp(x) for x in arrays], P, len(lam), 1.0, 1.0, 1e-12, 1e-5,
+                                                e._p(mean), cov_p, e._p(dmean), e._p(dcov), e._stream())
+
+    assert call() == 0
+    assert call(P=len(phi) - 1) == -1
+    assert call(cov_p=None) == -1
+    bad = [a.copy() for a in arrs]
+    bad[2][-1] *= 0.5                                  # the last latitude no longer mirrors its partner
+    assert call(arrays=bad) == -1
+    torch.cuda.synchronize()
+    assert np.all(np.isfinite(cov.cpu().numpy()))
+    # sp_lnlike_grad_marginal_multi
+    K, S = 40, 1
+    rta1 = e.f64(e.rTA1L([0.0, 0.0]))
+    e.set_moments_dev(mean, cov)
+    tab, mv = e.kernel_table(rta1, 300)
+    st = synthetic_star(0, K)
+    t, f = e.f64(st["t"][None, :]), e.f64(np.stack([st["flux"], st["flux"][::-1]])[None])
+    stars = e.stars_to_device(make_stars(S, period=1.0, data_var=1e-6))
+    ws = e.grad_workspace(S, K, 300, 2)
+    out, yb, mb = e.empty(S), e.empty(S, 304), e.empty(S)
+
+    def sweep(S_=S, K_=K, M_=2, covpts=300, ws_p=e._p(ws)):
+        return L.sp_lnlike_grad_marginal_multi(e._h, S_, K_, M_, e._p(t), e._p(f), None, e._p(stars), covpts, e._p(tab),
+                                               e._p(mv), 0, 1, 20, ctypes.c_double(0.023), ws_p, e._p(out), e._p(yb),
+                                               e._p(mb), None, e._stream())
+
+    assert sweep() == 0
+    assert sweep(M_=0) == -1
+    assert sweep(K_=1) == -1
+    assert sweep(ws_p=None) == -1
+    assert sweep(covpts=123) == -4                     # the table was built for another lag grid: SP_ERR_STATE
+    assert sweep(S_=0) == 0
+    assert L.sp_lnlike_grad_workspace_bytes_multi(e._h, 1, 40, 0, 300) == 0
+    assert L.sp_lnlike_grad_workspace_bytes_multi(e._h, 1, 40, 3, 300) > L.sp_lnlike_grad_workspace_bytes(e._h, 1, 40, 300)
+    torch.cuda.synchronize()
