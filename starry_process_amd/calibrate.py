@@ -140,13 +140,15 @@ class EnsembleLogProb(object):
     (an event per sample): the quadrature is a chain of a dozen small kernels, 0.3-0.4 ms of
     latency per sample that a likelihood stream would otherwise sit through with its share of
     the GPU idle: 0.726 -> 0.69 ms per sample with three likelihood streams + this one (a fifth stream in
-    flight loses more than it hides: 0.83 -- the same cliff bench.py sees at five steps in flight).  Under an initialised
+    flight loses more than it hides: 0.83 -- the same cliff bench.py sees at five steps in flight; round 5, one box,
+    tools/elp_modes.py: 0.584 as shipped, 0.603 with the moments on the three likelihood streams themselves
+    (upstream_stream=False), 0.699 on four of them, 0.818 with four + the upstream's own).  Under an initialised
     ``torch.distributed`` job the stars are sharded over the ranks and the per-sample sums are
     combined with ONE all-reduce for the whole batch."""
 
     def __init__(self, t, flux, ferr=1.0e-3, p=1.0, i=None, u=None, ydeg=15, baseline_log_var=0.0,
                  baseline_mean=0.0, apply_jac=True, normalized=True,
-                 marginalize_over_inclination=True, covpts=None, device=None, depth=3):
+                 marginalize_over_inclination=True, covpts=None, device=None, depth=3, upstream_stream=True):
         import torch
         import torch.distributed as dist
 
@@ -183,6 +185,7 @@ class EnsembleLogProb(object):
                            data_var=per(np.asarray(ferr, dtype=np.float64) ** 2, 1.0), table=table)
         slots = engine_slots(ydeg, udeg, device, max(2, int(depth) + 1))
         self._slots, self._up = slots[:-1], slots[-1]          # likelihood slots; the upstream's own engine + stream
+        self._upstream_stream = bool(upstream_stream)          # False: a sample's moments on its likelihood stream
         e0 = self._slots[0][0]
         self._t = e0.f64(np.ascontiguousarray(t[lo:hi]))
         self._flux = e0.f64(np.ascontiguousarray(flux[lo:hi, None, :]))
@@ -220,14 +223,19 @@ class EnsembleLogProb(object):
             eu, su = self._up
             keep = []                                   # (the moments stay alive until the batch is done)
             for k, (r, a, b, c, n) in enumerate(samples):
-                with torch.cuda.stream(su):
-                    mean, cov = ylm_moments_device(eu, r=r, a=a, b=b, c=c, n=n)
-                    ready = torch.cuda.Event()
-                    ready.record(su)
-                keep.append((mean, cov, ready))
                 e, stream = self._slots[k % len(self._slots)]
+                if self._upstream_stream:
+                    with torch.cuda.stream(su):
+                        mean, cov = ylm_moments_device(eu, r=r, a=a, b=b, c=c, n=n)
+                        ready = torch.cuda.Event()
+                        ready.record(su)
+                    keep.append((mean, cov, ready))
                 with torch.cuda.stream(stream):
-                    stream.wait_event(ready)
+                    if self._upstream_stream:
+                        stream.wait_event(ready)
+                    else:
+                        mean, cov = ylm_moments_device(e, r=r, a=a, b=b, c=c, n=n)
+                        keep.append((mean, cov))
                     e.set_moments_dev(mean, cov)
                     tab = mv = None
                     if self._marg:
