@@ -161,6 +161,31 @@ int sp_kernel_table(sp_handle *h, const double *rta1_dev, int ntab, int covpts,
                     const double *xp_host, double *tab_dev,
                     double *meanvar_dev, void *stream);
 
+/* ---- hyperparameter samples in batches (round 6) ----------------------------
+ * A sampler evaluates ONE data set at many hyperparameter vectors -- one light curve per log_likelihood call
+ * (sp.py:1052-1062), called 10^4-10^5 times (calibrate/sample.py:95-107, interfaces.py:142-166).  These two entry
+ * points take B samples per call, so that a single light curve fills the GPU like a 64-star ensemble does:
+ *   sp_polar_moments_samples   (r, alpha, beta, c, n)[B] -> ez [B][N], Ez [B][N][N]: the polar-frame moments of
+ *       flux.py:54-62 (row a4) of the Ylm process of sp.py:257-266 with ONE spot radius (dr = None) -- the chain
+ *       size.py:49-101 -> latitude.py:170-212 -> longitude.py:8-78 -> contrast.py:18-33 by exact quadrature of
+ *       rotations like sp_ylm_moments_quadrature, carried out in the polar frame where the longitude average is a
+ *       projection (csrc/sp_samples.hip): 2 (ydeg + 2) rotations per sample, one upload of 5 B numbers, six launches,
+ *       no host arithmetic (the Gauss-Jacobi rule is found on the device).  Equal to sp_ylm_moments_quadrature +
+ *       sp_set_ylm_moments_dev to rounding; B samples in one call give the bits of B calls with one sample each.
+ *       samples_host [B][5]: r in RADIANS, alpha, beta (the Beta law's shape parameters, latitude.py:176-197), c, n.
+ *       Needs sp_set_size_basis first (the spot profile's basis, size.py:9-47: theta [spts] = the colatitude grid,
+ *       Bp [ydeg + 1][spts] = the smoothed pseudo-inverse of the Legendre basis, sfac = the sigmoid's steepness).
+ *   sp_kernel_table_samples    sp_kernel_table for B sets of polar moments: table b ntab + i (tab_dev
+ *       [B ntab][5][covpts + 4], meanvar_dev [B ntab][2]) from sample b and flux operator i.
+ * The likelihood of the (sample, star) pairs is then ONE sp_lnlike_ensemble_planned call on a replicated plan
+ * (sp_plan_replicate below) whose stars carry table = b ntab + table_s.                                       */
+int sp_set_size_basis(sp_handle *h, const double *theta_host, const double *Bp_host, int spts, double sfac);
+int sp_polar_moments_samples(sp_handle *h, int B, const double *samples_host, double epsy, double epsy15,
+                             double *ez_dev, double *Ez_dev, void *stream);
+int sp_kernel_table_samples(sp_handle *h, int B, const double *ez_dev, const double *Ez_dev, const double *rta1_dev,
+                            int ntab, int covpts, const double *xp_host, double *tab_dev, double *meanvar_dev,
+                            void *stream);
+
 /* ---- per-star parameter block -------------------------------------------- */
 /* All batched entry points below take `S` stars with a common row length K.  A
  * RAGGED ensemble (light curves of different lengths) is padded to the longest:
@@ -301,9 +326,19 @@ int sp_plan_data(sp_handle *h, int S, int K, int M, const double *t_dev, const d
 void sp_plan_destroy(sp_plan *plan);
 /* wbar of the plan, [S, covpts + 4] (host; for tests) */
 int sp_plan_get_wbar(const sp_plan *plan, double *wbar_host);
-/* The per-sample call on planned data: marginal branch, normalised (sp.py:1129-1188 with sp.py:705-727).  The
- * data pointers must be the planned ones' contents (t, flux, diag are read again: residual rows, temporal
- * factors, variances); shapes, covpts and the temporal kernel come from the plan.                          */
+/* B copies of a planned data set as ONE batch of B S systems (round 6): system b S + s is star s of `src`, to be
+ * evaluated under hyperparameter sample b (its sp_star.table = b ntab + table_s).  The replica owns copies of
+ * everything the step reads by system index -- the plan's arrays and the data (t, flux, variances): B (K (M + 2) +
+ * covpts + M + 9) doubles, 1.6 MB for 64 samples of one K = 1000 light curve.  Call the planned step on it WITHOUT
+ * data pointers.  Synchronises `stream`.                                                                  */
+int sp_plan_replicate(sp_handle *h, const sp_plan *src, int B, void *stream, sp_plan **out);
+/* systems of a plan (S of sp_plan_data; B S of a replica) */
+int sp_plan_systems(const sp_plan *plan);
+/* The per-sample call on planned data: marginal branch, normalised (sp.py:1129-1188 with sp.py:705-727).
+ * t_dev / flux_dev / diag_dev: all NULL = the planned arrays (required for a replica), otherwise they must BE the
+ * pointers given to sp_plan_data (SP_ERR_INVALID if not: phases, weights and sums come from plan time, residual rows
+ * and variances are read again from these -- other arrays of the same shape would give a finite, wrong value; edits
+ * IN PLACE remain the caller's responsibility).  Shapes, covpts and the temporal kernel come from the plan.  */
 int sp_lnlike_ensemble_planned(sp_handle *h, const sp_plan *plan, const double *t_dev, const double *flux_dev,
                                const double *diag_dev, const sp_star *stars_dev, const double *tab_dev,
                                const double *meanvar_dev, int norm_order, double zmax, void *workspace_dev,

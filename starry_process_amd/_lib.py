@@ -131,6 +131,11 @@ PROTOTYPES = {
     "sp_cholesky_lnlike_batched": (_I, [_V, _I, _I, _I, _V, _V, _V, _V, _V, _V]),
     "sp_plan_data": (_I, [_V, _I, _I, _I, _V, _V, _V, _V, _I, _I, _V, _V, ctypes.POINTER(_V)]),
     "sp_plan_destroy": (None, [_V]),
+    "sp_plan_replicate": (_I, [_V, _V, _I, _V, ctypes.POINTER(_V)]),
+    "sp_plan_systems": (_I, [_V]),
+    "sp_set_size_basis": (_I, [_V, _V, _V, _I, _D]),
+    "sp_polar_moments_samples": (_I, [_V, _I, _V, _D, _D, _V, _V, _V]),
+    "sp_kernel_table_samples": (_I, [_V, _I, _V, _V, _V, _I, _I, _V, _V, _V, _V]),
     "sp_plan_get_wbar": (_I, [_V, _V]),
     "sp_lnlike_ensemble_planned": (_I, [_V, _V, _V, _V, _V, _V, _V, _V, _I, _D, _V, _V, _V, _V]),
 }

@@ -26,7 +26,103 @@ import numpy as np
 
 from .sp import StarryProcess
 
-__all__ = ["get_log_prob", "get_log_prob_ensemble", "EnsembleLogProb"]
+__all__ = ["get_log_prob", "get_log_prob_ensemble", "EnsembleLogProb", "SampleBatches", "MAX_STREAMS"]
+
+# Independent evaluations in flight on one GPU.  Four is where the throughput peaks; a fifth stream LOSES 10-25 %
+# (108k against 120k evaluations/s at cfg3's shape, bench.py; EnsembleLogProb 0.584 -> 0.818 ms per sample with
+# four likelihood streams + the upstream's own, tools/elp_modes.py, round 5) -- next to GPU_MAX_HW_QUEUES
+# (engine._want_hw_queues).  Callers' ``depth`` is clamped to it, with one warning.
+MAX_STREAMS = 4
+_warned_depth = [False]
+
+
+def clamp_depth(depth, extra_streams=0):
+    """``depth`` likelihood streams + ``extra_streams`` others, held to MAX_STREAMS concurrent streams."""
+    import warnings
+
+    depth = max(1, int(depth))
+    allowed = max(1, MAX_STREAMS - int(extra_streams))
+    if depth > allowed:
+        if not _warned_depth[0]:
+            warnings.warn("starry_process_amd: depth=%d (+%d) exceeds %d concurrent streams, beyond which the GPU's "
+                          "throughput DROPS by 10-25 %% (measured); using depth=%d" % (depth, extra_streams, MAX_STREAMS,
+                                                                                      allowed), RuntimeWarning, stacklevel=3)
+            _warned_depth[0] = True
+        depth = allowed
+    return depth
+
+
+class SampleBatches(object):
+    """log-likelihoods of MANY hyperparameter samples for ONE planned data set, ``group`` samples per library call:
+
+        lnl[b, s] = log_likelihood of star s under sample b = (r, a, b, c, n),        samples (ns, 5) -> (ns, S)
+
+    The systems of a call are (sample, star) pairs, ``group`` x S of them (about 64: what fills the GPU): the samples'
+    polar moments (sp_polar_moments_samples), their kernel tables (sp_kernel_table_samples) and ONE planned likelihood
+    call on a replicated data plan (sp_plan_replicate) whose stars carry the table of their sample.  A single light
+    curve -- how the reference is called, sp.py:1052-1062 driven by calibrate/sample.py:95-107 -- then runs at the
+    rate of a 64-star ensemble instead of one latency-bound step per sample.  Marginal, normalised branch, one spot
+    radius (dr = None); consecutive groups go to the slots' streams in turn."""
+
+    def __init__(self, slots, t_dev, flux_dev, stars, rta1_dev, covpts, diag_dev=None, temporal=None, group=None,
+                 norm_order=20, zmax=0.023, upstream_kwargs=None, plan=None):
+        import torch
+
+        from .engine import stars_for_samples
+
+        self._slots = slots
+        e0 = slots[0][0]
+        self.S, self.K = int(t_dev.shape[0]), int(t_dev.shape[1])
+        self.M = int(flux_dev.shape[1])
+        self.group = max(1, int(group) if group else -(-64 // self.S))
+        self._ntab = int(rta1_dev.shape[0])
+        self._rta1, self._covpts = rta1_dev, int(covpts)
+        self._norm_order, self._zmax = int(norm_order), float(zmax)
+        self._ukw = dict(upstream_kwargs or {})
+        n = self.group * self.S
+        stars_d = e0.stars_to_device(stars)
+        self._base_plan = plan if plan is not None else e0.plan_data(t_dev, flux_dev, stars_d, diag=diag_dev,
+                                                                      covpts=self._covpts, temporal=temporal)
+        self._plan = e0.replicate_plan(self._base_plan, self.group)
+        self._stars = e0.stars_to_device(stars_for_samples(stars, self.group, self._ntab))
+        self._buf = []
+        for e, _ in slots:
+            self._buf.append(dict(ws=e.workspace(n, self.K, self.M), ez=e.empty(self.group, e.N),
+                                  Ez=e.empty(self.group, e.N, e.N),
+                                  tab=e.empty(self.group * self._ntab, 5, self._covpts + 4),
+                                  mv=e.empty(self.group * self._ntab, 2)))
+            e.set_size_basis(**self._ukw)
+        torch.cuda.synchronize(e0.device)
+
+    def __call__(self, samples, out=None):
+        """samples (ns, 5) -> device tensor (ns, S); nothing is synchronised: the caller does, once."""
+        import torch
+
+        samples = np.atleast_2d(np.asarray(samples, dtype=np.float64))
+        ns, g, S = samples.shape[0], self.group, self.S
+        ngroups = -(-ns // g)
+        e0 = self._slots[0][0]
+        raw = e0.empty(ngroups, g * S)
+        if ns < ngroups * g:          # (the last group is filled up with its own last sample; those values are dropped)
+            samples = np.vstack([samples, np.repeat(samples[-1:], ngroups * g - ns, axis=0)])
+        cur = torch.cuda.current_stream(e0.device)
+        start = torch.cuda.Event()
+        start.record(cur)
+        for gi in range(ngroups):
+            k = gi % len(self._slots)
+            (e, stream), b = self._slots[k], self._buf[k]
+            with torch.cuda.stream(stream):
+                if gi < len(self._slots):
+                    stream.wait_event(start)
+                e.polar_moments_samples(samples[gi * g:(gi + 1) * g], ez=b["ez"], Ez=b["Ez"], **self._ukw)
+                e.kernel_table_samples(b["ez"], b["Ez"], self._rta1, self._covpts, tab=b["tab"], meanvar=b["mv"])
+                e.lnlike_ensemble_planned(self._plan, None, None, self._stars, b["tab"], b["mv"],
+                                          norm_order=self._norm_order, zmax=self._zmax, out=raw[gi], workspace=b["ws"])
+        for k in range(min(ngroups, len(self._slots))):
+            done = torch.cuda.Event()
+            done.record(self._slots[k][1])
+            cur.wait_event(done)
+        return raw.view(ngroups * g, S)[:ns]
 
 
 def get_log_prob(
@@ -148,7 +244,8 @@ class EnsembleLogProb(object):
 
     def __init__(self, t, flux, ferr=1.0e-3, p=1.0, i=None, u=None, ydeg=15, baseline_log_var=0.0,
                  baseline_mean=0.0, apply_jac=True, normalized=True,
-                 marginalize_over_inclination=True, covpts=None, device=None, depth=3, upstream_stream=True):
+                 marginalize_over_inclination=True, covpts=None, device=None, depth=3, upstream_stream=True,
+                 batch_samples=True):
         import torch
         import torch.distributed as dist
 
@@ -183,7 +280,9 @@ class EnsembleLogProb(object):
                            baseline_var=np.full(hi - lo, 10.0 ** baseline_log_var),
                            baseline_mean=per(baseline_mean, 0.0),
                            data_var=per(np.asarray(ferr, dtype=np.float64) ** 2, 1.0), table=table)
-        slots = engine_slots(ydeg, udeg, device, max(2, int(depth) + 1))
+        # (depth likelihood streams + the upstream's own: never more than MAX_STREAMS concurrent streams)
+        depth = clamp_depth(depth, 1)
+        slots = engine_slots(ydeg, udeg, device, max(2, depth + 1))
         self._slots, self._up = slots[:-1], slots[-1]          # likelihood slots; the upstream's own engine + stream
         self._upstream_stream = bool(upstream_stream)          # False: a sample's moments on its likelihood stream
         e0 = self._slots[0][0]
@@ -200,9 +299,21 @@ class EnsembleLogProb(object):
         # alone -- phases, the kernel table's weights in the covariance's sum, the sums of the flux -- is taken once
         # (sp_plan_data), and every sample goes through the planned call: no pass over the K^2 entries of every
         # star's covariance before its factorisation.  One plan, read-only, shared by the slots.
-        self._plan = None
+        self._plan = self._batch = None
         if self._marg and normalized and hi - lo > 0 and K >= 2:
-            self._plan = e0.plan_data(self._t, self._flux, self._stars, covpts=self._kw["covpts"], workspace=self._ws[0])
+            from ._lib import SPError
+
+            try:
+                self._plan = e0.plan_data(self._t, self._flux, self._stars, covpts=self._kw["covpts"], workspace=self._ws[0])
+            except SPError:
+                # (a shape the planned step does not serve -- e.g. a lag grid beyond its LDS budget, covpts > ~4 700:
+                #  the unplanned call has the fallbacks)
+                self._plan = None
+        # Fewer than 64 stars (one light curve above all): samples are packed ceil(64 / S) to a library call
+        # (SampleBatches) -- the GPU sees 64 systems per step whatever S is.
+        if self._plan is not None and batch_samples and hi - lo < 64:
+            self._batch = SampleBatches(self._slots + [self._up], self._t, self._flux, stars, self._rta1,
+                                        self._kw["covpts"], plan=self._plan, zmax=0.023)
         torch.cuda.synchronize(e0.device)
 
     def __call__(self, samples):
@@ -219,7 +330,9 @@ class EnsembleLogProb(object):
         e0 = self._slots[0][0]
         outs = e0.empty(ns, max(nl, 1))
         torch.cuda.synchronize(e0.device)
-        if nl:
+        if nl and self._batch is not None:
+            outs = self._batch(samples)
+        elif nl:
             eu, su = self._up
             keep = []                                   # (the moments stay alive until the batch is done)
             for k, (r, a, b, c, n) in enumerate(samples):
@@ -256,5 +369,7 @@ class EnsembleLogProb(object):
             dist.all_reduce(total, op=dist.ReduceOp.SUM)
         total = total.cpu().numpy()
         if self._apply_jac:
-            total = total + np.array([float(log_jac(a, b)) for _, a, b, _, _ in samples])
+            from .upstream import log_jac_samples
+
+            total = total + log_jac_samples(samples[:, 1], samples[:, 2])
         return total

@@ -14,7 +14,8 @@
 // launchers defined in the other translation units
 int sp_launch_kernel_table(sp_handle *h, const double *rta1_dev, int ntab,
                            int covpts, const double *xp_dev, double *tab_dev,
-                           double *meanvar_dev, hipStream_t st);
+                           double *meanvar_dev, hipStream_t st, int nsets = 0, const double *ez_dev = nullptr,
+                           const double *Ez_dev = nullptr);
 int sp_launch_theta(int S, int K, const double *t, const sp_star *stars,
                     double *theta, hipStream_t st, int32_t *info = nullptr,
                     uint32_t *status = nullptr, const double *tab = nullptr, int covpts = 0,
@@ -608,6 +609,9 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
   h->d_Rxm90 = nullptr;
   h->d_lamcs = nullptr;
   h->lamcs_Q = 0;
+  h->d_size_basis = nullptr;
+  h->size_spts = 0;
+  h->size_sfac = 0.0;
   const int N = h->N;
   h->l_of.resize(N);
   h->m_of.resize(N);
@@ -686,7 +690,8 @@ void sp_destroy(sp_handle *h) {
   (void)hipDeviceSynchronize();
   void *ptrs[] = {h->d_l_of, h->d_m_of,   h->d_mirror, h->d_blk,   h->d_Rx90,
                   h->d_wnp,  h->d_Wnp,    h->d_mean_ylm, h->d_cov_ylm, h->d_ez,
-                  h->d_Ez,   h->d_tmpNN,  h->d_scratch, h->d_xp, h->d_tab_scratch, h->d_Rxm90, h->d_lamcs};
+                  h->d_Ez,   h->d_tmpNN,  h->d_scratch, h->d_xp, h->d_tab_scratch, h->d_Rxm90, h->d_lamcs,
+                  h->d_size_basis};
   for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->gdone) (void)hipEventDestroy(e);
   for (hipStream_t s2 : h->gstream) (void)hipStreamDestroy(s2);
@@ -893,6 +898,26 @@ int sp_get_polar_moments(sp_handle *h, double *ez, double *Ez) {
   return SP_OK;
 }
 
+// the lag grid of the kernel table on the device: uploaded when it changes (sp_kernel_table, sp_kernel_table_samples)
+int sp_ensure_lag_grid(sp_handle *h, int covpts, const double *xp_host) {
+  const int np = covpts + 4;
+  const bool same = h->xp_covpts == covpts && (int)h->xp_host.size() == np &&
+                    memcmp(h->xp_host.data(), xp_host, sizeof(double) * np) == 0;
+  if (same) return SP_OK;
+  // new lag grid: (re)allocate and upload once; later calls with the same
+  // grid are fully asynchronous
+  SP_HIP(hipSetDevice(h->device));
+  SP_HIP(hipDeviceSynchronize());
+  if (h->d_xp) SP_HIP(hipFree(h->d_xp));
+  h->d_xp = nullptr;
+  h->xp_covpts = -1;
+  SP_HIP(hipMalloc((void **)&h->d_xp, sizeof(double) * np));
+  SP_HIP(hipMemcpy(h->d_xp, xp_host, sizeof(double) * np, hipMemcpyHostToDevice));
+  h->xp_host.assign(xp_host, xp_host + np);
+  h->xp_covpts = covpts;
+  return SP_OK;
+}
+
 int sp_kernel_table(sp_handle *h, const double *rta1_dev, int ntab, int covpts,
                     const double *xp_host, double *tab_dev, double *meanvar_dev,
                     void *stream) {
@@ -902,23 +927,26 @@ int sp_kernel_table(sp_handle *h, const double *rta1_dev, int ntab, int covpts,
     return SP_ERR_INVALID;
   if (!h->have_marginal || !h->have_moments) return SP_ERR_STATE;
   if (ntab == 0) return SP_OK;
-  const int np = covpts + 4;
-  const bool same = h->xp_covpts == covpts && (int)h->xp_host.size() == np &&
-                    memcmp(h->xp_host.data(), xp_host, sizeof(double) * np) == 0;
-  if (!same) {
-    // new lag grid: (re)allocate and upload once; later calls with the same
-    // grid are fully asynchronous
-    SP_HIP(hipDeviceSynchronize());
-    if (h->d_xp) SP_HIP(hipFree(h->d_xp));
-    h->d_xp = nullptr;
-    h->xp_covpts = -1;
-    SP_HIP(hipMalloc((void **)&h->d_xp, sizeof(double) * np));
-    SP_HIP(hipMemcpy(h->d_xp, xp_host, sizeof(double) * np, hipMemcpyHostToDevice));
-    h->xp_host.assign(xp_host, xp_host + np);
-    h->xp_covpts = covpts;
-  }
+  int rc = sp_ensure_lag_grid(h, covpts, xp_host);
+  if (rc) return rc;
   return sp_launch_kernel_table(h, rta1_dev, ntab, covpts, h->d_xp, tab_dev,
                                 meanvar_dev, (hipStream_t)stream);
+}
+
+// The kernel tables of B hyperparameter samples in one call (round 6): polar-frame moments ez [B][N], Ez [B][N][N]
+// given (sp_polar_moments_samples), table b ntab + i from sample b's moments and flux operator i.
+int sp_kernel_table_samples(sp_handle *h, int B, const double *ez_dev, const double *Ez_dev, const double *rta1_dev,
+                            int ntab, int covpts, const double *xp_host, double *tab_dev, double *meanvar_dev,
+                            void *stream) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || !ez_dev || !Ez_dev || !rta1_dev || !xp_host || !tab_dev || !meanvar_dev || ntab < 0 || covpts < 1 || B < 0)
+    return SP_ERR_INVALID;
+  if (!h->have_marginal) return SP_ERR_STATE;
+  if (ntab == 0 || B == 0) return SP_OK;
+  int rc = sp_ensure_lag_grid(h, covpts, xp_host);
+  if (rc) return rc;
+  return sp_launch_kernel_table(h, rta1_dev, ntab, covpts, h->d_xp, tab_dev, meanvar_dev, (hipStream_t)stream, B,
+                                ez_dev, Ez_dev);
 }
 
 int sp_cov_marginal_batched(sp_handle *h, int S, int K, const double *t_dev,
@@ -1240,10 +1268,20 @@ int sp_lnlike_ensemble_planned(sp_handle *h, const sp_plan *plan, const double *
                                const double *meanvar_dev, int norm_order, double zmax, void *workspace_dev,
                                double *lnlike_dev, uint32_t *status_dev, void *stream) {
   if (h && h->device < 0) return SP_ERR_NO_DEVICE;
-  if (!h || !plan || !t_dev || !flux_dev || !stars_dev || !tab_dev || !meanvar_dev || !workspace_dev || !lnlike_dev ||
+  if (!h || !plan || !stars_dev || !tab_dev || !meanvar_dev || !workspace_dev || !lnlike_dev ||
       norm_order < 0 || norm_order > SP_NORM_MAXORDER)
     return SP_ERR_INVALID;
-  if (plan->device != h->device || (diag_dev != nullptr) != (plan->has_diag != 0)) return SP_ERR_INVALID;
+  if (plan->device != h->device) return SP_ERR_INVALID;
+  // The data are the plan's: no data pointers at all = the planned ones (a replica's own copies, sp_plan_replicate);
+  // pointers given must BE the planned ones -- the plan's phases, weights and sums come from the arrays of plan time,
+  // residual rows and variances from these: another tensor of the same shape would give a finite, wrong value.
+  if (!t_dev && !flux_dev && !diag_dev) {
+    t_dev = plan->t;
+    flux_dev = plan->flux;
+    diag_dev = plan->diag;
+  } else if (t_dev != plan->t || flux_dev != plan->flux || diag_dev != plan->diag) {
+    return SP_ERR_INVALID;
+  }
   const int S = plan->S, K = plan->K, M = plan->M, covpts = plan->covpts, temporal = plan->temporal;
   if (h->xp_covpts != covpts) return SP_ERR_STATE;
   hipStream_t st = (hipStream_t)stream;

@@ -32,6 +32,9 @@ struct sp_handle {
   double *d_Rxm90;              // packed Rx(-pi/2) (sp_upstream.hip; first use)
   double *d_lamcs;              // cos / sin (m lam_q) of the lamcs_Q equispaced longitudes (sp_upstream.hip)
   int lamcs_Q;
+  double *d_size_basis;         // spot-size basis Bp [ydeg + 1][spts], then the colatitude grid [spts] (sp_set_size_basis)
+  int size_spts;
+  double size_sfac;
   double *d_wnp, *d_Wnp;        // marginalisation constants (flux.py:121-179)
   bool have_marginal;
   double *d_xp;                 // lag grid of the last kernel table
@@ -221,6 +224,10 @@ struct sp_plan {
   void *buf;               // one device allocation behind the pointers of `dev`
   size_t bytes;
   PlanDev dev;
+  // the data the plan was made from: the caller's arrays (sp_plan_data) or the plan's own copies (sp_plan_replicate;
+  // then part of `buf`).  sp_lnlike_ensemble_planned reads THESE when it is given no data pointers and refuses others.
+  const double *t, *flux, *diag;
+  int nrep;                // sp_plan_replicate: S = nrep x the source plan's stars (0: not a replica)
 };
 
 // What the workgroup that factors a group's LAST pivot block does behind it (sp_panel.hip): the

@@ -169,10 +169,13 @@ int sp_plan_data(sp_handle *h, int S, int K, int M, const double *t_dev, const d
   // (the systems are the last region of the workspace: S Kp'^2 doubles with Kp' >= Kp)
   double *partial = reinterpret_cast<double *>(static_cast<char *>(workspace_dev) + (size_t)ws_bytes) - (size_t)S * Kp * Kp;
 
+  // (the plan's buffer lives on the HANDLE's GPU whatever the caller's current device is)
+  SP_HIP(hipSetDevice(h->device));
   sp_plan *p = new (std::nothrow) sp_plan();
   if (!p) return SP_ERR_ALLOC;
   p->device = h->device;
   p->S = S; p->K = K; p->M = M; p->covpts = covpts; p->temporal = temporal; p->has_diag = diag_dev != nullptr;
+  p->t = t_dev; p->flux = flux_dev; p->diag = diag_dev; p->nrep = 0;
   const size_t d = sizeof(double);
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t o_theta = 0, o_wbar = o_theta + up(d * S * K), o_sflux = o_wbar + up(d * S * np),
@@ -225,6 +228,76 @@ int sp_plan_data(sp_handle *h, int S, int K, int M, const double *t_dev, const d
   *out = p;
   return SP_OK;
 }
+
+// B copies of a planned data set as ONE batch of B S systems (round 6: hyperparameter samples batched into the planned
+// call -- system b S + s is star s of the source under sample b).  The replica owns copies of everything the step reads
+// by system index: the plan's arrays and the data (t, flux, variances).  A data INDEX in the kernels instead would cost
+// the panel kernel's lazy instantiations scalar registers they do not have (106 of 106 SGPRs, sp_panel.hip); the copies
+// are B (K (M + 2) + covpts + M + 9) doubles -- 1.6 MB for 64 samples of a K = 1000 light curve, against 0.5 GB of systems.
+namespace {
+__global__ __launch_bounds__(256) void replicate_kernel(const double *__restrict__ src, long n, double *__restrict__ dst) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[(size_t)blockIdx.y * n + i] = src[i];
+}
+}  // namespace
+
+int sp_plan_replicate(sp_handle *h, const sp_plan *src, int B, void *stream, sp_plan **out) {
+  if (h && h->device < 0) return SP_ERR_NO_DEVICE;
+  if (!h || !src || !out || B < 1 || B > 65535 || src->device != h->device || (long)src->S * B > (1L << 24))
+    return SP_ERR_INVALID;
+  *out = nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  SP_HIP(hipSetDevice(h->device));
+  sp_plan *p = new (std::nothrow) sp_plan(*src);
+  if (!p) return SP_ERR_ALLOC;
+  const int S0 = src->S, K = src->K, M = src->M, np = src->covpts + 4;
+  p->S = S0 * B;
+  p->nrep = B;
+  p->buf = nullptr;
+  const size_t d = sizeof(double), S = (size_t)p->S;
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t o_theta = 0, o_wbar = o_theta + up(d * S * K), o_sflux = o_wbar + up(d * S * np),
+               o_sdv = o_sflux + up(d * S * M), o_key = o_sdv + up(d * S), o_ord = o_key + up(d * S * 3),
+               o_t = o_ord + up(d * S), o_flux = o_t + up(d * S * K), o_diag = o_flux + up(d * S * M * K),
+               total = o_diag + (src->has_diag ? up(d * S * K) : 0);
+  p->bytes = total;
+  hipError_t e = hipMalloc(&p->buf, total);
+  if (e != hipSuccess) {
+    sp_set_hip_error(e, "hipMalloc(plan replica)");
+    delete p;
+    return SP_ERR_ALLOC;
+  }
+  char *base = static_cast<char *>(p->buf);
+  auto at = [&](size_t o) { return reinterpret_cast<double *>(base + o); };
+  p->dev = PlanDev{at(o_theta), at(o_wbar), at(o_sflux), at(o_sdv), at(o_key), at(o_ord)};
+  p->t = at(o_t);
+  p->flux = at(o_flux);
+  p->diag = src->has_diag ? at(o_diag) : nullptr;
+  auto rep = [&](const double *from, size_t n, double *to) {
+    hipLaunchKernelGGL(replicate_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, st, from, (long)n, to);
+  };
+  rep(src->dev.theta, (size_t)S0 * K, at(o_theta));
+  rep(src->dev.wbar, (size_t)S0 * np, at(o_wbar));
+  rep(src->dev.sflux, (size_t)S0 * M, at(o_sflux));
+  rep(src->dev.sdv, (size_t)S0, at(o_sdv));
+  rep(src->dev.key, (size_t)S0 * 3, at(o_key));
+  rep(src->dev.inorder, (size_t)S0, at(o_ord));
+  rep(src->t, (size_t)S0 * K, at(o_t));
+  rep(src->flux, (size_t)S0 * M * K, at(o_flux));
+  if (src->has_diag) rep(src->diag, (size_t)S0 * K, at(o_diag));
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) {
+    sp_set_hip_error(e, "sp_plan_replicate");
+    (void)hipFree(p->buf);
+    delete p;
+    return SP_ERR_HIP;
+  }
+  *out = p;
+  return SP_OK;
+}
+
+int sp_plan_systems(const sp_plan *plan) { return plan ? plan->S : SP_ERR_INVALID; }
 
 void sp_plan_destroy(sp_plan *plan) {
   if (!plan) return;

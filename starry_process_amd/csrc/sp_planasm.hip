@@ -61,7 +61,9 @@ __global__ __launch_bounds__(256, SP_PLAN_OCC) void assemble_planned_kernel(
   const int np = covpts + 4, tid = threadIdx.x;
   const sp_star st = stars[s];
   const int t0 = chunks.start[chunk], t1 = chunks.start[chunk + 1];
-  if (t0 >= t1 && chunk != 0) return;
+  // (an empty chunk has nothing to do -- unless it is the star's LAST one, which writes the riding rows below:
+  //  SP_PLAN_TILES=1 can leave that chunk without tiles)
+  if (t0 >= t1 && chunk != 0 && !(rid && chunk == nchunk - 1)) return;
   double *s_tab = lds;                       // 4 np
   double *s_red = s_tab + 4 * np;            // 8
   double *s_th = s_red + 8;                  // [Kp] the star's phases (zero beyond K)            (lds_phases)

@@ -29,7 +29,8 @@ __device__ __forceinline__ double block_sum(double v, double *red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-// rows of W o Ez: grid (ceil(N/4), ntab), one wavefront per row n
+// rows of W o Ez: grid (ceil(N/4), ntab, nsets), one wavefront per row n; set b = blockIdx.z has its own polar moments
+// (Ez + b N^2, ez + b N: the hyperparameter samples of a batch, sp_kernel_table_samples) and writes table b ntab + blockIdx.y
 //   r1[n] = sum_j W[n,j] Ez[n,j],  r2[n] = sum_j W[n,j] Ez[n,mirror(j)],
 //   W[n,j] = Wnp[n,j] * rTA1[m0(l_n)] * rTA1[m0(l_j)]          (flux.py:199-209)
 // and the row's term of the first moment (flux.py:196-198, 297-300), which table_finish_kernel used to take
@@ -44,6 +45,8 @@ __global__ __launch_bounds__(256) void table_rows_kernel(
   const int n = blockIdx.x * 4 + wave;
   if (n >= N) return;
   const double *rta1 = rta1_all + (size_t)blockIdx.y * N;
+  Ez += (size_t)blockIdx.z * N * N;
+  ez += (size_t)blockIdx.z * N;
   const int ln = l_of[n];
   const double rn = rta1[ln * ln + ln];
   const double *Wn = Wnp + (size_t)n * N, *En = Ez + (size_t)n * N;
@@ -60,14 +63,14 @@ __global__ __launch_bounds__(256) void table_rows_kernel(
   double m1 = lane < w ? rta1[ln * ln + lane] * wnp[blk[ln] + lane * w + (n - ln * ln)] : 0.0;   // (2 ydeg + 1 <= 64)
   m1 = wave_sum(m1);
   if (lane == 0) {
-    double *rows = rows_all + (size_t)blockIdx.y * 3 * N;
+    double *rows = rows_all + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * 3 * N;
     rows[n] = a;
     rows[N + n] = b;
     rows[2 * N + n] = m1 * ez[n];
   }
 }
 
-// one workgroup per table: mean, variance, harmonics, lag grid, spline
+// one workgroup per table: mean, variance, harmonics, lag grid, spline.  grid (ntab, nsets): table blockIdx.y ntab + blockIdx.x
 __global__ __launch_bounds__(256) void table_finish_kernel(
     int ydeg, int N, const int32_t *__restrict__ l_of, const int32_t *__restrict__ blk,
     const double *__restrict__ wnp, const double *__restrict__ ez,
@@ -84,9 +87,10 @@ __global__ __launch_bounds__(256) void table_finish_kernel(
   double *s_red = s_sa + ydeg + 1;  // 4
   const int tid = threadIdx.x;
   const int np = covpts + 4;
+  const size_t it = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
   const double *rta1 = rta1_all + (size_t)blockIdx.x * N;
-  const double *rows = rows_all + (size_t)blockIdx.x * 3 * N;
-  double *tab = tab_all + (size_t)blockIdx.x * 5 * np;
+  const double *rows = rows_all + it * 3 * N;
+  double *tab = tab_all + it * 5 * np;
 
   for (int n = tid; n < N; n += 256) {
     s_rta1[n] = rta1[n];
@@ -105,8 +109,8 @@ __global__ __launch_bounds__(256) void table_finish_kernel(
   for (int n = tid; n < N; n += 256) pv += s_r1[n];
   const double wez = block_sum(pv, s_red);
   if (tid == 0) {
-    meanvar_all[2 * blockIdx.x] = mean;
-    meanvar_all[2 * blockIdx.x + 1] = wez - mean * mean;
+    meanvar_all[2 * it] = mean;
+    meanvar_all[2 * it + 1] = wez - mean * mean;
   }
 
   // harmonic coefficients
@@ -169,14 +173,20 @@ __global__ __launch_bounds__(256) void table_finish_kernel(
 
 }  // namespace
 
+// nsets == 0: the handle's resident polar moments (sp_kernel_table); nsets >= 1: ez [nsets][N], Ez [nsets][N][N] given
+// (sp_kernel_table_samples), tables [nsets ntab]
 int sp_launch_kernel_table(sp_handle *h, const double *rta1_dev, int ntab,
                            int covpts, const double *xp_dev, double *tab_dev,
-                           double *meanvar_dev, hipStream_t st) {
+                           double *meanvar_dev, hipStream_t st, int nsets, const double *ez_dev,
+                           const double *Ez_dev) {
+  const double *ez = nsets ? ez_dev : h->d_ez, *Ez = nsets ? Ez_dev : h->d_Ez;
+  const int nb = nsets ? nsets : 1;
+  if ((long)ntab * nb > 65535 || nb > 65535) return SP_ERR_INVALID;
   const size_t lds =
       sizeof(double) * ((size_t)3 * h->N + covpts + 4 + 2 * (h->ydeg + 1) + 4);
   if (lds > 150 * 1024) return SP_ERR_INVALID;
   // row-reduction scratch [ntab][2][N], grown on demand (rare: new ntab)
-  const size_t need = sizeof(double) * (size_t)ntab * 3 * h->N;
+  const size_t need = sizeof(double) * (size_t)ntab * nb * 3 * h->N;
   if (h->tab_scratch_bytes < need) {
     SP_HIP(hipDeviceSynchronize());
     if (h->d_tab_scratch) SP_HIP(hipFree(h->d_tab_scratch));
@@ -191,12 +201,12 @@ int sp_launch_kernel_table(sp_handle *h, const double *rta1_dev, int ntab,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     h->table_attr_done = true;
   }
-  hipLaunchKernelGGL(table_rows_kernel, dim3((h->N + 3) / 4, ntab), dim3(256), 0, st,
-                     h->N, h->d_l_of, h->d_mirror, h->d_Wnp, h->d_Ez, rta1_dev,
-                     h->d_tab_scratch, h->d_blk, h->d_wnp, h->d_ez);
+  hipLaunchKernelGGL(table_rows_kernel, dim3((h->N + 3) / 4, ntab, nb), dim3(256), 0, st,
+                     h->N, h->d_l_of, h->d_mirror, h->d_Wnp, Ez, rta1_dev,
+                     h->d_tab_scratch, h->d_blk, h->d_wnp, ez);
   SP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(table_finish_kernel, dim3(ntab), dim3(256), lds, st, h->ydeg, h->N,
-                     h->d_l_of, h->d_blk, h->d_wnp, h->d_ez, rta1_dev, h->d_tab_scratch,
+  hipLaunchKernelGGL(table_finish_kernel, dim3(ntab, nb), dim3(256), lds, st, h->ydeg, h->N,
+                     h->d_l_of, h->d_blk, h->d_wnp, ez, rta1_dev, h->d_tab_scratch,
                      covpts, xp_dev, tab_dev, meanvar_dev);
   SP_LAUNCH_CHECK();
   return SP_OK;

@@ -13,7 +13,7 @@ from . import _lib
 from . import hostconst
 from ._lib import STAR_DTYPE, TEMPORAL, SPError, c_void_p, check, hptr
 
-__all__ = ["Engine", "DataPlan", "get_engine", "make_stars"]
+__all__ = ["Engine", "DataPlan", "get_engine", "make_stars", "stars_for_samples", "sample_parameters"]
 
 
 def _torch():
@@ -36,6 +36,47 @@ def make_stars(S, period=1.0, inc_deg=60.0, tau=0.0, baseline_var=0.0,
     st["table"] = table
     st["nobs"] = nobs
     return st
+
+
+def stars_for_samples(stars, B, ntab):
+    """The sp_star array of a batch of B hyperparameter samples x S stars (sample-major: system b S + s): the S stars
+    repeated B times with table = b ntab + table_s, the kernel table of sample b for the star's flux operator
+    (sp_kernel_table_samples' numbering)."""
+    stars = np.ascontiguousarray(stars)
+    assert stars.dtype == STAR_DTYPE
+    out = np.tile(stars, int(B))
+    out["table"] = (np.repeat(np.arange(int(B), dtype=np.int64), stars.shape[0]) * int(ntab) + out["table"]).astype(np.int32)
+    return out
+
+
+def sample_parameters(samples, **kw):
+    """samples [B, 5] = (r [degrees], a, b, c, n) -> [B, 5] = (r [radians], alpha, beta, c, n), what
+    sp_polar_moments_samples takes: the reference's bounds (size.py:68, latitude.py:176-197, contrast.py:21-33 through
+    CheckBoundsOp: ValueError outside, tolerance 1e-6) and its (a, b) -> (alpha, beta) map, for the whole batch at once
+    (NumPy; one sample at a time ``upstream.ab_to_alphabeta`` does the same)."""
+    from .defaults import defaults
+
+    sm = np.array(np.atleast_2d(np.asarray(samples, dtype=np.float64)), dtype=np.float64)
+    if sm.ndim != 2 or sm.shape[1] != 5:
+        raise ValueError("samples must be (B, 5): r, a, b, c, n")
+    r, a, b, n = sm[:, 0] * (np.pi / 180), sm[:, 1], sm[:, 2], sm[:, 4]
+    from .ops import CheckBoundsOp
+
+    for name, v, lo, hi in (("r", r, 0.0, 0.5 * np.pi), ("a", a, 0.0, 1.0), ("b", b, 0.0, 1.0), ("n", n, 0.0, np.inf)):
+        CheckBoundsOp(name=name, lower=lo, upper=hi)(v)
+    if not np.all(np.isfinite(sm)):
+        raise ValueError("samples must be finite")
+    abmin = kw.get("abmin", defaults["abmin"])
+    lam = kw.get("log_alpha_max", defaults["log_alpha_max"])
+    lbm = kw.get("log_beta_max", defaults["log_beta_max"])
+    a, b = np.maximum(a, abmin), np.maximum(b, abmin)
+    out = np.empty_like(sm)
+    out[:, 0] = np.clip(r, 0.0, None)
+    out[:, 1] = np.exp(a * lam)
+    out[:, 2] = np.exp(np.log(0.5) + b * (lbm - np.log(0.5)))
+    out[:, 3] = sm[:, 3]
+    out[:, 4] = np.clip(n, 0.0, None)
+    return np.ascontiguousarray(out)
 
 
 _STAGE_BYTES, _STAGE_SLOTS = 1 << 16, 16   # pinned staging ring of Engine.dev (small uploads)
@@ -297,6 +338,60 @@ class Engine(object):
                                       self._p(tab), self._p(mv), self._stream()))
         return tab, mv
 
+    # -- hyperparameter samples in batches (round 6) -------------------------------
+    def set_size_basis(self, **kw):
+        """Hands the spot profile's basis (size.py:9-47; upstream._spot_basis) to the library once per engine
+        (sp_set_size_basis): what sp_polar_moments_samples integrates the sigmoid profile against."""
+        from .defaults import defaults
+        from .upstream import _spot_basis
+
+        skw = {k: kw[k] for k in ("spts", "eps4", "smoothing") if k in kw}
+        sfac = float(kw.get("sfac", 300))
+        key = (tuple(sorted(skw.items())), sfac)
+        if self.__dict__.get("_size_basis_key") == key:
+            return
+        theta, Bp, _ = _spot_basis(self.ydeg, **skw)
+        theta, Bp = np.ascontiguousarray(theta, dtype=np.float64), np.ascontiguousarray(Bp, dtype=np.float64)
+        assert Bp.shape == (self.ydeg + 1, theta.shape[0])
+        check(self._L.sp_set_size_basis(self._h, hptr(theta), hptr(Bp), int(theta.shape[0]), sfac))
+        self._size_basis_key = key
+
+    def polar_moments_samples(self, samples, ez=None, Ez=None, **kw):
+        """samples [B, 5] = (r [degrees], a, b, c, n) per row, the argument order of the reference's log-probability
+        (calibrate/log_prob.py:93-102) -> (ez [B, N], Ez [B, N, N]) device tensors: the polar-frame moments of B
+        hyperparameter samples in one library call (sp_polar_moments_samples).  Bounds are the reference's
+        (ValueError before anything is launched)."""
+        from .defaults import defaults
+
+        sm = sample_parameters(samples, **kw)
+        B = sm.shape[0]
+        self.set_size_basis(**kw)
+        if ez is None:
+            ez = self.empty(B, self.N)
+        if Ez is None:
+            Ez = self.empty(B, self.N, self.N)
+        assert tuple(ez.shape) == (B, self.N) and tuple(Ez.shape) == (B, self.N, self.N)
+        check(self._L.sp_polar_moments_samples(
+            self._h, B, hptr(sm), float(kw.get("epsy", defaults["epsy"])), float(kw.get("epsy15", defaults["epsy15"])),
+            self._p(ez), self._p(Ez), self._stream()))
+        return ez, Ez
+
+    def kernel_table_samples(self, ez, Ez, rta1, covpts, tab=None, meanvar=None):
+        """ez [B, N], Ez [B, N, N], rta1 [ntab, N] (device) -> tab [B ntab, 5, covpts + 4], meanvar [B ntab, 2]: table
+        b ntab + i belongs to sample b and flux operator i (sp_kernel_table_samples)."""
+        B = ez.shape[0]
+        ntab = rta1.shape[0]
+        xp = self.__dict__.setdefault("_xp_cache", {}).get(int(covpts))
+        if xp is None:
+            xp = self._xp_cache[int(covpts)] = np.ascontiguousarray(hostconst.lag_grid(int(covpts))[1])
+        if tab is None:
+            tab = self.empty(B * ntab, 5, covpts + 4)
+        if meanvar is None:
+            meanvar = self.empty(B * ntab, 2)
+        check(self._L.sp_kernel_table_samples(self._h, B, self._p(ez), self._p(Ez), self._p(rta1), ntab, int(covpts),
+                                              hptr(xp), self._p(tab), self._p(meanvar), self._stream()))
+        return tab, meanvar
+
     # -- covariances -----------------------------------------------------------
     def cov_marginal(self, t, stars, covpts, tab, meanvar, temporal=None,
                      normalized=True, norm_order=20):
@@ -514,7 +609,16 @@ class Engine(object):
         p = c_void_p()
         check(self._L.sp_plan_data(self._h, S, K, M, self._p(t), self._p(flux), self._p(diag), self._p(stars_dev),
                                    int(covpts), TEMPORAL[temporal], self._p(ws), self._stream(), ctypes.byref(p)))
-        return DataPlan(self._L, p, S, K, M, int(covpts), temporal, diag is not None)
+        # (the plan records the data pointers: the tensors must outlive it)
+        return DataPlan(self._L, p, S, K, M, int(covpts), temporal, diag is not None, keep=(t, flux, diag))
+
+    def replicate_plan(self, plan, B):
+        """B copies of a planned data set as one batch of B S systems (sp_plan_replicate): system b S + s is star s under
+        hyperparameter sample b.  The replica owns its data; evaluate it with ``lnlike_ensemble_planned(plan, None, None,
+        stars_for_samples(...), ...)``."""
+        p = c_void_p()
+        check(self._L.sp_plan_replicate(self._h, plan.ptr, int(B), self._stream(), ctypes.byref(p)))
+        return DataPlan(self._L, p, plan.S * int(B), plan.K, plan.M, plan.covpts, plan.temporal, plan.has_diag)
 
     def lnlike_ensemble_planned(self, plan, t, flux, stars_dev, tab, meanvar, diag=None, norm_order=20,
                                 zmax=0.023, out=None, status=None, workspace=None):
@@ -522,7 +626,8 @@ class Engine(object):
         the same values to rounding, without the per-sample pass over the covariance's entries."""
         torch = _torch()
         S, K, M = plan.S, plan.K, plan.M
-        assert tuple(t.shape) == (S, K) and tuple(flux.shape) == (S, M, K)
+        # (t = flux = diag = None: the plan's own arrays -- a replica's copies, or the tensors of plan time)
+        assert (t is None and flux is None and diag is None) or (tuple(t.shape) == (S, K) and tuple(flux.shape) == (S, M, K))
         ws = workspace if workspace is not None else self.workspace(S, K, M)
         if out is None:
             out = self.empty(S)
@@ -579,9 +684,10 @@ class Engine(object):
 class DataPlan(object):
     """Owner of an ``sp_plan`` (include/starry_process_amd.h: sp_plan_data)."""
 
-    def __init__(self, L, ptr, S, K, M, covpts, temporal, has_diag):
+    def __init__(self, L, ptr, S, K, M, covpts, temporal, has_diag, keep=None):
         self._L, self.ptr = L, ptr
         self.S, self.K, self.M, self.covpts, self.temporal, self.has_diag = S, K, M, covpts, temporal, has_diag
+        self._keep = keep
 
     def wbar(self):
         """[S, covpts + 4] host copy of the table's weights in the covariance's sum."""

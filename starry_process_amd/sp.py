@@ -257,6 +257,71 @@ class StarryProcess(object):
             val = -np.inf
         return Eager(val)
 
+    def log_likelihood_samples(
+        self,
+        t,
+        flux,
+        data_cov,
+        samples,
+        i=defaults["i"],
+        p=defaults["p"],
+        u=defaults["u"][: defaults["udeg"]],
+        baseline_mean=defaults["baseline_mean"],
+        baseline_var=defaults["baseline_var"],
+        depth=3,
+    ):
+        """``log_likelihood(t, flux, data_cov, ...)`` of THIS process's settings (degree, normalisation, lag grid,
+        temporal kernel) at many hyperparameter vectors: samples (ns, 5) = rows of (r, a, b, c, n) -> (ns,) values, each
+        what ``StarryProcess(r=r, a=a, b=b, c=c, n=n, <same settings>, upstream="device").log_likelihood(...)``
+        returns.  What a sampler does with the reference one call at a time (sp.py:1052-1062 driven by
+        calibrate/sample.py:95-107) is here ONE batched device step per 64 samples (calibrate.SampleBatches) --
+        marginalised, normalised processes with one spot radius and scalar or per-cadence data variance; anything
+        else is evaluated sample by sample."""
+        from .calibrate import SampleBatches, clamp_depth
+        from .engine import engine_slots
+
+        f = self._flux
+        t, i, p, u = f._ingest(t, i, p, u)
+        K = t.shape[0]
+        samples = np.atleast_2d(np.asarray(samples, dtype=np.float64))
+        if samples.shape[1] != 5:
+            raise ValueError("samples must be (ns, 5): r, a, b, c, n")
+        flux = np.asarray(flux, dtype=np.float64)
+        F = flux.reshape(1, K) if flux.ndim == 1 else flux.reshape(-1, K)
+        data_cov = np.asarray(data_cov, dtype=np.float64)
+        bmean, bvar = np.asarray(baseline_mean, dtype=np.float64), np.asarray(baseline_var, dtype=np.float64)
+        batched = (self._marginalize_over_inclination and self._normalized and self._dr is None and K >= 2
+                   and data_cov.ndim <= 1 and bmean.ndim == 0 and bvar.ndim == 0)
+        if not batched:
+            kw = dict(self._kwargs)
+            kw.update(dr=self._dr, tau=self._tau if self._time_variable else None, temporal_kernel=self._temporal or "matern32",
+                      marginalize_over_inclination=self._marginalize_over_inclination, normalized=self._normalized,
+                      covpts=self._covpts, upstream="device")
+            return Eager(np.array([float(StarryProcess(r=r, a=a, b=b, c=c, n=n, **kw).log_likelihood(
+                t, flux, data_cov, i=i, p=p, u=u, baseline_mean=baseline_mean, baseline_var=baseline_var))
+                for r, a, b, c, n in samples]))
+        key = (t.tobytes(), F.tobytes(), data_cov.tobytes(), float(p), tuple(np.asarray(u, dtype=float).reshape(-1)),
+               float(bmean), float(bvar), int(depth))
+        cache = self.__dict__.get("_sample_batches")
+        if cache is None or cache[0] != key:
+            # (the data set is planned once and kept: a sampler calls this with the same data every iteration)
+            slots = engine_slots(self._ydeg, self._udeg, self._kwargs.get("device"), clamp_depth(depth))
+            e0 = slots[0][0]
+            stars = make_stars(1, period=p, inc_deg=i, tau=self._tau, baseline_var=float(bvar), baseline_mean=float(bmean),
+                               data_var=float(data_cov) if data_cov.ndim == 0 else 0.0)
+            ukw = {k: self._kwargs[k] for k in ("epsy", "epsy15", "spts", "eps4", "smoothing", "sfac", "abmin",
+                                                "log_alpha_max", "log_beta_max") if k in self._kwargs}
+            sb = SampleBatches(slots, e0.f64(t[None, :]), e0.f64(F[None, :, :]), stars,
+                               e0.f64(e0.rTA1L(np.asarray(u, dtype=np.float64))), self._covpts,
+                               diag_dev=e0.f64(data_cov.reshape(1, K)) if data_cov.ndim == 1 else None,
+                               temporal=self._temporal, norm_order=self._normN, zmax=self._normzmax, upstream_kwargs=ukw)
+            cache = self._sample_batches = (key, sb)
+        out = cache[1](samples)
+        import torch
+
+        torch.cuda.synchronize(out.device)
+        return Eager(_neg_inf_if_nan(out[:, 0].cpu().numpy()))
+
     def log_likelihood_grad(
         self,
         t,

@@ -22,7 +22,7 @@ from .defaults import defaults
 from .hostconst import wigner_poly
 from .ops import CheckBoundsOp
 
-__all__ = ["ylm_moments", "gauss2beta", "beta2gauss", "latitude_integrals", "log_jac"]
+__all__ = ["ylm_moments", "gauss2beta", "beta2gauss", "latitude_integrals", "log_jac", "log_jac_samples"]
 
 _cache = {}
 _ANG = np.pi / 180
@@ -253,3 +253,26 @@ def log_jac(a, b, **kwargs):
                * (2 * (-1 + alpha + beta) + 3 * (-1 + beta) * np.cos(mu)
                   - 2 * (-1 + alpha - beta) * np.cos(2 * mu) + (-1 + beta) * np.cos(3 * mu)) ** 2)))
     return float(-np.inf) if sigma > sigma_max else float(val)
+
+
+def log_jac_samples(a, b, **kwargs):
+    """``log_jac`` for arrays of (a, b): one NumPy pass for the samples of a batch (a Python call per sample costs more
+    than the sample's share of a batched likelihood step)."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    CheckBoundsOp(name="a", lower=0, upper=1)(a)
+    CheckBoundsOp(name="b", lower=0, upper=1)(b)
+    abmin = kwargs.get("abmin", defaults["abmin"])
+    lam = kwargs.get("log_alpha_max", defaults["log_alpha_max"])
+    lbm = kwargs.get("log_beta_max", defaults["log_beta_max"])
+    alpha = np.exp(np.maximum(a, abmin) * lam)
+    beta = np.exp(np.log(0.5) + np.maximum(b, abmin) * (lbm - np.log(0.5)))
+    sigma_max = kwargs.get("sigma_max", defaults["sigma_max"]) * _ANG
+    with np.errstate(invalid="ignore", divide="ignore"):
+        mu, sigma = _mu_sigma(alpha, beta)
+        val = np.log(np.abs(
+            (alpha * beta * (1 + np.cos(mu)) ** 3 * np.sin(2 * mu) ** 3)
+            / (sigma
+               * (-3 + 2 * alpha + beta + (-1 + 2 * alpha + beta) * np.cos(mu))
+               * (2 * (-1 + alpha + beta) + 3 * (-1 + beta) * np.cos(mu)
+                  - 2 * (-1 + alpha - beta) * np.cos(2 * mu) + (-1 + beta) * np.cos(3 * mu)) ** 2)))
+    return np.where(sigma > sigma_max, -np.inf, val)
