@@ -308,6 +308,75 @@ def bench_shape(torch, dist, ydeg, Kc, S, tspan, tau, u, conditional, F, steps, 
     return res
 
 
+def bench_samples(torch, ydeg, Kc, Sd, F, steps, device):
+    """BASELINE cfg2 the way the reference is driven -- ONE light curve (Sd = 1; or a small ensemble) evaluated at many
+    hyperparameter samples (sp.py:1052-1062 inside calibrate/sample.py:95-107) -- with the samples batched ceil(64 / Sd)
+    to a library call (calibrate.SampleBatches): per step the samples' polar moments FROM THE HYPERPARAMETERS
+    (sp_polar_moments_samples: the upstream is per-sample work here, so it is INSIDE the timed step), their kernel
+    tables, one planned likelihood call on (sample, star) systems.  Fresh samples every step; F steps in flight."""
+    from starry_process_amd.calibrate import SampleBatches
+    from starry_process_amd.engine import engine_slots, make_stars
+    from starry_process_amd.synthetic import synthetic_star
+
+    sts = [synthetic_star(s, Kc) for s in range(Sd)]
+    slots = engine_slots(ydeg, UDEG, device, F)
+    e0 = slots[0][0]
+    stars = make_stars(Sd, period=[s["p"] for s in sts], data_var=1e-6)
+    sb = SampleBatches(slots, e0.f64(np.array([s["t"] for s in sts])), e0.f64(np.array([s["flux"] for s in sts])[:, None, :]),
+                       stars, e0.f64(e0.rTA1L([0.0, 0.0])), COVPTS)
+    g = sb.group
+    rng = np.random.RandomState(7)
+
+    def draw(n):      # around the defaults (defaults.py:7-12), inside z < zmax
+        return np.column_stack([rng.uniform(15.0, 25.0, n), rng.uniform(0.3, 0.5, n), rng.uniform(0.2, 0.35, n),
+                                rng.uniform(0.08, 0.12, n), rng.uniform(5.0, 12.0, n)])
+
+    sb(draw(3 * F * g))
+    torch.cuda.synchronize()
+    smp = draw(steps * g)
+    t0 = time.perf_counter()
+    out = sb(smp)
+    host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    vals = out.cpu().numpy()
+    # one step at a time, and the share of the moments + tables in it (the same calls, on one slot)
+    (e, stream), b = sb._slots[0], sb._buf[0]
+    one = draw(g)
+
+    def upstream_only():
+        e.polar_moments_samples(one, ez=b["ez"], Ez=b["Ez"])
+        e.kernel_table_samples(b["ez"], b["Ez"], sb._rta1, COVPTS, tab=b["tab"], meanvar=b["mv"])
+
+    def whole():
+        upstream_only()
+        e.lnlike_ensemble_planned(sb._plan, None, None, sb._stars, b["tab"], b["mv"], workspace=b["ws"])
+
+    res = {}
+    with torch.cuda.stream(stream):
+        for name, fn, reps in (("upstream_ms", upstream_only, 30), ("one_step_at_a_time_ms", whole, 30)):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            res[name] = 1e3 * (time.perf_counter() - t1) / reps
+    fl, _ = step_work(g * Sd, Kc, 1, 0)
+    ms = 1e3 * dt / steps
+    res.update({"ydeg": ydeg, "K": Kc, "stars": Sd, "samples_per_call": g, "systems_per_call": g * Sd, "steps": steps,
+                "steps_in_flight": F, "evals_per_s": g * Sd * steps / dt, "samples_per_s": g * steps / dt,
+                "ms_per_step": ms, "host_enqueue_ms_per_step": 1e3 * host / steps,
+                "upstream_share_one_at_a_time": res["upstream_ms"] / res["one_step_at_a_time_ms"],
+                "whole_step_TFLOPs": fl / (ms * 1e-3) / 1e12, "whole_step_frac": fl / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                "finite": bool(np.isfinite(vals).all()),
+                "note": "hyperparameters -> polar moments (device Gauss-Jacobi + rotations, sp_polar_moments_samples) -> "
+                        "kernel tables -> planned likelihood of (sample, star) systems, all inside the timed step; "
+                        "upstream_ms = moments + tables of one call alone"})
+    return res
+
+
 def bench_grad(torch, S, Kc, device, forward_ms):
     """The ensemble gradient d sum_s lnL_s / d(r, a, b, c, n) at cfg3's shape (grad.EnsembleGradient: one device
     sweep for the whole batch -- C^-1 by the factorisation's machinery, the kernel table's adjoint on the device),
@@ -814,6 +883,9 @@ def main():
             extras["cfg2_single_star_one_at_a_time"] = bench_shape(torch, dist, ydeg=15, Kc=1000, S=1, tspan=4.0, tau=None,
                                                                    u=(0.0, 0.0), conditional=False, F=1, steps=100,
                                                                    device=local_rank, planned=plan is not None)
+            # ... and the same light curve with the hyperparameter samples batched 64 to a call, upstream included
+            extras["cfg2_batched_samples"] = bench_samples(torch, 15, 1000, 1, F, 40, local_rank)
+            extras["ensemble8_batched_samples"] = bench_samples(torch, 15, 1000, 8, F, 40, local_rank)
             extras["cfg3_conditional"] = bench_shape(torch, dist, ydeg=15, Kc=1000, S=64, tspan=4.0, tau=None,
                                                      u=(0.0, 0.0), conditional=True, F=F, steps=24,
                                                      device=local_rank)

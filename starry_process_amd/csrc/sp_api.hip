@@ -592,7 +592,7 @@ int sp_create(int ydeg, int udeg, int device, sp_handle **out) {
   h->table_attr_done = false;
   h->big_ptr = nullptr;
   h->big_bytes = 0;
-  for (auto &c : h->cs_ring) c = sp_handle::CsSlot{nullptr, nullptr, 0, nullptr, false};
+  h->cs_ring.assign(4, sp_handle::CsSlot{nullptr, nullptr, 0, nullptr, false});
   h->cs_next = 0;
   h->superpanel = 0;
   h->groups = 1;
@@ -712,6 +712,50 @@ int sp_udeg(const sp_handle *h) { return h ? h->udeg : SP_ERR_INVALID; }
 int sp_nylm(const sp_handle *h) { return h ? h->N : SP_ERR_INVALID; }
 int sp_nwig(const sp_handle *h) { return h ? h->NWIG : SP_ERR_INVALID; }
 
+}  // extern "C"
+
+int sp_stage_acquire(sp_handle *h, size_t doubles, sp_handle::CsSlot **out) {
+  const size_t n = h->cs_ring.size();
+  int pick = -1;
+  for (size_t k = 0; k < n && pick < 0; ++k) {
+    const size_t i = ((size_t)h->cs_next + k) % n;
+    sp_handle::CsSlot &c = h->cs_ring[i];
+    if (!c.used) {
+      pick = (int)i;
+    } else {
+      const hipError_t q = hipEventQuery(c.done);
+      if (q == hipSuccess) pick = (int)i;
+      else (void)hipGetLastError();     // (hipErrorNotReady is an answer, not a failure to report later)
+    }
+  }
+  if (pick < 0 && n < SP_STAGE_MAX) {
+    h->cs_ring.push_back(sp_handle::CsSlot{nullptr, nullptr, 0, nullptr, false});
+    pick = (int)n;
+  }
+  if (pick < 0) {
+    pick = h->cs_next % (int)n;
+    SP_HIP(hipEventSynchronize(h->cs_ring[pick].done));
+  }
+  sp_handle::CsSlot &c = h->cs_ring[pick];
+  c.used = false;
+  if (c.cap < doubles) {
+    if (c.host) SP_HIP(hipHostFree(c.host));
+    if (c.dev) SP_HIP(hipFree(c.dev));
+    c.host = c.dev = nullptr;
+    c.cap = 0;
+    const size_t cap = doubles < 512 ? 512 : doubles;
+    SP_HIP(hipHostMalloc((void **)&c.host, sizeof(double) * cap, hipHostMallocDefault));
+    SP_HIP(hipMalloc((void **)&c.dev, sizeof(double) * cap));
+    c.cap = cap;
+  }
+  if (!c.done) SP_HIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+  h->cs_next = (pick + 1) % (int)h->cs_ring.size();
+  *out = &c;
+  return SP_OK;
+}
+
+extern "C" {
+
 int sp_stream_synchronize(sp_handle *h, void *stream) {
   if (h && h->device < 0) return SP_ERR_NO_DEVICE;
   if (!h) return SP_ERR_INVALID;
@@ -728,21 +772,13 @@ int sp_Rx(sp_handle *h, const double *theta_host, int nangles, double *R_dev,
   // cos/sin on the host with libm, like the reference (wigner.h:153-154), staged through the
   // handle's ring: the slot's previous use is waited for on the host (long finished in
   // practice), nothing is allocated, freed or synchronised once the ring has grown
-  sp_handle::CsSlot &c = h->cs_ring[h->cs_next];
-  h->cs_next = (h->cs_next + 1) & 3;
   const size_t need = 2 * (size_t)nangles;
-  if (c.used) SP_HIP(hipEventSynchronize(c.done));
-  if (c.cap < need) {
-    if (c.host) SP_HIP(hipHostFree(c.host));
-    if (c.dev) SP_HIP(hipFree(c.dev));
-    c.host = c.dev = nullptr;
-    c.cap = 0;
-    const size_t cap = need < 64 ? 64 : need;
-    SP_HIP(hipHostMalloc((void **)&c.host, sizeof(double) * cap, hipHostMallocDefault));
-    SP_HIP(hipMalloc((void **)&c.dev, sizeof(double) * cap));
-    c.cap = cap;
+  sp_handle::CsSlot *cp = nullptr;
+  {
+    int rc = sp_stage_acquire(h, need, &cp);
+    if (rc) return rc;
   }
-  if (!c.done) SP_HIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+  sp_handle::CsSlot &c = *cp;
   for (int i = 0; i < nangles; ++i) {
     c.host[2 * i] = std::cos(theta_host[i]);
     c.host[2 * i + 1] = std::sin(theta_host[i]);

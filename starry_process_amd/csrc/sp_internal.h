@@ -62,7 +62,7 @@ struct sp_handle {
     hipEvent_t done;
     bool used;
   };
-  CsSlot cs_ring[4];
+  std::vector<CsSlot> cs_ring;  // (sp_stage_acquire: grows while every slot is still in flight, up to SP_STAGE_MAX)
   int cs_next;
   int superpanel;               // panels per super-panel (SP_SUPER; 0 = chosen from K)
   int groups;                   // concurrent star groups (SP_GROUPS, default 1)
@@ -134,6 +134,15 @@ struct SpProfScope {
 };
 
 const char *sp_set_hip_error(hipError_t e, const char *what);
+
+// A staging slot of at least `doubles` doubles (pinned host + device buffer) that no copy in flight still reads: the
+// oldest slot whose event has completed (hipEventQuery -- never a host wait: hipEventSynchronize on an event recorded
+// behind a kernel launch waits until the stream has DRAINED, the runtime gives kernels no completion signal of their
+// own: 0.9 ms per call with a step's launches queued, round 6), a new slot while all are busy, and only with
+// SP_STAGE_MAX slots in flight a wait for the oldest.  The caller fills c->host, enqueues its copy and records c->done
+// behind the last launch that reads c->dev, then sets c->used.
+#define SP_STAGE_MAX 64
+int sp_stage_acquire(sp_handle *h, size_t doubles, sp_handle::CsSlot **out);
 
 #define SP_HIP(call)                                   \
   do {                                                 \

@@ -3,7 +3,7 @@
 // A sampler evaluates the likelihood of one data set at many (r, a, b, c, n) (calibrate/sample.py:95-107,
 // interfaces.py:142-166 of the reference); one sample at a time the upstream of the path was a chain of ten launches
 // behind 0.5 ms of host preparation (size integral in NumPy, Gauss-Jacobi rule through ctypes).  Here the whole chain
-// hyperparameters -> (ez, Ez) runs on the device for the B samples of a batch: one staged upload of 5 B numbers, six
+// hyperparameters -> (ez, Ez) runs on the device for the B samples of a batch: one staged upload of 5 B numbers, five
 // launches, no host arithmetic.
 //
 // What is computed is what sp_ylm_moments_quadrature + sp_set_ylm_moments_dev compute (csrc/sp_upstream.hip documents
@@ -18,11 +18,12 @@
 // (l', +-m), m > 0, the 2 x 2 block X becomes (X11 + X22) / 2 on its diagonal and +-(X12 - X21) / 2 off it.  So
 //     e1 = g sum_k w_k (the m = 0 entries of u_k),        ez = sqrt(n) e1,
 //     Ez = g^2 Proj(sum_k w_k u_k^T u_k) + (n - 1) e1 e1^T + diag(eps):
-// 2 (ydeg + 2) rotations per sample instead of 2 (ydeg + 2) (2 ydeg + 3), and no rotation back and forth.  (Checked on
+// 2 (ydeg + 2) rotations per sample instead of 2 (ydeg + 2) (2 ydeg + 3), and no rotation back and forth; the rotation
+// Rx(phi_k) of the zonal size vector is a row of associated Legendre functions (sm_rows_kernel): no Wigner recursion.  (Checked on
 // the CPU against the oracle's quadrature + polar_moments: 1e-15 relative, tests/test_samples_identities.py.)
 //
-// The Gauss-Jacobi nodes come from bisection on the Jacobi matrix's Sturm sequence (one thread per node; the weights
-// from the orthonormal recurrence at the node): the same rule as sp_gauss_jacobi's implicit QL to 1e-15 in the nodes
+// The Gauss-Jacobi nodes come from multi-section on the Jacobi matrix's Sturm sequence (a group of threads per node; the
+// weights from the orthonormal recurrence at the node): the same rule as sp_gauss_jacobi's implicit QL to 1e-15 in the nodes
 // and 2e-11 in the weights over the reference's whole prior box (tests/test_gpu_samples.py).
 #include <cmath>
 #include <cstring>
@@ -87,12 +88,18 @@ __global__ __launch_bounds__(256) void sm_prepare_kernel(int ydeg, int spts, dou
       if (lane == 0) svec[(size_t)b * nl + l] = acc;
     }
   }
-  // node i: the i-th eigenvalue of the Jacobi matrix by bisection on the Sturm count (all of them lie in (-1, 1))
-  double ti = 0.0;
-  if (tid < nq) {
-    double lo = -1.0, hi = 1.0;
-    for (int it = 0; it < 58; ++it) {
-      const double x = 0.5 * (lo + hi);
+  // node i: the i-th eigenvalue of the Jacobi matrix, bracketed on the Sturm count (all of them lie in (-1, 1)).  A
+  // group of npt threads per node cuts the bracket into npt + 1 parts per round (plain bisection, one thread per node,
+  // was 58 dependent rounds of nq divisions: 110 us of latency in front of every batch; 15 rounds now).
+  const int npt = 256 / nq < 15 ? 256 / nq : 15, node = tid / npt, pt = tid - node * npt;
+  int rounds = 0;
+  for (double span = 2.0; span > 3.0e-18; span /= npt + 1) ++rounds;
+  int *s_flag = reinterpret_cast<int *>(s_w + nq);        // [256]
+  double lo = -1.0, hi = 1.0;
+  for (int it = 0; it < rounds; ++it) {
+    int above = 0;
+    if (node < nq) {
+      const double x = lo + (hi - lo) * ((double)(pt + 1) / (double)(npt + 1));
       // (LAPACK's dlaebz: a pivot below pivmin counts as negative and is replaced BEFORE it is counted and used --
       //  alpha = beta makes the diagonal zero and the first midpoint, x = 0, an exact zero pivot)
       double q = s_d[0] - x;
@@ -103,9 +110,21 @@ __global__ __launch_bounds__(256) void sm_prepare_kernel(int ydeg, int spts, dou
         if (fabs(q) < 1.0e-290) q = -1.0e-290;
         cnt += q < 0.0 ? 1 : 0;
       }
-      if (cnt > tid) hi = x;
-      else lo = x;
+      above = cnt > node ? 1 : 0;       // more than `node` eigenvalues below x: node's eigenvalue is below x
     }
+    s_flag[tid] = above;
+    __syncthreads();
+    if (node < nq) {
+      int below = 0;                    // trial points at or below the eigenvalue
+      for (int j = 0; j < npt; ++j) below += 1 - s_flag[node * npt + j];
+      const double w = hi - lo, l0 = lo;
+      if (below > 0) lo = l0 + w * ((double)below / (double)(npt + 1));
+      if (below < npt) hi = l0 + w * ((double)(below + 1) / (double)(npt + 1));
+    }
+    __syncthreads();
+  }
+  double ti = 0.0;
+  if (node < nq && pt == 0) {
     ti = 0.5 * (lo + hi);
     // weight: 1 / sum_k p_k(t_i)^2 of the orthonormal polynomials (p_0 = 1)
     double p0 = 0.0, p1 = 1.0, sum = 1.0;
@@ -115,10 +134,12 @@ __global__ __launch_bounds__(256) void sm_prepare_kernel(int ydeg, int spts, dou
       p0 = p1;
       p1 = p2;
     }
-    s_w[tid] = 1.0 / sum;
+    s_w[node] = 1.0 / sum;
+    s_e2[node] = ti;                    // (the squares are not needed any more: the nodes, by index)
   }
   __syncthreads();
   if (tid < nq) {
+    const double ti = s_e2[tid];
     double tot = 0.0;
     for (int k = 0; k < nq; ++k) tot += s_w[k];
     const double wphi = 0.5 * (s_w[tid] / tot);      // both signs of the latitude share a node's weight
@@ -142,25 +163,50 @@ __global__ __launch_bounds__(256) void sm_prepare_kernel(int ydeg, int spts, dou
 
 // T[b][n][k] = g sqrt(w_k) (s Rx(+-phi_k) Rx(pi/2))[n]: rotation k of sample b.  grid (SM_TK, B); the columns from
 // P on are the zero padding of the product's long dimension.
-__global__ __launch_bounds__(256) void sm_rows_kernel(int N, int nl, int P, int nwig, const int32_t *__restrict__ l_of,
+//
+// The size vector s has its nonzero entries at m = 0 (size.py:92-101: a spot at the pole is zonal), so s Rx(phi) needs
+// row m' = 0 of every degree's block only -- and that row is the Wigner function d^l_{m0}(phi), a normalised
+// associated Legendre function: with N_l^m = sqrt((l - m)! / (l + m)!) P_l^m(cos phi) (no Condon-Shortley phase),
+//     N_m^m = sqrt((2m - 1) / (2m)) sin(phi) N_{m-1}^{m-1},
+//     N_l^m = ((2l - 1) cos(phi) N_{l-1}^m - sqrt((l - 1)^2 - m^2) N_{l-2}^m) / sqrt(l^2 - m^2),
+// the real block's row is R_l[0][0] = N_l^0, R_l[0][+m] = (-1)^m sqrt(2) cos(m pi/2) N_l^m, R_l[0][-m] = -(-1)^m sqrt(2)
+// sin(m pi/2) N_l^m (the complex -> real step of wigner.h:225-271 applied to that row; equal to sp_Rx's row to 1e-14,
+// tests/test_samples_identities.py).  O(ydeg^2) per rotation, one thread per order m -- the full recursion of
+// wigner.h:36-139 (rx_kernel: all (2l + 1)^2 entries of every block, 100 us per angle and 23 KB of LDS) is not run here.
+__global__ __launch_bounds__(256) void sm_rows_kernel(int ydeg, int N, int P, const int32_t *__restrict__ l_of,
                                                       const int32_t *__restrict__ blk, const double *__restrict__ svec,
-                                                      const double *__restrict__ Rphi, const double *__restrict__ Rx90,
+                                                      const double *__restrict__ cs, const double *__restrict__ Rx90,
                                                       const double *__restrict__ sc, double *__restrict__ T) {
   extern __shared__ __attribute__((aligned(16))) double sm_v[];   // [N]
-  const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nl = ydeg + 1;
   double *Tb = T + (size_t)b * N * SM_TK;
   if (k >= P) {
     for (int n = tid; n < N; n += 256) Tb[(size_t)n * SM_TK + k] = 0.0;
     return;
   }
   const int Ph = P / 2, kr = k < Ph ? k : k - Ph;
-  const bool rt = k >= Ph;            // -phi: the transposed blocks of +phi's rotation
-  const double *R = Rphi + ((size_t)b * Ph + kr) * nwig;
-  // the size vector has its nonzero entries at m = 0 (index l^2 + l): row l of the degree's block (column l of it
-  // for the transposed rotation)
-  for (int n = tid; n < N; n += 256) {
-    const int l = l_of[n], w = 2 * l + 1, base = l * l;
-    sm_v[n] = svec[(size_t)b * nl + l] * R[blk[l] + (rt ? (n - base) * w + l : l * w + (n - base))];
+  const double c = cs[((size_t)b * Ph + kr) * 2];
+  const double sn = k < Ph ? cs[((size_t)b * Ph + kr) * 2 + 1] : -cs[((size_t)b * Ph + kr) * 2 + 1];   // (-phi: the mirror latitude)
+  if (tid < nl) {
+    const int m = tid;
+    double nmm = 1.0;
+    for (int j = 1; j <= m; ++j) nmm *= sqrt((double)(2 * j - 1) / (double)(2 * j)) * sn;
+    const int t4 = m & 3;
+    const double sg = (m & 1) ? -1.0 : 1.0, r2 = 1.4142135623730951;
+    const double fc = m == 0 ? 1.0 : sg * r2 * (t4 == 0 ? 1.0 : (t4 == 2 ? -1.0 : 0.0));     // on N_l^m at order +m
+    const double fs = m == 0 ? 0.0 : -sg * r2 * (t4 == 1 ? 1.0 : (t4 == 3 ? -1.0 : 0.0));    // at order -m
+    double p2 = 0.0, p1 = nmm;
+    for (int l = m; l < nl; ++l) {
+      double v = nmm;
+      if (l > m) {
+        v = ((double)(2 * l - 1) * c * p1 - sqrt((double)((l - 1) * (l - 1) - m * m)) * p2) / sqrt((double)(l * l - m * m));
+        p2 = p1;
+        p1 = v;
+      }
+      const double sl = svec[(size_t)b * nl + l];
+      sm_v[l * l + l + m] = sl * fc * v;
+      if (m > 0) sm_v[l * l + l - m] = sl * fs * v;
+    }
   }
   __syncthreads();
   const double scale = sc[(size_t)b * 2 * P + k];
@@ -246,7 +292,7 @@ int sp_polar_moments_samples(sp_handle *h, int B, const double *samples_host, do
   if (!h || !samples_host || !ez_dev || !Ez_dev || B < 0 || B > 65535) return SP_ERR_INVALID;
   if (!h->d_size_basis) return SP_ERR_STATE;
   if (B == 0) return SP_OK;
-  const int N = h->N, NWIG = h->NWIG, nl = h->ydeg + 1, nq = h->ydeg + 2, P = 2 * nq, spts = h->size_spts;
+  const int N = h->N, nl = h->ydeg + 1, nq = h->ydeg + 2, P = 2 * nq, spts = h->size_spts;
   if (P > SM_TK) return SP_ERR_INVALID;
   for (int b = 0; b < B; ++b) {
     const double *s = samples_host + 5 * (size_t)b;
@@ -257,37 +303,26 @@ int sp_polar_moments_samples(sp_handle *h, int B, const double *samples_host, do
   }
   hipStream_t st = (hipStream_t)stream;
   SP_HIP(hipSetDevice(h->device));
-  // scratch: Rphi [B nq][NWIG] | svec [B][nl] | cs [B nq][2] | sc [B][2][P] | scal [B][4] | T [B][N][64] | M [B][N][N] | e1 [B][N]
+  // scratch: svec [B][nl] | cs [B nq][2] | sc [B][2][P] | scal [B][4] | T [B][N][64] | M [B][N][N] | e1 [B][N]
   size_t off = 0;
   auto take = [&](size_t doubles) { size_t o = off; off += sm_align(sizeof(double) * doubles); return o; };
-  const size_t oR = take((size_t)B * nq * NWIG), oS = take((size_t)B * nl), oC = take((size_t)B * nq * 2),
+  const size_t oS = take((size_t)B * nl), oC = take((size_t)B * nq * 2),
                oSc = take((size_t)B * 2 * P), oSl = take((size_t)B * 4), oT = take((size_t)B * N * SM_TK),
                oM = take((size_t)B * N * N), oE = take((size_t)B * N);
   void *ws = nullptr;
   int rc = ensure_big_scratch(h, off, &ws);
   if (rc) return rc;
   auto at = [&](size_t o) { return reinterpret_cast<double *>(reinterpret_cast<char *>(ws) + o); };
-  double *Rphi = at(oR), *svec = at(oS), *cs = at(oC), *sc = at(oSc), *scal = at(oSl), *T = at(oT), *M = at(oM),
+  double *svec = at(oS), *cs = at(oC), *sc = at(oSc), *scal = at(oSl), *T = at(oT), *M = at(oM),
          *e1 = at(oE);
   // ONE staged upload: the samples
-  sp_handle::CsSlot &c = h->cs_ring[h->cs_next];
-  h->cs_next = (h->cs_next + 1) & 3;
   const size_t need = 5 * (size_t)B;
-  if (c.used) SP_HIP(hipEventSynchronize(c.done));
-  if (c.cap < need) {
-    if (c.host) SP_HIP(hipHostFree(c.host));
-    if (c.dev) SP_HIP(hipFree(c.dev));
-    c.host = c.dev = nullptr;
-    c.cap = 0;
-    const size_t cap = need < 512 ? 512 : need;
-    SP_HIP(hipHostMalloc((void **)&c.host, sizeof(double) * cap, hipHostMallocDefault));
-    SP_HIP(hipMalloc((void **)&c.dev, sizeof(double) * cap));
-    c.cap = cap;
-  }
-  if (!c.done) SP_HIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+  sp_handle::CsSlot *cp = nullptr;
+  if ((rc = sp_stage_acquire(h, need, &cp))) return rc;
+  sp_handle::CsSlot &c = *cp;
   memcpy(c.host, samples_host, sizeof(double) * need);
   SP_HIP(hipMemcpyAsync(c.dev, c.host, sizeof(double) * need, hipMemcpyHostToDevice, st));
-  const size_t lds1 = sizeof(double) * ((size_t)spts + 4 * nq);
+  const size_t lds1 = sizeof(double) * ((size_t)spts + 4 * nq + 128);      // (+ 256 ints of flags)
   if (lds1 > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sm_prepare_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds1);
@@ -296,9 +331,8 @@ int sp_polar_moments_samples(sp_handle *h, int B, const double *samples_host, do
   SP_LAUNCH_CHECK();
   SP_HIP(hipEventRecord(c.done, st));
   c.used = true;
-  if ((rc = sp_launch_Rx(h, cs, B * nq, Rphi, nullptr, st))) return rc;
-  hipLaunchKernelGGL(sm_rows_kernel, dim3(SM_TK, B), dim3(256), sizeof(double) * N, st, N, nl, P, NWIG, h->d_l_of, h->d_blk,
-                     svec, Rphi, h->d_Rx90, sc, T);
+  hipLaunchKernelGGL(sm_rows_kernel, dim3(SM_TK, B), dim3(256), sizeof(double) * N, st, h->ydeg, N, P, h->d_l_of, h->d_blk,
+                     svec, cs, h->d_Rx90, sc, T);
   SP_LAUNCH_CHECK();
   hipLaunchKernelGGL(sm_first_kernel, dim3(B), dim3(256), 0, st, N, P, h->d_m_of, sc, T, e1);
   SP_LAUNCH_CHECK();

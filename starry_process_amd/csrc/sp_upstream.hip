@@ -176,20 +176,10 @@ extern "C" int sp_ylm_moments_quadrature(sp_handle *h, const double *vecs_host, 
          *m1 = at(om1), *part = at(opart), *Cp = at(oC);
 
   // ONE staged upload: cos / sin of the latitudes, sqrt weights, plain weights, the vectors
-  sp_handle::CsSlot &c = h->cs_ring[h->cs_next];
-  h->cs_next = (h->cs_next + 1) & 3;
   const size_t need = 2 * (size_t)P + 2 * (size_t)P + (size_t)mv * N;
-  if (c.used) SP_HIP(hipEventSynchronize(c.done));
-  if (c.cap < need) {
-    if (c.host) SP_HIP(hipHostFree(c.host));
-    if (c.dev) SP_HIP(hipFree(c.dev));
-    c.host = c.dev = nullptr;
-    c.cap = 0;
-    SP_HIP(hipHostMalloc((void **)&c.host, sizeof(double) * need, hipHostMallocDefault));
-    SP_HIP(hipMalloc((void **)&c.dev, sizeof(double) * need));
-    c.cap = need;
-  }
-  if (!c.done) SP_HIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+  sp_handle::CsSlot *cp = nullptr;
+  if ((rc = sp_stage_acquire(h, need, &cp))) return rc;
+  sp_handle::CsSlot &c = *cp;
   double *hcs = c.host, *hsw = hcs + 2 * P, *hw = hsw + P, *hv = hw + P;
   for (int k = 0; k < P; ++k) {
     hcs[2 * k] = std::cos(phi_host[k]);
@@ -393,20 +383,10 @@ extern "C" int sp_ylm_moments_quadrature_grad(sp_handle *h, const double *s_host
 
   // ONE staged upload: cos / sin of the Ph latitudes | coefficients [P][UPG][3] | sqrt weights [P] | their
   // derivatives [UPG][P] | s, ds/dr [2][N]
-  sp_handle::CsSlot &c = h->cs_ring[h->cs_next];
-  h->cs_next = (h->cs_next + 1) & 3;
   const size_t need = 2 * (size_t)Ph + (size_t)P * UPG * 3 + (size_t)P + (size_t)UPG * P + 2 * (size_t)N;
-  if (c.used) SP_HIP(hipEventSynchronize(c.done));
-  if (c.cap < need) {
-    if (c.host) SP_HIP(hipHostFree(c.host));
-    if (c.dev) SP_HIP(hipFree(c.dev));
-    c.host = c.dev = nullptr;
-    c.cap = 0;
-    SP_HIP(hipHostMalloc((void **)&c.host, sizeof(double) * need, hipHostMallocDefault));
-    SP_HIP(hipMalloc((void **)&c.dev, sizeof(double) * need));
-    c.cap = need;
-  }
-  if (!c.done) SP_HIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+  sp_handle::CsSlot *cp = nullptr;
+  if ((rc = sp_stage_acquire(h, need, &cp))) return rc;
+  sp_handle::CsSlot &c = *cp;
   double *hcs = c.host, *hco = hcs + 2 * Ph, *hsq = hco + (size_t)P * UPG * 3, *hdsq = hsq + P, *hsv = hdsq + (size_t)UPG * P;
   for (int k = 0; k < Ph; ++k) {
     hcs[2 * k] = std::cos(phi_host[k]);

@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256) void rx_kernel(int ydeg,
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int bs = (2 * ydeg + 1) * (2 * ydeg + 1);
   double *Dbuf[3] = {lds, lds + bs, lds + 2 * bs};
-  double *Pbuf[3] = {lds + 3 * bs, lds + 4 * bs, lds + 5 * bs};
+  // (without the derivative the launch asks for the three value buffers only: twice the workgroups per CU)
+  double *Pbuf[3] = {WITH_DERIV ? lds + 3 * bs : lds, WITH_DERIV ? lds + 4 * bs : lds, WITH_DERIV ? lds + 5 * bs : lds};
   const int tid = threadIdx.x;
   const int nthr = blockDim.x;
   const double c2 = cs[2 * blockIdx.x], s2 = cs[2 * blockIdx.x + 1];
@@ -48,25 +49,27 @@ __global__ __launch_bounds__(256) void rx_kernel(int ydeg,
   if (tid == 0) {
     double *D0 = Dbuf[0], *D1 = Dbuf[1], *P0 = Pbuf[0], *P1 = Pbuf[1];
     D0[0] = 1.0;
-    P0[0] = 0.0;
     D1[8] = 0.5 * (1.0 + c2);
-    P1[8] = 0.5 * c2p;
     D1[7] = -s2 / r2;
-    P1[7] = -s2p / r2;
     D1[6] = 0.5 * (1.0 - c2);
-    P1[6] = -0.5 * c2p;
     D1[5] = -D1[7];
-    P1[5] = -P1[7];
     D1[4] = D1[8] - D1[6];
-    P1[4] = P1[8] - P1[6];
     D1[3] = D1[7];
-    P1[3] = P1[7];
     D1[2] = D1[6];
-    P1[2] = P1[6];
     D1[1] = D1[5];
-    P1[1] = P1[5];
     D1[0] = D1[8];
-    P1[0] = P1[8];
+    if (WITH_DERIV) {      // (without the derivative the P buffers do not exist: rx_kernel's launch)
+      P0[0] = 0.0;
+      P1[8] = 0.5 * c2p;
+      P1[7] = -s2p / r2;
+      P1[6] = -0.5 * c2p;
+      P1[5] = -P1[7];
+      P1[4] = P1[8] - P1[6];
+      P1[3] = P1[7];
+      P1[2] = P1[6];
+      P1[1] = P1[5];
+      P1[0] = P1[8];
+    }
     R[0] = 1.0;
     if (WITH_DERIV) Rp[0] = 0.0;
     if (ydeg >= 1) {
@@ -525,7 +528,7 @@ __global__ __launch_bounds__(256) void special_series_kernel(
 int sp_launch_Rx(sp_handle *h, const double *cs_dev, int n, double *R,
                  double *dR, hipStream_t st) {
   const int bs = (2 * h->ydeg + 1) * (2 * h->ydeg + 1);
-  const size_t lds = (size_t)6 * bs * sizeof(double);
+  const size_t lds = (size_t)(dR ? 6 : 3) * bs * sizeof(double);
   if (dR)
     hipLaunchKernelGGL(rx_kernel<true>, dim3(n), dim3(256), lds, st, h->ydeg,
                        cs_dev, h->d_blk, h->NWIG, R, dR);

@@ -64,8 +64,43 @@ def test_polar_frame_projection_is_the_quadrature_of_rotations(hyper):
     assert np.abs(Ez - Ez2).max() < 1e-13 * np.abs(Ez).max()
 
 
+def legendre_row0(ydeg, c, s):
+    """Row m' = 0 of every degree's real rotation block about x by the angle of cosine c and sine s, the way
+    sm_rows_kernel computes it (normalised associated Legendre recurrence)."""
+    out = np.zeros((ydeg + 1) ** 2)
+    nmm = 1.0
+    for m in range(ydeg + 1):
+        if m > 0:
+            nmm *= np.sqrt((2 * m - 1) / (2 * m)) * s
+        p2, p1 = 0.0, nmm
+        sg, t4 = (-1.0) ** m, m % 4
+        for l in range(m, ydeg + 1):
+            v = nmm
+            if l > m:
+                v = ((2 * l - 1) * c * p1 - np.sqrt((l - 1) ** 2 - m * m) * p2) / np.sqrt(l * l - m * m)
+                p2, p1 = p1, v
+            if m == 0:
+                out[l * l + l] = v
+            else:
+                out[l * l + l + m] = sg * np.sqrt(2.0) * [1, 0, -1, 0][t4] * v
+                out[l * l + l - m] = -sg * np.sqrt(2.0) * [0, 1, 0, -1][t4] * v
+    return out
+
+
+def test_rotated_zonal_vector_is_a_row_of_legendre_functions():
+    """s Rx(phi) for a zonal s: row m' = 0 of sp_Rx's blocks (wigner.h:36-284) = d^l_{m0}(phi) in the real basis."""
+    from oracle import sp_oracle as orc
+
+    for ydeg in (5, 15, 20):
+        for th in (0.3, -0.3, 1.2, -2.0, 0.5 * np.pi, 1e-3, -1e-9, 3.1):
+            R = orc.Rx(ydeg, th)[0]
+            ref = np.concatenate([R[(orc.nwig(l - 1) if l else 0):orc.nwig(l)].reshape(2 * l + 1, 2 * l + 1)[l]
+                                  for l in range(ydeg + 1)])
+            assert np.abs(legendre_row0(ydeg, np.cos(th), np.sin(th)) - ref).max() < 5e-14, (ydeg, th)
+
+
 def bisection_gauss_jacobi(n, a, b):
-    """sm_prepare_kernel's rule: node i = i-th eigenvalue of the Jacobi matrix by bisection on the Sturm count (pivots
+    """sm_prepare_kernel's rule: node i = i-th eigenvalue of the Jacobi matrix by multi-section on the Sturm count (pivots
     below 1e-290 are replaced by -1e-290 BEFORE they are counted and used), weights from the orthonormal recurrence."""
     d, e = np.zeros(n), np.zeros(n)
     ab = a + b
@@ -77,24 +112,33 @@ def bisection_gauss_jacobi(n, a, b):
             4.0 * k * (k + a) * (k + b) * (k + ab) / ((s * s) * (s + 1) * (s - 1))
         e[k - 1] = np.sqrt(num)
     e2 = e * e
+
+    def count_below(x):
+        q = d[0] - x
+        if abs(q) < 1e-290:
+            q = -1e-290
+        cnt = int(q < 0)
+        for k in range(1, n):
+            q = d[k] - x - e2[k - 1] / q
+            if abs(q) < 1e-290:
+                q = -1e-290
+            cnt += int(q < 0)
+        return cnt
+
+    npt = min(15, 256 // n)            # trial points per node and round (a group of threads per node on the device)
+    rounds, span = 0, 2.0
+    while span > 3.0e-18:
+        rounds, span = rounds + 1, span / (npt + 1)
     t = np.zeros(n)
     for i in range(n):
         lo, hi = -1.0, 1.0
-        for _ in range(58):
-            x = 0.5 * (lo + hi)
-            q = d[0] - x
-            if abs(q) < 1e-290:
-                q = -1e-290
-            cnt = int(q < 0)
-            for k in range(1, n):
-                q = d[k] - x - e2[k - 1] / q
-                if abs(q) < 1e-290:
-                    q = -1e-290
-                cnt += int(q < 0)
-            if cnt > i:
-                hi = x
-            else:
-                lo = x
+        for _ in range(rounds):
+            below = sum(1 - int(count_below(lo + (hi - lo) * ((j + 1) / (npt + 1))) > i) for j in range(npt))
+            w0, l0 = hi - lo, lo
+            if below > 0:
+                lo = l0 + w0 * (below / (npt + 1))
+            if below < npt:
+                hi = l0 + w0 * ((below + 1) / (npt + 1))
         t[i] = 0.5 * (lo + hi)
     w = np.zeros(n)
     for i in range(n):
