@@ -503,6 +503,11 @@ int sp_profile_end(sp_handle *h, long *launches, double *total_ms, double *flops
  * Kinds 1 and 3 are not produced any more.  Scopes nest.  Stops the profile like sp_profile_end;
  * may be called for several kinds in a row.                                                  */
 int sp_profile_kind(sp_handle *h, int kind, long *launches, double *total_ms, double *flops);
+/* The same with both flop counts (round 6): `flops` is the ALGORITHMIC count -- the K cadences' rows and the M residual
+ * rows, the last pivot block as wide as it is --, `flops_padded` the count on the padded system the launches execute
+ * (rows up to roundup(K + M + 2, 64), every block 64 wide: 7 % more at K = 1000), which rounds 1-5 reported as the
+ * former.  sp_profile_kind / sp_profile_end return the algorithmic count.                                      */
+int sp_profile_kind_ex(sp_handle *h, int kind, long *launches, double *total_ms, double *flops, double *flops_padded);
 /* sp_profile_begin for a chosen set of kinds (bit k of kind_mask = kind k; sp_profile_begin
  * = kind 0 only).  An event pair costs a few microseconds of stream time: bracket every panel
  * launch (17 per K = 1000 factorisation) only outside timed regions.                      */

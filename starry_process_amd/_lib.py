@@ -108,6 +108,7 @@ PROTOTYPES = {
     "sp_debug_set_look_ahead": (_I, [_V, _I]),
     "sp_debug_set_panel_layout": (_I, [_V, _I, _I]),
     "sp_profile_kind": (_I, [_V, _I, ctypes.POINTER(ctypes.c_long), c_double_p, c_double_p]),
+    "sp_profile_kind_ex": (_I, [_V, _I, ctypes.POINTER(ctypes.c_long), c_double_p, c_double_p, c_double_p]),
     "sp_set_lazy_cov": (_I, [_V, _I]),
     "sp_set_defer_norm": (_I, [_V, _I]),
     "sp_profile_begin_kinds": (_I, [_V, _I, ctypes.c_uint]),

@@ -30,7 +30,7 @@ __all__ = ["get_log_prob", "get_log_prob_ensemble", "EnsembleLogProb", "SampleBa
 
 # Independent evaluations in flight on one GPU.  Four is where the throughput peaks; a fifth stream LOSES 10-25 %
 # (108k against 120k evaluations/s at cfg3's shape, bench.py; EnsembleLogProb 0.584 -> 0.818 ms per sample with
-# four likelihood streams + the upstream's own, tools/elp_modes.py, round 5) -- next to GPU_MAX_HW_QUEUES
+# four likelihood streams + the upstream's own, tools/attic/elp_modes.py, round 5) -- next to GPU_MAX_HW_QUEUES
 # (engine._want_hw_queues).  Callers' ``depth`` is clamped to it, with one warning.
 MAX_STREAMS = 4
 _warned_depth = [False]
@@ -237,7 +237,7 @@ class EnsembleLogProb(object):
     latency per sample that a likelihood stream would otherwise sit through with its share of
     the GPU idle: 0.726 -> 0.69 ms per sample with three likelihood streams + this one (a fifth stream in
     flight loses more than it hides: 0.83 -- the same cliff bench.py sees at five steps in flight; round 5, one box,
-    tools/elp_modes.py: 0.584 as shipped, 0.603 with the moments on the three likelihood streams themselves
+    tools/attic/elp_modes.py: 0.584 as shipped, 0.603 with the moments on the three likelihood streams themselves
     (upstream_stream=False), 0.699 on four of them, 0.818 with four + the upstream's own).  Under an initialised
     ``torch.distributed`` job the stars are sharded over the ranks and the per-sample sums are
     combined with ONE all-reduce for the whole batch."""

@@ -863,6 +863,7 @@ int sp_profile_begin_kinds(sp_handle *h, int max_launches, unsigned kind_mask) {
   }
   h->prof_kind.assign(h->prof_ev.size() / 2, 0);
   h->prof_fl.assign(h->prof_ev.size() / 2, 0.0);
+  h->prof_flp.assign(h->prof_ev.size() / 2, 0.0);
   h->prof_n.assign(h->prof_ev.size() / 2, 0);
   h->prof_used = 0;
   h->prof_on = true;
@@ -870,10 +871,14 @@ int sp_profile_begin_kinds(sp_handle *h, int max_launches, unsigned kind_mask) {
 }
 
 int sp_profile_kind(sp_handle *h, int kind, long *launches, double *total_ms, double *flops) {
+  return sp_profile_kind_ex(h, kind, launches, total_ms, flops, nullptr);
+}
+
+int sp_profile_kind_ex(sp_handle *h, int kind, long *launches, double *total_ms, double *flops, double *flops_padded) {
   if (h && h->device < 0) return SP_ERR_NO_DEVICE;
   if (!h || kind < 0 || kind >= SP_PROF_NKINDS) return SP_ERR_INVALID;
   h->prof_on = false;
-  double ms = 0.0, fl = 0.0;
+  double ms = 0.0, fl = 0.0, flp = 0.0;
   long n = 0;
   for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
     if (h->prof_kind[i / 2] != kind) continue;
@@ -882,11 +887,13 @@ int sp_profile_kind(sp_handle *h, int kind, long *launches, double *total_ms, do
     SP_HIP(hipEventElapsedTime(&dt, h->prof_ev[i], h->prof_ev[i + 1]));
     ms += dt;
     fl += h->prof_fl[i / 2];
+    flp += h->prof_flp[i / 2];
     n += h->prof_n[i / 2];
   }
   if (launches) *launches = n;
   if (total_ms) *total_ms = ms;
   if (flops) *flops = fl;
+  if (flops_padded) *flops_padded = flp;
   return SP_OK;
 }
 

@@ -807,7 +807,7 @@ extern "C" int sp_debug_asm_stamps(long long *out, int n) {
 
 // Chunks of equal COST, not of equal length: a tile of the last row tile (masks, residual rows, identity padding; it
 // also ends its strip: the column sums' trip through LDS) costs 3.8 tiles, a tile that is written (the diagonal one,
-// any tile of strip 0) 1.2 -- per-workgroup stamps, tools/asm_wall.py: with 17 tiles each the workgroup of the last
+// any tile of strip 0) 1.2 -- per-workgroup stamps, tools/attic/asm_wall.py: with 17 tiles each the workgroup of the last
 // strips (five last-row tiles) ran for 50-58 us, the others for 33-37, and the launch lasted as long as it did.  The
 // weights depend on the shape alone -- not on the batch, not on which tiles are left to their first touch: a star's
 // sums are the same bits whoever shares its launch and whichever way its tiles are formed.

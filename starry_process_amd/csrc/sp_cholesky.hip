@@ -251,10 +251,19 @@ static int cholesky_panel2(sp_handle *h, int ngroups, const sp_chol_group *grp, 
         for (int g = 0; g < ngroups; ++g) {
           const sp_chol_group &G = grp[g];
           const LazyCov *lzp = (G.lazy.theta && s0 == 0 && !G.lazy.no_panels) ? &G.lazy : nullptr;
-          // algorithmic work as the per-panel drivers have always counted it: left-looking product,
-          // triangular solve, eager rank-64 updates, the diagonal block
-          const double fl = (double)G.S * (2.0 * rows * 64 * (q * 64.0) + rows * 64 * 64 +
-                                           neager * 64.0 * 64 * 64 + 64.0 * 64 * 64 / 3);
+          // Work of the launch: left-looking product, triangular solve, eager rank-64 updates, the diagonal block.
+          // flp: on the PADDED system, every block 64 wide, all (ntile - j - 1) 64 rows below it -- what the launch
+          // executes (rounds 1-5 reported this as the algorithmic count: 7 % high at K = 1000, Kp = 1024).
+          // fl: the ALGORITHMIC count -- the K cadences' rows and the M riding residual rows (the forward solve of
+          // math.py:98) below a block of nact = min(64, K - 64 j) columns; padding rows and the normalisation's
+          // riding rows are the implementation's.
+          const double flp = (double)G.S * (2.0 * rows * 64 * (q * 64.0) + rows * 64 * 64 +
+                                            neager * 64.0 * 64 * 64 + 64.0 * 64 * 64 / 3);
+          const double na = nact_of(j), rk0 = (double)(K - (j + 1) * SP_NB);
+          const double rowsK = (rk0 > 0 ? rk0 : 0.0) + (rows > 0 ? (double)G.red.M : 0.0);
+          double eag = 0.0;      // eager updates: the diagonal blocks j + 1 .. last take a rank-nact update each
+          for (int i2 = j + 1; i2 <= last && i2 < nsteps; ++i2) eag += (double)nact_of(i2) * nact_of(i2) * na;
+          const double fl = (double)G.S * (2.0 * rowsK * na * (q * 64.0) + rowsK * na * na + eag + na * na * na / 3);
           const bool d_alone = j == 0;                         // block 0: nobody before it
           // block j + 1 in the tail of this launch (same super-panel: the next one's first block
           // belongs to the trailing update)
@@ -263,12 +272,12 @@ static int cholesky_panel2(sp_handle *h, int ngroups, const sp_chol_group *grp, 
           const bool first_la = la_on && q >= 2 && rows > 0;   // (launch j - 1 qualified: q - 1 >= 1, j + 1 < ntile)
           const int nl = (d_alone && !G.block0_done && rows > 0) ? 2 : 1;
           if (!d_alone && rows <= 0) {   // the last pivot block with no row tile below it: factored in launch j - 1's tail
-            sp_scope.add(fl, 0);
+            sp_scope.add(fl, 0, flp);
             continue;
           }
-          SpProfScope prof(h, G.st, SP_PROF_CHAIN, fl, nl);
-          SpProfScope prof1(h, G.st, SP_PROF_PANEL_LAUNCH, fl, nl);
-          sp_scope.add(fl, nl);
+          SpProfScope prof(h, G.st, SP_PROF_CHAIN, fl, nl, flp);
+          SpProfScope prof1(h, G.st, SP_PROF_PANEL_LAUNCH, fl, nl, flp);
+          sp_scope.add(fl, nl, flp);
           int rc = SP_OK;
           if (d_alone && !G.block0_done)
             rc = sp_launch_panel2(h->panel_layout | (tri0 >= 0 ? (2 | (tri0 << 8)) : 0), nullptr, G.sys, ld, stride, G.S, ntile, j, s0, nact_of(j), 0, last, SP_PANEL_D,
@@ -300,7 +309,9 @@ static int cholesky_panel2(sp_handle *h, int ngroups, const sp_chol_group *grp, 
         LazyCov lzv = G.lazy;
         lzv.tr0 = lzv.tc0 = jE;
         DiagFuse df{G.sys, ld, stride, jE, nact_of(jE), G.invL, lts, G.info, tri0, s0};
-        SpProfScope prof(h, G.st, SP_PROF_SYRK, (double)G.S * (double)n * (n + 1) * kd);
+        // (algorithmic: the rows of the K cadences and the M residual rows; executed: every row of the padded system)
+        const double nK = (double)(K + G.red.M - cE) > 0 ? (double)(K + G.red.M - cE) : 0.0;
+        SpProfScope prof(h, G.st, SP_PROF_SYRK, (double)G.S * nK * (nK + 1) * kd, 1, (double)G.S * (double)n * (n + 1) * kd);
 #ifdef SP_PROBE
         static const bool probe_skip_mm = getenv("SP_PROBE_SKIP_MM2") != nullptr;
         if (probe_skip_mm) continue;

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256, SP_MM_WAVES) void mm_nt_kernel(
 // block above the diagonal -- (R0, R0 + 1) -- and the pivot block (0, 0) are computed and not stored (2.4 % of the
 // blocks at nb = 39).  One more workgroup factors the pivot block (DiagFuse), as in mm_nt_kernel.  Twice the
 // flops per operand byte and per barrier of the 64 x 64 tiles: 0.777 against 0.720 of the fp64 peak on a full
-// product of the size (tools/mm_tile_bench.py); for small remainders the wasted blocks weigh more than that
+// product of the size (tools/attic/mm_tile_bench.py); for small remainders the wasted blocks weigh more than that
 // (nb = 8: 40 blocks executed for 35) and the 64 x 64 kernel stays (sp_launch_syrk_diag).
 using Syrk128Core = MM2<128, 64, 8, 4, 4>;
 #ifndef SP_SYRK128_WGS
@@ -452,7 +452,7 @@ static int launch_gemm(const double *A, long lda, long strideA, const double *B,
     // 128 x 128 tiles for full products of that granularity (0.80 of peak against 0.73), 64 x 64
     // tiles otherwise (lower-triangular updates: no wasted half tiles)
 #ifdef SP_MM_TILE_PROBE
-    // (tools/mm_tile_bench.py: the engine's tile shapes against each other on one full product)
+    // (tools/attic/mm_tile_bench.py: the engine's tile shapes against each other on one full product)
     static const int probe = getenv("SP_MM_TILE") ? atoi(getenv("SP_MM_TILE")) : 0;
     if (!lower_only && probe == 1 && (Mrows % 128) == 0)
       return mm_launch<MM2<128, 64, 8, 4, 4>>(A, lda, strideA, B, ldb, strideB, C, ldc, strideC, Mrows, Nrows, Kd, alpha,

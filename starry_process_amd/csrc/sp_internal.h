@@ -80,7 +80,8 @@ struct sp_handle {
   unsigned prof_mask;                // kinds that are bracketed (bit k = kind k)
   std::vector<hipEvent_t> prof_ev;   // pairs (start, stop)
   std::vector<int> prof_kind;        // kind of pair i
-  std::vector<double> prof_fl;       // algorithmic flops of pair i
+  std::vector<double> prof_fl;       // algorithmic flops of pair i, counted on the K cadences (+ the M riding residual rows)
+  std::vector<double> prof_flp;      // the same count on the PADDED system (rows up to roundup(K + M + 2, 64)): what runs
   std::vector<int> prof_n;           // launches bracketed by pair i
   size_t prof_used;                  // events handed out so far
 };
@@ -102,27 +103,30 @@ struct SpProfScope {
   hipStream_t st;
   bool on;
   size_t idx;     // first event of this scope's pair
-  SpProfScope(sp_handle *h_, hipStream_t st_, int kind, double flops, int launches = 1)
+  SpProfScope(sp_handle *h_, hipStream_t st_, int kind, double flops, int launches = 1, double flops_padded = -1.0)
       : h(h_), st(st_), on(false), idx(0) {
     if (!h || !h->prof_on || !((h->prof_mask >> kind) & 1u) || h->prof_used + 2 > h->prof_ev.size()) return;
     idx = h->prof_used;
     h->prof_used += 2;
     h->prof_kind[idx / 2] = kind;
     h->prof_fl[idx / 2] = flops;
+    h->prof_flp[idx / 2] = flops_padded < 0.0 ? flops : flops_padded;
     h->prof_n[idx / 2] = launches;
     // (a pair whose start could not be recorded stays reserved with zero launches: read as empty)
     if (hipEventRecord(h->prof_ev[idx], st) != hipSuccess) {
       h->prof_n[idx / 2] = 0;
       h->prof_fl[idx / 2] = 0.0;
+      h->prof_flp[idx / 2] = 0.0;
       h->prof_kind[idx / 2] = -1;
       return;
     }
     on = true;
   }
   // (a scope around several launches: add each one's algorithmic flops as it is issued)
-  void add(double flops, int launches = 1) {
+  void add(double flops, int launches = 1, double flops_padded = -1.0) {
     if (!on) return;
     h->prof_fl[idx / 2] += flops;
+    h->prof_flp[idx / 2] += flops_padded < 0.0 ? flops : flops_padded;
     h->prof_n[idx / 2] += launches;
   }
   ~SpProfScope() {

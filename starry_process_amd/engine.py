@@ -303,14 +303,16 @@ class Engine(object):
             mask |= 1 << self.PROF_KINDS[k]
         check(self._L.sp_profile_begin_kinds(self._h, int(max_launches), mask))
 
-    def profile_kind(self, kind):
-        """(launches, summed milliseconds, summed algorithmic flops) of one kind; ends the profile."""
+    def profile_kind(self, kind, padded=False):
+        """(launches, summed milliseconds, summed algorithmic flops) of one kind; ends the profile.  padded: a fourth
+        value, the flops on the padded system the launches execute (sp_profile_kind_ex)."""
         n = ctypes.c_long()
         ms = ctypes.c_double()
         fl = ctypes.c_double()
-        check(self._L.sp_profile_kind(self._h, self.PROF_KINDS[kind], ctypes.byref(n), ctypes.byref(ms),
-                                      ctypes.byref(fl)))
-        return n.value, ms.value, fl.value
+        flp = ctypes.c_double()
+        check(self._L.sp_profile_kind_ex(self._h, self.PROF_KINDS[kind], ctypes.byref(n), ctypes.byref(ms),
+                                         ctypes.byref(fl), ctypes.byref(flp)))
+        return (n.value, ms.value, fl.value, flp.value) if padded else (n.value, ms.value, fl.value)
 
     def profile_end(self):
         n = ctypes.c_long()
@@ -737,7 +739,9 @@ def engine_slots(ydeg=15, udeg=2, device=None, depth=3):
     each with its own workspace and outputs.  One evaluation alone leaves most of the GPU idle
     during its latency-bound phases (the chain of diagonal blocks); with three in flight those
     overlap the neighbours' assembly and trailing updates: 0.95 -> 0.66 ms per 64-star step
-    (bench.py).  A handle is not re-entrant, hence one per slot (fresh handles; the
+    (bench.py).  FOUR is where it peaks: a fifth stream in flight loses 10-25 % (108k against 120k
+    evaluations/s at cfg3's shape; calibrate.MAX_STREAMS, to which the callers' ``depth`` is clamped -- this function
+    gives what it is asked for, bench.py measures the cliff with it).  A handle is not re-entrant, hence one per slot (fresh handles; the
     process-wide engine of ``get_engine`` is left as it is, and is what depth = 1 returns)."""
     torch = _torch()
     depth = max(1, int(depth))

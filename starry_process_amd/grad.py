@@ -592,6 +592,16 @@ def ensemble_gradient_conditional(t, flux, ferr=1.0e-3, p=1.0, i=defaults["i"], 
         out["c"] = float(gmu @ mu / c + 2.0 * np.sum(gSig * S0) / c)
         out["n"] = float(gmu @ mu / n + np.sum(gSig * S0) / n)
     else:
-        out["c"] = out["n"] = 0.0
+        # On the boundary c = 0 or n = 0 the moments at the point hold nothing to divide by, but the derivative is not
+        # zero there: with the moments at unit contrast and unit number of spots, mu = c n m1 and Sigma - eps = c^2 n S1
+        # give d/dc = n gmu.m1 + 2 c n <gSig, S1> and d/dn = c gmu.m1 + c^2 <gSig, S1> -- what hyper_gradient and
+        # EnsembleGradient return there too (one more upstream evaluation).
+        from .upstream_device import ylm_moments_device
+
+        m1, Sig1 = [x.cpu().numpy() for x in ylm_moments_device(e, r=r, a=a, b=b, c=1.0, n=1.0, **ukw)]
+        S1 = Sig1 - np.diag(eps)
+        gm, gS = float(gmu @ m1), float(np.sum(gSig * S1))
+        out["c"] = float(n) * gm + 2.0 * float(c) * float(n) * gS
+        out["n"] = float(c) * gm + float(c) ** 2 * gS
     out["i"], out["p"] = gi, gp
     return float(lnl.sum()), out, lnl

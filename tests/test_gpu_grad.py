@@ -515,6 +515,33 @@ def test_conditional_ensemble_gradient_against_finite_differences_of_the_oracle(
         assert abs(g["p"][s] - fd) < 2e-5 * max(abs(fd), 1.0), ("p", s, g["p"][s], fd)
 
 
+def test_conditional_ensemble_gradient_on_the_boundary_of_the_box():
+    """c = 0 (no contrast: where a bounded optimiser sits): mu = c n m1, Sigma - eps = c^2 n S1 give d/dc = n gmu.m1 there,
+    not zero -- the three gradient entry points agree at the boundary."""
+    from starry_process_amd.grad import ensemble_gradient_conditional
+
+    S, K = 2, 80
+    t, flux, p, sts = _ensemble(S, K, seed0=41)
+    inc = np.array([40.0, 70.0])
+    hp = dict(r=20.0, a=0.40, b=0.27, c=0.0, n=10.0)
+    total, g, lnl = ensemble_gradient_conditional(t, flux, ferr=1e-3, p=p, i=inc, normalized=True, **hp)
+
+    def f(d, name="c"):
+        q = dict(hp)
+        q[name] = hp[name] + d
+        mu, Sig = _oracle_moments(q["r"], q["a"], q["b"], q["c"], q["n"])
+        return sum(_oracle_lnlike(mu, Sig, t[s], flux[s], 1e-6, marg=False, normalized=True, i=float(inc[s]),
+                                  p=float(p[s])) for s in range(S))
+
+    assert abs(total - f(0.0)) < 1e-8 * abs(total)
+    # (mu is odd and Sigma even in c: the oracle evaluates c < 0 as well.  The step is small: c^2 n S overtakes the
+    #  noise variance at c ~ 1e-3, the series in c converges slowly beyond a tenth of that)
+    fd = _central(f, 3e-6)
+    assert abs(fd) > 0.05 and abs(g["c"] - fd) < 1e-4 * max(abs(fd), 1.0), (g["c"], fd)
+    fdn = _central(lambda d: f(d, "n"), 1e-3)
+    assert abs(g["n"] - fdn) < 1e-6 * max(abs(fd), 1.0), (g["n"], fdn)
+
+
 def test_new_entry_points_refuse_bad_arguments():
     """The C ABI does not throw (include/starry_process_amd.h): the round's new entry points -- the moments with their
     tangents, the rule's derivatives, the gradient sweep for M light curves -- hand bad arguments back as status codes."""

@@ -65,7 +65,11 @@ def run(e, t, flux, stars, planned, u=(0.0, 0.0), covpts=300, temporal=None, dia
     if planned:
         if plan is None:
             plan = e.plan_data(t_d, f_d, s_d, diag=d_d, covpts=covpts, temporal=temporal)
-        out, status = e.lnlike_ensemble_planned(plan, t_d, f_d, s_d, tab, mv, diag=d_d)
+            out, status = e.lnlike_ensemble_planned(plan, t_d, f_d, s_d, tab, mv, diag=d_d)
+        else:
+            # (a plan of an earlier call: its data are the arrays of plan time -- the call takes them from the plan;
+            #  fresh copies of the same numbers are refused, sp_lnlike_ensemble_planned)
+            out, status = e.lnlike_ensemble_planned(plan, None, None, s_d, tab, mv)
     else:
         out, status = e.lnlike_ensemble(t_d, f_d, s_d, diag=d_d, covpts=covpts, tab=tab, meanvar=mv,
                                         temporal=temporal, normalized=True)

@@ -231,6 +231,35 @@ def test_ensemble_log_prob_packs_samples(e15):
     assert same(v, w, 1e-9)
 
 
+def test_stream_depth_is_clamped_and_large_lag_grids_fall_back():
+    """depth = 6 runs on MAX_STREAMS concurrent streams (a fifth loses 10-25 %, calibrate.MAX_STREAMS) with the values
+    of depth = 3; a lag grid of 4 000 points (no room for the star's phases beside the table in the assembly's LDS, no
+    tiles formed at first touch) goes through the planned and the batched calls all the same."""
+    import warnings
+
+    from starry_process_amd import calibrate
+    from starry_process_amd.calibrate import EnsembleLogProb, get_log_prob_ensemble
+
+    K, S = 128, 3
+    sts = [synthetic_star(s, K) for s in range(S)]
+    t, flux, per = np.array([s["t"] for s in sts]), np.array([s["flux"] for s in sts]), [s["p"] for s in sts]
+    sm = random_samples(7, seed=12)
+    calibrate._warned_depth[0] = False
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        deep = EnsembleLogProb(t, flux, ferr=1e-3, p=per, depth=6, batch_samples=False)
+    assert any("concurrent streams" in str(w.message) for w in rec)
+    assert len(deep._slots) + 1 <= calibrate.MAX_STREAMS
+    assert same(deep(sm), EnsembleLogProb(t, flux, ferr=1e-3, p=per, depth=3, batch_samples=False)(sm), 1e-12)
+    big = EnsembleLogProb(t, flux, ferr=1e-3, p=per, covpts=4000)
+    assert big._plan is not None and big._batch is not None
+    v = big(sm[:2])
+    for k in range(2):
+        r, a, b, c, n = sm[k]
+        ref = get_log_prob_ensemble(t, flux, ferr=1e-3, p=per, covpts=4000, upstream="device")(r, a, b, c, n)
+        assert same(v[k], ref, 1e-9), k
+
+
 def test_log_likelihood_samples_of_a_process():
     from starry_process_amd import StarryProcess
 
