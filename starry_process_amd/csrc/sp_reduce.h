@@ -37,12 +37,25 @@ __device__ __forceinline__ double red_ld(const double *p) {
   return *p;
 }
 
-// red: 48 doubles of LDS; s-indexed pointers are the star's own entries (null where the caller has none)
+// Where the reduction reads the factored system: diag(i) = L_ii, row(m, k) = entry k of riding row m (row K + m of the
+// system: the residual rows 0 .. M - 1, then L^-1 1, then L^-1 d).  RedSrcMem: the system in memory, row-major with
+// leading dimension ld (every caller but the small-K kernel, which holds them in LDS arrays of its own: sp_small.hip).
 template <bool COHERENT>
-__device__ __forceinline__ void lnlike_reduce_body(
-    const double *__restrict__ Mx, long ld, int K, int M, const int32_t *info_s,
+struct RedSrcMem {
+  const double *Mx;
+  long ld;
+  int K;
+  __device__ __forceinline__ double diag(int i) const { return red_ld<COHERENT>(Mx + (size_t)i * ld + i); }
+  __device__ __forceinline__ double row(int m, int k) const { return red_ld<COHERENT>(Mx + (size_t)(K + m) * ld + k); }
+};
+
+// red: 48 doubles of LDS; s-indexed pointers are the star's own entries (null where the caller has none)
+template <bool COHERENT, class SRC>
+__device__ __forceinline__ void lnlike_reduce_src(
+    const SRC src, int K, int M, const int32_t *info_s,
     double *__restrict__ lnlike_s, uint32_t *status_s, uint32_t *status_out_s,
-    const sp_star *star_s, const RedCoef *coef_s, const double *rscal_s, int dvec, double *red, int tid) {
+    const sp_star *star_s, const RedCoef *coef_s, const double *rscal_s, int dvec, double *red, int tid,
+    int notpd_in = 0) {
   const int wave = tid >> 6;
   // sums of v[0 .. 8) over the workgroup, in every thread (all eight always: constant indices
   // keep v in registers; the unused ones are zero)
@@ -61,8 +74,7 @@ __device__ __forceinline__ void lnlike_reduce_body(
   };
   double v[8];
   for (int a = 0; a < 8; ++a) v[a] = 0.0;
-  const double *y1 = Mx + (size_t)(K + M) * ld, *yd = y1 + ld;
-  const double *y0 = Mx + (size_t)K * ld;       // the first light curve's residuals ride in the same pass
+  // (the first light curve's residuals, row 0, ride in the same pass as rows M and M + 1)
   const bool defer = coef_s != nullptr;
   const bool dv = defer && dvec;
   // (four rows of loads in flight at a time: the diagonal is one cache line per entry, and one
@@ -74,10 +86,10 @@ __device__ __forceinline__ void lnlike_reduce_body(
       const int i = base + tid + 256 * u;
       const bool ok = i < K;
       const int ii = ok ? i : 0;
-      dg[u] = red_ld<COHERENT>(Mx + (size_t)ii * ld + ii);
-      r[u] = red_ld<COHERENT>(y0 + ii);
-      pa[u] = defer ? red_ld<COHERENT>(y1 + ii) : 0.0;
-      pb[u] = dv ? red_ld<COHERENT>(yd + ii) : 0.0;
+      dg[u] = src.diag(ii);
+      r[u] = src.row(0, ii);
+      pa[u] = defer ? src.row(M, ii) : 0.0;
+      pb[u] = dv ? src.row(M + 1, ii) : 0.0;
       if (!ok) {
         dg[u] = 1.0;
         r[u] = pa[u] = pb[u] = 0.0;
@@ -98,7 +110,7 @@ __device__ __forceinline__ void lnlike_reduce_body(
   const int nobs = (star_s && star_s->nobs > 0 && star_s->nobs < K) ? star_s->nobs : K;
   // rank-1 steps on the 3 x 3 Gram matrix H (0 = p, 1 = 1, 2 = q): factor f_k and old column c_k
   double f[3] = {0.0, 0.0, 0.0}, col[3][3], logs = 0.0;
-  bool notpd = false;
+  bool notpd = notpd_in != 0;
   double c1 = 1.0, km = 1.0, delta = 0.0;
   if (defer) {
     const RedCoef rc = *coef_s;
@@ -124,17 +136,16 @@ __device__ __forceinline__ void lnlike_reduce_body(
   }
   double quad = 0.0;
   for (int m = 0; m < M; ++m) {
-    const double *y = Mx + (size_t)(K + m) * ld;
     double w[8];
     for (int a = 0; a < 8; ++a) w[a] = 0.0;
     if (m == 0) {
       w[0] = v[4]; w[1] = v[5]; w[2] = v[6];
     } else {
       for (int k = tid; k < K; k += 256) {
-        const double r = red_ld<COHERENT>(y + k);
+        const double r = src.row(m, k);
         w[0] += r * r;
-        if (defer) w[1] += r * red_ld<COHERENT>(y1 + k);
-        if (dv) w[2] += r * red_ld<COHERENT>(yd + k);
+        if (defer) w[1] += r * src.row(M, k);
+        if (dv) w[2] += r * src.row(M + 1, k);
       }
       block_sum(w);
     }
@@ -169,6 +180,15 @@ __device__ __forceinline__ void lnlike_reduce_body(
     if (status_s) *status_s = st;
     if (status_out_s) *status_out_s = st;
   }
+}
+
+template <bool COHERENT>
+__device__ __forceinline__ void lnlike_reduce_body(
+    const double *__restrict__ Mx, long ld, int K, int M, const int32_t *info_s,
+    double *__restrict__ lnlike_s, uint32_t *status_s, uint32_t *status_out_s,
+    const sp_star *star_s, const RedCoef *coef_s, const double *rscal_s, int dvec, double *red, int tid) {
+  lnlike_reduce_src<COHERENT>(RedSrcMem<COHERENT>{Mx, ld, K}, K, M, info_s, lnlike_s, status_s, status_out_s, star_s, coef_s,
+                              rscal_s, dvec, red, tid);
 }
 
 #endif

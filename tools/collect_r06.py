@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""Copy the judged summaries of gpurun_out/r05 (tools/profile_r05.sh) into profiles/ and derive the
+"""Copy the judged summaries of gpurun_out/r06 (tools/profile_r06.sh) into profiles/ and derive the
 per-step HBM traffic file bench.py quotes (`roofline.traffic`).
-python tools/collect_r05.py gpurun_out/r05"""
+python tools/collect_r06.py gpurun_out/r06"""
 import csv
 import glob
 import json
@@ -29,12 +29,15 @@ fn = os.path.join(O, "driver_cmd_bench.json")
 if os.path.exists(fn):
     for l in open(fn):
         if l.startswith("{"):
-            json.dump(json.loads(l), open(os.path.join(P, "r05_driver_cmd_bench.json"), "w"), indent=1)
-copy(last("stats_inflight/**/*kernel_stats.csv"), "r05_inflight_kernel_stats.csv")
-copy(last("stats_one/**/*kernel_stats.csv"), "r05_one_kernel_stats.csv")
-for name in ("one_step_trace.txt", "prof_elp.txt", "inflight_probe.txt", "grad_timing.txt", "cfg5_shape.txt", "ab_planned.txt",
-             "pmc_lds.txt", "stats_unplanned_inflight.txt"):
-    copy(os.path.join(O, name), "r05_" + name)
+            json.dump(json.loads(l), open(os.path.join(P, "r06_driver_cmd_bench.json"), "w"), indent=1)
+copy(last("stats_inflight/**/*kernel_stats.csv"), "r06_inflight_kernel_stats.csv")
+copy(last("stats_one/**/*kernel_stats.csv"), "r06_one_kernel_stats.csv")
+copy(last("stats_cfg5/**/*kernel_stats.csv"), "r06_cfg5_kernel_stats.csv")
+copy(last("stats_samples/**/*kernel_stats.csv"), "r06_samples_kernel_stats.csv")
+for name in ("one_step_trace.txt", "prof_elp.txt", "inflight_probe.txt", "grad_timing.txt", "cfg5_shape.txt",
+             "pmc_lds.txt", "stats_unplanned_inflight.txt", "mfma_budget.txt", "samples_bench.txt", "k_sweep.txt",
+             "cfg5_one_step_trace.txt"):
+    copy(os.path.join(O, name), "r06_" + name)
 
 
 def steps_of(d):   # steps in the PMC runs: the planned assembly's dispatches (one per step)
@@ -45,10 +48,10 @@ def steps_of(d):   # steps in the PMC runs: the planned assembly's dispatches (o
 fd, wd = os.path.join(O, "pmc_FETCH_SIZE"), os.path.join(O, "pmc_WRITE_SIZE")
 if os.path.isdir(fd) and os.path.isdir(wd):
     n = steps_of("pmc_FETCH_SIZE")
-    out = os.path.join(P, "r05_step_traffic.json")
+    out = os.path.join(P, "r06_step_traffic.json")
     txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_traffic.py"), fd, wd, str(n), out],
                          capture_output=True, text=True).stdout
-    open(os.path.join(P, "r05_step_traffic.txt"), "w").write(txt)
+    open(os.path.join(P, "r06_step_traffic.txt"), "w").write(txt)
     tr = json.load(open(out))
     # (the panel kernel is one instantiation per kind of launch since round 4: all of them together)
     dom = [k for k in tr["per_kernel"] if k["kernel"].startswith("panel_kernel")]
@@ -66,5 +69,5 @@ for d in ("pmc_sq", "pmc_grbm"):
         txt += subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc.py"), os.path.join(O, d)],
                               capture_output=True, text=True).stdout
 if txt:
-    open(os.path.join(P, "r05_pmc_sq.txt"), "w").write(txt)
-print("profiles/:", sorted(f for f in os.listdir(P) if f.startswith("r05_")))
+    open(os.path.join(P, "r06_pmc_sq.txt"), "w").write(txt)
+print("profiles/:", sorted(f for f in os.listdir(P) if f.startswith("r06_")))
