@@ -572,6 +572,11 @@ int sp_debug_set_syrk128_from(int blocks);
  * SP_SYRK_SYMDIAG; 0 = the plain loop, all sixteen blocks; -1 = back to the default): which blocks are multiplied,
  * never what the wanted ones hold -- identical bits below the diagonal.                                       */
 int sp_debug_set_syrk_symdiag(int on);
+/* (debug, process-wide) sp_lnlike_ensemble_planned evaluates light curves of K <= 128 cadences (M + 2 <= 4 riding rows, a
+ * lag grid that fits beside the tiles) in ONE kernel, a workgroup per star, nothing of the system in memory
+ * (csrc/sp_small.hip; default on, environment SP_SMALL_K; 0 = the blocked path at every size, -1 = back to the
+ * default): which kernels run, the same values to rounding.                                                        */
+int sp_debug_set_small_k(int on);
 /* (debug, host only) how the hot assembly kernel (csrc/sp_assemble.hip, assemble_sums_kernel) cuts a star's
  * ntr (ntr + 1) / 2 lower tiles (column-strip order) into nchunk chunks of equal COST: start_host[c] = first tile
  * of chunk c, c = 0 .. nchunk (start_host[nchunk] = the number of tiles).  A function of the shape alone.   */

@@ -104,6 +104,7 @@ PROTOTYPES = {
     "sp_debug_panel2_chain": (_I, [_V]),
     "sp_debug_asm_chunks": (_I, [_I, _I, _V]),
     "sp_debug_set_syrk128_from": (_I, [_I]),
+    "sp_debug_set_small_k": (_I, [_I]),
     "sp_debug_set_syrk_symdiag": (_I, [_I]),
     "sp_debug_set_look_ahead": (_I, [_V, _I]),
     "sp_debug_set_panel_layout": (_I, [_V, _I, _I]),

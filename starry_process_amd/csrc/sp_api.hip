@@ -53,6 +53,16 @@ int sp_launch_assemble_planned(int S, int K, int M, int Kp, const PlanDev &plan,
                                uint32_t *status, hipStream_t st, double *img, long lts, int fuse0, double *rid, int dfrom);
 int sp_launch_cholesky_systems(sp_handle *h, double *sys, int S, int K, int Kp,
                                int32_t *info, double *invL, hipStream_t st);
+bool sp_small_k_serves(int K, int M, int covpts, bool has_diag);
+static int g_small_k = -1;       // sp_debug_set_small_k: -1 = the environment's SP_SMALL_K (default on)
+static bool sp_small_k_on() {
+  if (g_small_k >= 0) return g_small_k != 0;
+  static const bool env = !(getenv("SP_SMALL_K") && atoi(getenv("SP_SMALL_K")) == 0);
+  return env;
+}
+int sp_launch_small_lnlike(int S, int K, int M, const PlanDev &plan, const double *t, const sp_star *stars, int covpts,
+                           const double *tab, const double *meanvar, int temporal, const double *flux, const double *diag,
+                           int order, double zmax, double *lnlike, uint32_t *status_out, hipStream_t st);
 int sp_launch_cond_system(const double *B1, const double *A, int N, int Kr, int S, int K, int M, int Kp,
                           const double *t, const sp_star *stars, int temporal, const void *coef,
                           const double *diag, const double *flux, double *sys, double *part,
@@ -915,6 +925,12 @@ int sp_set_defer_norm(sp_handle *h, int on) {
   return SP_OK;
 }
 
+// (debug, process-wide) the one-kernel path of short light curves on / off / back to the environment's setting
+int sp_debug_set_small_k(int on) {
+  g_small_k = on < 0 ? -1 : (on ? 1 : 0);
+  return SP_OK;
+}
+
 // (debug) look-ahead items of the panel launches on / off (sp_cholesky.hip); results agree to rounding
 int sp_debug_set_look_ahead(sp_handle *h, int on) {
   if (!h) return SP_ERR_INVALID;
@@ -1328,6 +1344,11 @@ int sp_lnlike_ensemble_planned(sp_handle *h, const sp_plan *plan, const double *
   const int S = plan->S, K = plan->K, M = plan->M, covpts = plan->covpts, temporal = plan->temporal;
   if (h->xp_covpts != covpts) return SP_ERR_STATE;
   hipStream_t st = (hipStream_t)stream;
+  // Short light curves: the whole evaluation of a star in one workgroup's LDS (sp_small.hip) -- no system in memory, no
+  // panel launches.  SP_SMALL_K=0: the blocked path at every size.
+  if (sp_small_k_on() && sp_small_k_serves(K, M, covpts, diag_dev != nullptr))
+    return sp_launch_small_lnlike(S, K, M, plan->dev, t_dev, stars_dev, covpts, tab_dev, meanvar_dev, temporal, flux_dev,
+                                  diag_dev, norm_order, zmax, lnlike_dev, status_dev, st);
   Layout L = make_layout(h, S, K, M, true);
   void *ws = workspace_dev;
   // (the stars' packed tables for the kernels that form tiles at first touch: the design-matrix region)

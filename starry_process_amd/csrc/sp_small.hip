@@ -1,0 +1,299 @@
+// Short light curves (K <= 128 cadences) in ONE kernel, one workgroup per star (round 6).
+//
+// The blocked path spends a launch per 64-column panel and a workgroup per (star, row tile) and launch: at K = 128 a
+// step of 1 688 stars is ~10 000 workgroups, each at least one 12 us diagonal-block chain long, over four launches,
+// with the 192-row padded system (2.25 x the entries) written to and read from HBM in between -- 0.31 ms per step,
+// 0.07 of the fp64 peak (bench.py's K sweep; the reference's own benchmark sweeps K, joss/figures/speed.py:22-37).
+// Here a star's whole evaluation -- the planned step's assembly (sp_planasm.hip: phases and weights from the data plan,
+// the normalisation's coefficients from yp . wbar), the factorisation, the riding rows' solves, the reduction of
+// sp_reduce.h -- happens in the LDS and registers of one workgroup; nothing of the system ever reaches memory:
+//
+//   tile (0, 0) -> LDS, factored in place by diag_block (sp_diag.h: L below the diagonal, L^-T above it);
+//   K > 64: tile (1, 0) -> LDS (in the spline table's place once the assembly is through), X = T10 L00^-T on the matrix
+//           cores (the wavefront's own 16-row strip, in place); tile (1, 1) in MFMA accumulators from its assembly on,
+//           -= X X^T there, then to the LDS for diag_block;
+//   the riding rows [r_0 .. r_{M-1}, 1, (d)] in LDS: R <- R L^-T by substitution against L^-T;
+//   lnlike_reduce_src on the LDS copies.
+//
+// 77 KB of LDS per workgroup for K > 64 (two per CU), 50 KB for K <= 64 (three; measured: keeping tile (1, 0) in
+// registers in fragment order would leave three for K > 64 too, and needs more than 256 registers); the same values as the blocked planned
+// step to rounding (tests/test_gpu_small.py: 1e-10 against it, 1e-8 against the oracle).
+#include "sp_internal.h"
+#include "sp_cov.h"
+#include "sp_asm.h"
+#include "sp_tile.h"
+#include "sp_reduce.h"
+
+namespace {
+
+typedef SpCoef Coef;
+constexpr int SMK_MAXR = 4;          // riding rows: M + 1 (scalar variance) or M + 2 (per-cadence variances)
+
+struct SmallSrc {                    // lnlike_reduce_src's view of the factored star
+  const double *dg;                  // [64 NB] L_ii
+  const double *rows;                // [nr][64 NB] riding rows
+  int ldr;
+  __device__ __forceinline__ double diag(int i) const { return dg[i]; }
+  __device__ __forceinline__ double row(int m, int k) const { return rows[m * ldr + k]; }
+};
+
+// (wavefronts per SIMD the register budget is held to: two workgroups a CU for K > 64, three for K <= 64 -- what their LDS allows)
+template <int NB, int TK>
+__global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void small_lnlike_kernel(
+    int K, int M, PlanDev plan, const double *__restrict__ t, const sp_star *__restrict__ stars, int covpts,
+    const double *__restrict__ tab, const double *__restrict__ meanvar, const double *__restrict__ flux,
+    const double *__restrict__ diag, int order, double zmax, double *__restrict__ lnlike,
+    uint32_t *__restrict__ status_out, int regionB) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int KC = 64 * NB;
+  const int s = blockIdx.x, tid = threadIdx.x, np = covpts + 4;
+  const int nr = M + (diag ? 2 : 1);
+  double *sD = lds;                              // 64 BLD  | sRd 64 | leaf 256           (SP_DIAG_LDS_DOUBLES)
+  double *sRd = sD + 64 * BLD;
+  double *sB = lds + SP_DIAG_LDS_DOUBLES;        // region B: the spline table, then (NB == 2) tile (1, 0) / X
+  double *sTh = sB + regionB;                    // [KC] phases
+  double *sTt = sTh + KC;                        // [KC] times
+  double *sR = sTt + KC;                         // [nr][KC] riding rows
+  double *sDg = sR + nr * KC;                    // [KC] L_ii
+  double *sRed = sDg + KC;                       // 48
+  double *sRs = sRed + 48;                       // [SP_RSCAL_HEAD + M] the reduction's scalars
+  Coef *sCoef = reinterpret_cast<Coef *>(sRs + SP_RSCAL_HEAD + M + ((SP_RSCAL_HEAD + M) & 1));   // 8 doubles
+  uint32_t *sStat = reinterpret_cast<uint32_t *>(reinterpret_cast<double *>(sCoef) + 8);
+  const sp_star st = stars[s];
+  const int nobs = star_nobs(st, K);
+  const double *th = plan.theta + (size_t)s * K, *tt = t + (size_t)s * K;
+  // ---- prologue: phases, table, m = yp . wbar / nobs^2 (the planned assembly's, sp_planasm.hip) --------------------
+  if (tid < KC) {
+    sTh[tid] = tid < K ? th[tid] : 0.0;
+    sTt[tid] = (TK != SP_TEMPORAL_NONE && tid < K) ? tt[tid] : 0.0;
+  }
+  double dot = 0.0;
+  {
+    const double *src = tab + (size_t)st.table * 5 * np, *wb = plan.wbar + (size_t)s * np;
+    for (int e = tid; e < np; e += 256) {
+      *reinterpret_cast<dd2 *>(sB + 2 * e) = dd2{src[np + e], src[2 * np + e]};
+      *reinterpret_cast<dd2 *>(sB + 2 * np + 2 * e) = dd2{src[3 * np + e], src[4 * np + e]};
+      dot += src[e] * wb[e];
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) dot += __shfl_down(dot, off, 64);
+  if ((tid & 63) == 0) sRed[tid >> 6] = dot;
+  __syncthreads();
+  const double total = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+  const double fmean = meanvar[2 * st.table], var1 = meanvar[2 * st.table + 1];
+  const double m = nobs == 1 ? var1 : total / ((double)nobs * (double)nobs);
+  const Coef c = defer_coef(m, fmean, order, st.baseline_var);
+  const double inv_c1 = 1.0 / c.c1;
+  if (tid == 0) {
+    const double delta = st.data_var / c.c1;
+    sRs[0] = (double)nobs * m;
+    sRs[1] = diag ? plan.sdv[s] / c.c1 : (double)nobs * delta;
+    sRs[2] = delta;
+    *sCoef = c;
+    const double *key = plan.key + 3 * (size_t)s;
+    const bool stale = !(key[0] == st.period) || (TK != SP_TEMPORAL_NONE && !(key[1] == st.tau)) || key[2] != (double)nobs;
+    *sStat = (c.z > zmax ? SP_STAR_ZMAX : 0u) | (stale ? SP_STAR_STALE_PLAN : 0u);
+  }
+  for (int mm = tid; mm < M; mm += 256) sRs[SP_RSCAL_HEAD + mm] = plan.sflux[(size_t)s * M + mm] - (double)nobs * st.baseline_mean;
+  // riding rows: residuals, ones, variances / c1 (zero beyond the valid cadences)
+  for (int e = tid; e < nr * KC; e += 256) {
+    const int mr = e / KC, col = e - mr * KC;
+    double v = 0.0;
+    if (col < nobs) {
+      if (mr < M) v = flux[((size_t)s * M + mr) * K + col] - st.baseline_mean;
+      else if (mr == M) v = 1.0;
+      else v = diag[(size_t)s * K + col] * inv_c1;
+    }
+    sR[e] = v;
+  }
+  // ---- assembly: a thread's sixteen entries of a tile in the MFMA accumulator layout -------------------------------
+  const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+  SplineGen g{sB, 2 * np, 6.283185307179586 / covpts, 1.0 / (6.283185307179586 / covpts), covpts};
+  // (entries in batches of BT through SplineGen::many, one batch after the other: sixteen at once keep ~90 doubles of
+  //  gather temporaries alive beside the tiles held in registers -- 121 spilled registers in the K > 64 kernel)
+  constexpr int BT = NB == 2 ? 4 : 8;
+  auto tile = [&](int ti, int tj, double (&w)[16]) {
+#pragma unroll
+    for (int e0 = 0; e0 < 16; e0 += BT) {
+      // (a diagonal tile's 16 x 16 blocks above the diagonal are never read: the wavefront's row strip is block row
+      //  `wave`, column blocks beyond it are skipped whole -- wavefront-uniform)
+      if (ti == tj && (e0 >> 2) > wave) {
+#pragma unroll
+        for (int q = 0; q < BT; ++q) w[e0 + q] = 0.0;
+        continue;
+      }
+      double a[BT], b[BT], o[BT];
+#pragma unroll
+      for (int q = 0; q < BT; ++q) {      // e = 4 nb + r: row 16 wave + fg + 4 r, column 16 nb + fr
+        const int e = e0 + q;
+        a[q] = sTh[64 * ti + 16 * wave + fg + 4 * (e & 3)];
+        b[q] = sTh[64 * tj + 16 * (e >> 2) + fr];
+      }
+      g.many<BT>(a, b, o);
+#pragma unroll
+      for (int q = 0; q < BT; ++q) {
+        const int e = e0 + q;
+        const int i = 64 * ti + 16 * wave + fg + 4 * (e & 3), j = 64 * tj + 16 * (e >> 2) + fr;
+        double v = nobs == 1 ? var1 : o[q];
+        if (TK != SP_TEMPORAL_NONE) v *= temporal_factor(TK, sTt[i], sTt[j], st.tau);
+        if (i < nobs && j < nobs) {
+          if (i == j) v += (diag ? diag[(size_t)s * K + i] : st.data_var) * inv_c1;
+        } else {
+          v = i == j ? 1.0 : 0.0;
+        }
+        w[e] = v;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  double w10[16];
+  d4 a11[4];
+  if (NB == 2) {
+    double w11[16];
+    tile(1, 1, w11);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) a11[nb] = d4{w11[4 * nb], w11[4 * nb + 1], w11[4 * nb + 2], w11[4 * nb + 3]};
+    __builtin_amdgcn_sched_barrier(0);
+    tile(1, 0, w10);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  {
+    double w00[16];
+    tile(0, 0, w00);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = 16 * wave + fg + 4 * (e & 3), col = 16 * (e >> 2) + fr;
+      sD[row * BLD + col] = col > row ? 0.0 : w00[e];
+    }
+  }
+  __syncthreads();                       // (the table has been read by everybody: region B may take tile (1, 0))
+  if (NB == 2) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sB[(16 * wave + fg + 4 * (e & 3)) * BLD + 16 * (e >> 2) + fr] = w10[e];
+  }
+  // ---- pivot block 0 ------------------------------------------------------------------------------------------------
+  // (wavefront w of diag_block owns block column w: workgroups that share a CU -- 256 apart in the grid, the hardware
+  //  deals consecutive ones to the XCDs and their CUs in turn -- start in step, and with the same roles their leaf
+  //  chains would queue on ONE SIMD while three idle: the roles are rotated from workgroup to workgroup)
+  const int tid_rot = (tid + 64 * ((blockIdx.x >> 8) & 3)) & 255;
+  int notpd = diag_block(sD, sRd, tid_rot);  // (ends behind a barrier)
+  if (tid < 64) sDg[tid] = sD[tid * BLD + tid];
+  // Linv[n][k] of the block in sD / sRd (sp_diag.h: L^-T above the diagonal, the reciprocal diagonal apart)
+  auto linv = [&](int n, int k) { return k < n ? sD[k * BLD + n] : (k == n ? sRd[k] : 0.0); };
+  auto ride = [&](int c0) {              // R[:, c0 .. c0 + 63] <- R[:, c0 ..] L^-T   (value returned, stored by the caller)
+    double acc = 0.0;
+    if (tid < nr * 64) {
+      const int mr = tid >> 6, n = tid & 63;
+      const double *row = sR + mr * KC + c0;
+      acc = row[n] * sRd[n];
+#pragma unroll 4
+      for (int k = 0; k < n; ++k) acc = fma(row[k], sD[k * BLD + n], acc);
+    }
+    return acc;
+  };
+  double rnew = ride(0);
+  if (NB == 2) {
+    // X = T10 L00^-T: the wavefront's own sixteen rows, all four column blocks in registers before the first store
+    d4 x[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+      for (int ks = 0; ks < 4 * (nb + 1); ++ks) {
+        const int k = 4 * ks + fg;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sB[(16 * wave + fr) * BLD + k], linv(16 * nb + fr, k), acc, 0, 0, 0);
+      }
+      x[nb] = acc;
+    }
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sB[(16 * wave + fg + 4 * r) * BLD + 16 * nb + fr] = x[nb][r];
+  }
+  __syncthreads();                       // (every reader of R's first half and of L00^-T is through)
+  if (tid < nr * 64) sR[(tid >> 6) * KC + (tid & 63)] = rnew;
+  if (NB == 2) {
+    __syncthreads();                     // X and the solved first half of R are in place
+    // R[:, 64 ..] -= R[:, .. 63] X^T
+    if (tid < nr * 64) {
+      const int mr = tid >> 6, cc = tid & 63;
+      const double *r0 = sR + mr * KC, *xr = sB + cc * BLD;
+      double acc = r0[64 + cc];
+#pragma unroll 4
+      for (int n = 0; n < 64; ++n) acc = fma(-r0[n], xr[n], acc);
+      sR[mr * KC + 64 + cc] = acc;
+    }
+    // T11 -= X X^T (the blocks on or below the diagonal), then to the LDS for its factorisation
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      if (nb > wave) continue;
+      d4 acc = a11[nb];
+#pragma unroll 4
+      for (int ks = 0; ks < 16; ++ks) {
+        const int k = 4 * ks + fg;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-sB[(16 * wave + fr) * BLD + k], sB[(16 * nb + fr) * BLD + k], acc, 0, 0, 0);
+      }
+      a11[nb] = acc;
+    }
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * wave + fg + 4 * r, col = 16 * nb + fr;
+        sD[row * BLD + col] = col > row ? 0.0 : a11[nb][r];
+      }
+    __syncthreads();                     // (diag_block wants a barrier behind the block's stores)
+    notpd |= diag_block(sD, sRd, tid_rot);
+    if (tid < 64) sDg[64 + tid] = sD[tid * BLD + tid];
+    rnew = ride(64);
+    __syncthreads();
+    if (tid < nr * 64) sR[(tid >> 6) * KC + 64 + (tid & 63)] = rnew;
+  }
+  notpd = __syncthreads_or(notpd);
+  // ---- reduction ------------------------------------------------------------------------------------------------------
+  lnlike_reduce_src<false>(SmallSrc{sDg, sR, KC}, K, M, nullptr, lnlike + s, sStat, status_out ? status_out + s : nullptr,
+                           stars + s, sCoef, sRs, diag ? 1 : 0, sRed, tid, notpd);
+}
+
+}  // namespace
+
+// can the planned step of this shape run in the small-K kernel?  (sp_lnlike_ensemble_planned asks)
+bool sp_small_k_serves(int K, int M, int covpts, bool has_diag) {
+  const int nr = M + (has_diag ? 2 : 1);
+  if (K < 2 || K > 128 || nr > SMK_MAXR) return false;
+  const int np = covpts + 4;
+  // the table lies in the region tile (1, 0) takes later; at most what leaves two workgroups a CU (K > 64) or three
+  if (K > 64) return 4 * np <= 64 * BLD;
+  return 4 * np <= 2560;
+}
+
+int sp_launch_small_lnlike(int S, int K, int M, const PlanDev &plan, const double *t, const sp_star *stars, int covpts,
+                           const double *tab, const double *meanvar, int temporal, const double *flux, const double *diag,
+                           int order, double zmax, double *lnlike, uint32_t *status_out, hipStream_t st) {
+  if (!sp_small_k_serves(K, M, covpts, diag != nullptr)) return SP_ERR_INVALID;
+  const int NB = K > 64 ? 2 : 1, KC = 64 * NB, np = covpts + 4, nr = M + (diag ? 2 : 1);
+  int regionB = 4 * np;
+  if (NB == 2 && regionB < 64 * BLD) regionB = 64 * BLD;
+  const size_t doubles = (size_t)SP_DIAG_LDS_DOUBLES + regionB + 2 * KC + (size_t)nr * KC + KC + 48 + SP_RSCAL_HEAD + M + 1 + 8 + 2;
+  const size_t lds = sizeof(double) * doubles;
+#define SP_SMALL(NBV, TKV)                                                                                        \
+  do {                                                                                                            \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(small_lnlike_kernel<NBV, TKV>),                      \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);                            \
+    hipLaunchKernelGGL((small_lnlike_kernel<NBV, TKV>), dim3(S), dim3(256), lds, st, K, M, plan, t, stars, covpts, tab, \
+                       meanvar, flux, diag, order, zmax, lnlike, status_out, regionB);                            \
+  } while (0)
+#define SP_SMALL_TK(NBV)                                                                \
+  do {                                                                                  \
+    if (temporal == SP_TEMPORAL_NONE) SP_SMALL(NBV, SP_TEMPORAL_NONE);                  \
+    else if (temporal == SP_TEMPORAL_MATERN32) SP_SMALL(NBV, SP_TEMPORAL_MATERN32);     \
+    else if (temporal == SP_TEMPORAL_EXPSQUARED) SP_SMALL(NBV, SP_TEMPORAL_EXPSQUARED); \
+    else return SP_ERR_INVALID;                                                         \
+  } while (0)
+  if (NB == 2) SP_SMALL_TK(2);
+  else SP_SMALL_TK(1);
+#undef SP_SMALL_TK
+#undef SP_SMALL
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}
