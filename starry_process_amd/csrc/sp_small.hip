@@ -24,6 +24,20 @@
 #include "sp_tile.h"
 #include "sp_reduce.h"
 
+#ifdef SP_SMALL_TRACE
+// (debug builds, tools/ab_build.sh trace -DSP_SMALL_TRACE: wall-clock stamps of the first 64 workgroups' phases)
+__device__ long long g_small_trace[64 * 8];
+#define SMK_STAMP(k)                                                          \
+  do {                                                                        \
+    if (blockIdx.x < 64 && threadIdx.x == 0) g_small_trace[blockIdx.x * 8 + (k)] = wall_clock64(); \
+  } while (0)
+extern "C" int sp_debug_small_trace(long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_small_trace), sizeof(long long) * 64 * 8) == hipSuccess ? SP_OK : SP_ERR_HIP;
+}
+#else
+#define SMK_STAMP(k)
+#endif
+
 namespace {
 
 typedef SpCoef Coef;
@@ -59,6 +73,7 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void small_lnlike_kernel(
   double *sRs = sRed + 48;                       // [SP_RSCAL_HEAD + M] the reduction's scalars
   Coef *sCoef = reinterpret_cast<Coef *>(sRs + SP_RSCAL_HEAD + M + ((SP_RSCAL_HEAD + M) & 1));   // 8 doubles
   uint32_t *sStat = reinterpret_cast<uint32_t *>(reinterpret_cast<double *>(sCoef) + 8);
+  SMK_STAMP(0);
   const sp_star st = stars[s];
   const int nobs = star_nobs(st, K);
   const double *th = plan.theta + (size_t)s * K, *tt = t + (size_t)s * K;
@@ -106,6 +121,7 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void small_lnlike_kernel(
     }
     sR[e] = v;
   }
+  SMK_STAMP(1);
   // ---- assembly: a thread's sixteen entries of a tile in the MFMA accumulator layout -------------------------------
   const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
   SplineGen g{sB, 2 * np, 6.283185307179586 / covpts, 1.0 / (6.283185307179586 / covpts), covpts};
@@ -171,12 +187,14 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void small_lnlike_kernel(
 #pragma unroll
     for (int e = 0; e < 16; ++e) sB[(16 * wave + fg + 4 * (e & 3)) * BLD + 16 * (e >> 2) + fr] = w10[e];
   }
+  SMK_STAMP(2);
   // ---- pivot block 0 ------------------------------------------------------------------------------------------------
   // (wavefront w of diag_block owns block column w: workgroups that share a CU -- 256 apart in the grid, the hardware
   //  deals consecutive ones to the XCDs and their CUs in turn -- start in step, and with the same roles their leaf
   //  chains would queue on ONE SIMD while three idle: the roles are rotated from workgroup to workgroup)
   const int tid_rot = (tid + 64 * ((blockIdx.x >> 8) & 3)) & 255;
   int notpd = diag_block(sD, sRd, tid_rot);  // (ends behind a barrier)
+  SMK_STAMP(3);
   if (tid < 64) sDg[tid] = sD[tid * BLD + tid];
   // Linv[n][k] of the block in sD / sRd (sp_diag.h: L^-T above the diagonal, the reciprocal diagonal apart)
   auto linv = [&](int n, int k) { return k < n ? sD[k * BLD + n] : (k == n ? sRd[k] : 0.0); };
@@ -243,16 +261,20 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void small_lnlike_kernel(
         sD[row * BLD + col] = col > row ? 0.0 : a11[nb][r];
       }
     __syncthreads();                     // (diag_block wants a barrier behind the block's stores)
+    SMK_STAMP(4);
     notpd |= diag_block(sD, sRd, tid_rot);
+    SMK_STAMP(5);
     if (tid < 64) sDg[64 + tid] = sD[tid * BLD + tid];
     rnew = ride(64);
     __syncthreads();
     if (tid < nr * 64) sR[(tid >> 6) * KC + 64 + (tid & 63)] = rnew;
   }
   notpd = __syncthreads_or(notpd);
+  SMK_STAMP(6);
   // ---- reduction ------------------------------------------------------------------------------------------------------
   lnlike_reduce_src<false>(SmallSrc{sDg, sR, KC}, K, M, nullptr, lnlike + s, sStat, status_out ? status_out + s : nullptr,
                            stars + s, sCoef, sRs, diag ? 1 : 0, sRed, tid, notpd);
+  SMK_STAMP(7);
 }
 
 }  // namespace

@@ -6,10 +6,10 @@ set -e
 cd "$(dirname "$0")/../starry_process_amd/csrc"
 name=$1; shift
 tmp=$(mktemp -d)
-for f in sp_host.cpp sp_wigner.hip sp_gemm.hip sp_panel.hip sp_cond.hip sp_upstream.hip sp_table.hip sp_assemble.hip sp_plan.hip sp_planasm.hip sp_cholesky.hip sp_grad.hip sp_api.hip; do
+for f in sp_host.cpp sp_wigner.hip sp_gemm.hip sp_panel.hip sp_cond.hip sp_upstream.hip sp_samples.hip sp_table.hip sp_assemble.hip sp_plan.hip sp_planasm.hip sp_small.hip sp_cholesky.hip sp_grad.hip sp_api.hip; do
   fl="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -fno-fast-math"
   case $f in sp_wigner.hip|sp_assemble.hip|sp_plan.hip|sp_table.hip|sp_host.cpp) fl="$fl -ffp-contract=off";; esac
-  case $f in sp_cholesky.hip|sp_gemm.hip|sp_panel.hip|sp_cond.hip|sp_planasm.hip) fl="$fl -mllvm -amdgpu-mfma-vgpr-form=1";; esac
+  case $f in sp_cholesky.hip|sp_gemm.hip|sp_panel.hip|sp_cond.hip|sp_planasm.hip|sp_small.hip) fl="$fl -mllvm -amdgpu-mfma-vgpr-form=1";; esac
   /opt/rocm/bin/hipcc $fl "$@" -I. -c $f -o $tmp/${f%.*}.o &
   pids="$pids $!"
 done

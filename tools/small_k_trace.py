@@ -1,0 +1,43 @@
+"""In-kernel timeline of the small-K kernel's phases (first 64 workgroups): needs the variant library
+    bash tools/ab_build.sh trace -DSP_SMALL_TRACE ;  SP_LIB_VARIANT=trace python tools/small_k_trace.py [K] [S]"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from starry_process_amd import _lib  # noqa: E402
+from starry_process_amd.engine import Engine, make_stars  # noqa: E402
+from starry_process_amd.synthetic import synthetic_star  # noqa: E402
+
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 1536
+e = Engine(15, 2, 0)
+mom = np.load(os.path.join(ROOT, "tests", "golden", "moments_L15.npz"))
+e.set_moments(mom["default_mean_ylm"], mom["default_cov_ylm"])
+tab, mv = e.kernel_table(e.f64(e.rTA1L([0.0, 0.0])), 300)
+base = [synthetic_star(s, K) for s in range(64)]
+sts = [base[s % 64] for s in range(S)]
+t_d = e.f64(np.array([s["t"] for s in sts]))
+f_d = e.f64(np.array([s["flux"] for s in sts])[:, None, :])
+s_d = e.stars_to_device(make_stars(S, period=[s["p"] for s in sts], data_var=1e-6))
+plan = e.plan_data(t_d, f_d, s_d, covpts=300)
+for _ in range(3):
+    e.lnlike_ensemble_planned(plan, None, None, s_d, tab, mv)
+torch.cuda.synchronize()
+L = ctypes.CDLL(_lib.LIB_PATH)
+buf = np.zeros(64 * 8, dtype=np.int64)
+assert L.sp_debug_small_trace(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+tr = buf.reshape(64, 8).astype(float)
+names = ["prologue", "assembly", "to LDS", "diag 0", "solve / update", "diag 1", "rows", "reduce"]
+d = np.diff(tr, axis=1) * 0.01          # 100 MHz clock -> us
+if K <= 64:
+    d[:, 3] = (tr[:, 6] - tr[:, 3]) * 0.01
+    d[:, 4] = d[:, 5] = 0.0
+print("K %d, S %d: phases of workgroups 0 .. 63, us (mean / min / max); whole %.1f us" % (K, S, np.mean(tr[:, 7] - tr[:, 0]) * 0.01))
+for k, n in enumerate(names[:-1] if False else names[:7]):
+    print("  %-16s %6.2f  %6.2f  %6.2f" % (n, d[:, k].mean(), d[:, k].min(), d[:, k].max()))
