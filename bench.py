@@ -919,8 +919,11 @@ def main():
                                                                    u=(0.0, 0.0), conditional=False, F=1, steps=100,
                                                                    device=local_rank, planned=plan is not None)
             # ... and the same light curve with the hyperparameter samples batched 64 to a call, upstream included
-            extras["cfg2_batched_samples"] = bench_samples(torch, 15, 1000, 1, F, 40, local_rank)
-            extras["ensemble8_batched_samples"] = bench_samples(torch, 15, 1000, 8, F, 40, local_rank)
+            # (six streams: a third of such a step is the samples' moments and tables, light kernels -- 88-92k evaluations/s
+            #  with four, 95-99k with six; calibrate.MAX_STREAMS_SAMPLES)
+            Fs = F if F < 4 else 6
+            extras["cfg2_batched_samples"] = bench_samples(torch, 15, 1000, 1, Fs, 120, local_rank)
+            extras["ensemble8_batched_samples"] = bench_samples(torch, 15, 1000, 8, Fs, 120, local_rank)
             extras["cfg3_conditional"] = bench_shape(torch, dist, ydeg=15, Kc=1000, S=64, tspan=4.0, tau=None,
                                                      u=(0.0, 0.0), conditional=True, F=F, steps=24,
                                                      device=local_rank)

@@ -33,15 +33,19 @@ __all__ = ["get_log_prob", "get_log_prob_ensemble", "EnsembleLogProb", "SampleBa
 # four likelihood streams + the upstream's own, tools/attic/elp_modes.py, round 5) -- next to GPU_MAX_HW_QUEUES
 # (engine._want_hw_queues).  Callers' ``depth`` is clamped to it, with one warning.
 MAX_STREAMS = 4
+# ... except for steps that carry their upstream (SampleBatches: a third of a step's time on a stream is the samples'
+# moments and tables, light kernels that leave the GPU to the other streams): 88-92k evaluations/s of one K = 1000
+# light curve with four streams, 94-98k with five, 95-99k with six (round 6, one box, bench.bench_samples).
+MAX_STREAMS_SAMPLES = 6
 _warned_depth = [False]
 
 
-def clamp_depth(depth, extra_streams=0):
-    """``depth`` likelihood streams + ``extra_streams`` others, held to MAX_STREAMS concurrent streams."""
+def clamp_depth(depth, extra_streams=0, limit=None):
+    """``depth`` likelihood streams + ``extra_streams`` others, held to MAX_STREAMS (``limit``) concurrent streams."""
     import warnings
 
     depth = max(1, int(depth))
-    allowed = max(1, MAX_STREAMS - int(extra_streams))
+    allowed = max(1, (MAX_STREAMS if limit is None else int(limit)) - int(extra_streams))
     if depth > allowed:
         if not _warned_depth[0]:
             warnings.warn("starry_process_amd: depth=%d (+%d) exceeds %d concurrent streams, beyond which the GPU's "
@@ -312,7 +316,8 @@ class EnsembleLogProb(object):
         # Fewer than 64 stars (one light curve above all): samples are packed ceil(64 / S) to a library call
         # (SampleBatches) -- the GPU sees 64 systems per step whatever S is.
         if self._plan is not None and batch_samples and hi - lo < 64:
-            self._batch = SampleBatches(self._slots + [self._up], self._t, self._flux, stars, self._rta1,
+            more = engine_slots(ydeg, udeg, device, 2) if len(self._slots) + 1 + 2 <= MAX_STREAMS_SAMPLES else []
+            self._batch = SampleBatches(self._slots + [self._up] + more, self._t, self._flux, stars, self._rta1,
                                         self._kw["covpts"], plan=self._plan, zmax=0.023)
         torch.cuda.synchronize(e0.device)
 

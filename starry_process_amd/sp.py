@@ -268,7 +268,7 @@ class StarryProcess(object):
         u=defaults["u"][: defaults["udeg"]],
         baseline_mean=defaults["baseline_mean"],
         baseline_var=defaults["baseline_var"],
-        depth=3,
+        depth=6,
     ):
         """``log_likelihood(t, flux, data_cov, ...)`` of THIS process's settings (degree, normalisation, lag grid,
         temporal kernel) at many hyperparameter vectors: samples (ns, 5) = rows of (r, a, b, c, n) -> (ns,) values, each
@@ -277,7 +277,7 @@ class StarryProcess(object):
         calibrate/sample.py:95-107) is here ONE batched device step per 64 samples (calibrate.SampleBatches) --
         marginalised, normalised processes with one spot radius and scalar or per-cadence data variance; anything
         else is evaluated sample by sample."""
-        from .calibrate import SampleBatches, clamp_depth
+        from .calibrate import MAX_STREAMS_SAMPLES, SampleBatches, clamp_depth
         from .engine import engine_slots
 
         f = self._flux
@@ -305,7 +305,8 @@ class StarryProcess(object):
         cache = self.__dict__.get("_sample_batches")
         if cache is None or cache[0] != key:
             # (the data set is planned once and kept: a sampler calls this with the same data every iteration)
-            slots = engine_slots(self._ydeg, self._udeg, self._kwargs.get("device"), clamp_depth(depth))
+            slots = engine_slots(self._ydeg, self._udeg, self._kwargs.get("device"),
+                                 clamp_depth(depth, limit=MAX_STREAMS_SAMPLES))
             e0 = slots[0][0]
             stars = make_stars(1, period=p, inc_deg=i, tau=self._tau, baseline_var=float(bvar), baseline_mean=float(bmean),
                                data_var=float(data_cov) if data_cov.ndim == 0 else 0.0)

@@ -193,7 +193,7 @@ def test_host_helpers_of_a_sample_batch():
     w = np.array([upstream.log_jac(a, b) for a, b in ab])
     assert np.array_equal(np.isfinite(v), np.isfinite(w)) and np.allclose(v[np.isfinite(w)], w[np.isfinite(w)], rtol=1e-13, atol=1e-13)
     # depth + other streams never exceed MAX_STREAMS; one warning
-    assert MAX_STREAMS == 4 and clamp_depth(3, 1) == 3 and clamp_depth(1) == 1
+    assert MAX_STREAMS == 4 and clamp_depth(3, 1) == 3 and clamp_depth(1) == 1 and clamp_depth(9, limit=6) == 6
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter("always")
         assert clamp_depth(6, 1) == 3 and clamp_depth(9) == 4

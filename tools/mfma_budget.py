@@ -51,9 +51,9 @@ for s0 in range(0, nsteps, w):
         p = 2 * rows_p * 64 * (q * 64.0) + rows_p * 64 * 64 + eag_p + 64.0 ** 3 / 3.0
         alg_panel += S * a
         pad_panel += S * (p - a)
-        # the solve as a product with the explicit inverse L_d^-1: a dense 64 x 64 product (2 rows 64^2) where forward
-        # substitution needs rows 64^2
-        inv_dup += S * rows_p * 64 * 64
+        # the solve as a product with the explicit inverse L_d^-1 on the matrix cores: its ten 16 x 16 blocks on or below
+        # the diagonal, 2 rows 64^2 (10 / 16) = 1.25 rows 64^2 where forward substitution needs rows 64^2
+        inv_dup += S * 0.25 * rows_p * 64 * 64
         # forming L_d^-1 of every pivot block: 64^3 / 3 (the inverse of a triangular block)
         ldinv += S * 64.0 ** 3 / 3.0
 alg_syrk = pad_syrk = diag_dup = 0.0
@@ -84,7 +84,7 @@ print("analytic split of the factorisation's launches (closed forms of cholesky_
 rows = [("algorithmic on K: panel launches", alg_panel), ("algorithmic on K: trailing updates", alg_syrk),
         ("padding to %d rows / 64-wide blocks: panel launches" % Kp, pad_panel),
         ("padding: trailing updates", pad_syrk),
-        ("solve by the explicit inverse (dense L_d^-1 product, 2x substitution)", inv_dup),
+        ("solve by the explicit inverse (ten blocks of L_d^-1: 1.25 x substitution)", inv_dup),
         ("forming L_d^-1 of %d pivot blocks" % nsteps, ldinv),
         ("trailing update: diagonal 16 x 16 blocks in full", diag_dup)]
 acc = 0.0
