@@ -15,7 +15,7 @@
 //   the riding rows [r_0 .. r_{M-1}, 1, (d)] in LDS: R <- R L^-T by substitution against L^-T;
 //   lnlike_reduce_src on the LDS copies.
 //
-// 77 KB of LDS per workgroup for K > 64 (two per CU), 50 KB for K <= 64 (three; measured: keeping tile (1, 0) in
+// 77 KB of LDS per workgroup for K > 64 (two per CU), 40 KB for K <= 64 (four; measured: keeping tile (1, 0) in
 // registers in fragment order would leave three for K > 64 too, and needs more than 256 registers); the same values as the blocked planned
 // step to rounding (tests/test_gpu_small.py: 1e-10 against it, 1e-8 against the oracle).
 #include "sp_internal.h"
@@ -26,13 +26,13 @@
 
 #ifdef SP_SMALL_TRACE
 // (debug builds, tools/ab_build.sh trace -DSP_SMALL_TRACE: wall-clock stamps of the first 64 workgroups' phases)
-__device__ long long g_small_trace[64 * 8];
+__device__ long long g_small_trace[64 * 16];
 #define SMK_STAMP(k)                                                          \
   do {                                                                        \
-    if (blockIdx.x < 64 && threadIdx.x == 0) g_small_trace[blockIdx.x * 8 + (k)] = wall_clock64(); \
+    if (blockIdx.x < 64 && threadIdx.x == 0) g_small_trace[blockIdx.x * 16 + (k)] = wall_clock64(); \
   } while (0)
 extern "C" int sp_debug_small_trace(long long *out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_small_trace), sizeof(long long) * 64 * 8) == hipSuccess ? SP_OK : SP_ERR_HIP;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_small_trace), sizeof(long long) * 64 * 16) == hipSuccess ? SP_OK : SP_ERR_HIP;
 }
 #else
 #define SMK_STAMP(k)
@@ -51,9 +51,9 @@ struct SmallSrc {                    // lnlike_reduce_src's view of the factored
   __device__ __forceinline__ double row(int m, int k) const { return rows[m * ldr + k]; }
 };
 
-// (wavefronts per SIMD the register budget is held to: two workgroups a CU for K > 64, three for K <= 64 -- what their LDS allows)
+// (wavefronts per SIMD the register budget is held to: two workgroups a CU for K > 64, four for K <= 64 -- what their LDS allows)
 template <int NB, int TK>
-__global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void small_lnlike_kernel(
+__global__ __launch_bounds__(256, NB == 2 ? 2 : 4) void small_lnlike_kernel(
     int K, int M, PlanDev plan, const double *__restrict__ t, const sp_star *__restrict__ stars, int covpts,
     const double *__restrict__ tab, const double *__restrict__ meanvar, const double *__restrict__ flux,
     const double *__restrict__ diag, int order, double zmax, double *__restrict__ lnlike,
@@ -64,8 +64,10 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void small_lnlike_kernel(
   const int nr = M + (diag ? 2 : 1);
   double *sD = lds;                              // 64 BLD  | sRd 64 | leaf 256           (SP_DIAG_LDS_DOUBLES)
   double *sRd = sD + 64 * BLD;
-  double *sB = lds + SP_DIAG_LDS_DOUBLES;        // region B: the spline table, then (NB == 2) tile (1, 0) / X
-  double *sTh = sB + regionB;                    // [KC] phases
+  // region B: the spline table, then (NB == 2) tile (1, 0) / X.  NB == 1: no region of its own -- the table lies in the
+  // pivot block's place until the assembly is through (the tile is assembled in registers): 40 KB, four workgroups a CU
+  double *sB = NB == 2 ? lds + SP_DIAG_LDS_DOUBLES : lds;
+  double *sTh = lds + SP_DIAG_LDS_DOUBLES + regionB;   // [KC] phases
   double *sTt = sTh + KC;                        // [KC] times
   double *sR = sTt + KC;                         // [nr][KC] riding rows
   double *sDg = sR + nr * KC;                    // [KC] L_ii
@@ -176,6 +178,7 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void small_lnlike_kernel(
   {
     double w00[16];
     tile(0, 0, w00);
+    if (NB == 1) __syncthreads();        // (the table, in the block's place, has been read by everybody)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int row = 16 * wave + fg + 4 * (e & 3), col = 16 * (e >> 2) + fr;
@@ -210,6 +213,7 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void small_lnlike_kernel(
     return acc;
   };
   double rnew = ride(0);
+  SMK_STAMP(8);
   if (NB == 2) {
     // X = T10 L00^-T: the wavefront's own sixteen rows, all four column blocks in registers before the first store
     d4 x[4];
@@ -228,10 +232,12 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void small_lnlike_kernel(
 #pragma unroll
       for (int r = 0; r < 4; ++r) sB[(16 * wave + fg + 4 * r) * BLD + 16 * nb + fr] = x[nb][r];
   }
+  SMK_STAMP(9);
   __syncthreads();                       // (every reader of R's first half and of L00^-T is through)
   if (tid < nr * 64) sR[(tid >> 6) * KC + (tid & 63)] = rnew;
   if (NB == 2) {
     __syncthreads();                     // X and the solved first half of R are in place
+    SMK_STAMP(10);
     // R[:, 64 ..] -= R[:, .. 63] X^T
     if (tid < nr * 64) {
       const int mr = tid >> 6, cc = tid & 63;
@@ -241,6 +247,7 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void small_lnlike_kernel(
       for (int n = 0; n < 64; ++n) acc = fma(-r0[n], xr[n], acc);
       sR[mr * KC + 64 + cc] = acc;
     }
+    SMK_STAMP(11);
     // T11 -= X X^T (the blocks on or below the diagonal), then to the LDS for its factorisation
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
@@ -253,6 +260,7 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void small_lnlike_kernel(
       }
       a11[nb] = acc;
     }
+    SMK_STAMP(12);
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
@@ -285,8 +293,8 @@ bool sp_small_k_serves(int K, int M, int covpts, bool has_diag) {
   if (K < 2 || K > 128 || nr > SMK_MAXR) return false;
   const int np = covpts + 4;
   // the table lies in the region tile (1, 0) takes later; at most what leaves two workgroups a CU (K > 64) or three
-  if (K > 64) return 4 * np <= 64 * BLD;
-  return 4 * np <= 2560;
+  // (K <= 64: in the pivot block's place)
+  return 4 * np <= 64 * BLD;
 }
 
 int sp_launch_small_lnlike(int S, int K, int M, const PlanDev &plan, const double *t, const sp_star *stars, int covpts,
@@ -294,8 +302,8 @@ int sp_launch_small_lnlike(int S, int K, int M, const PlanDev &plan, const doubl
                            int order, double zmax, double *lnlike, uint32_t *status_out, hipStream_t st) {
   if (!sp_small_k_serves(K, M, covpts, diag != nullptr)) return SP_ERR_INVALID;
   const int NB = K > 64 ? 2 : 1, KC = 64 * NB, np = covpts + 4, nr = M + (diag ? 2 : 1);
-  int regionB = 4 * np;
-  if (NB == 2 && regionB < 64 * BLD) regionB = 64 * BLD;
+  // (K <= 64: the table lies in the pivot block's place -- no region of its own)
+  const int regionB = NB == 2 ? (4 * np < 64 * BLD ? 64 * BLD : 4 * np) : 0;
   const size_t doubles = (size_t)SP_DIAG_LDS_DOUBLES + regionB + 2 * KC + (size_t)nr * KC + KC + 48 + SP_RSCAL_HEAD + M + 1 + 8 + 2;
   const size_t lds = sizeof(double) * doubles;
 #define SP_SMALL(NBV, TKV)                                                                                        \
