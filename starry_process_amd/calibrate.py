@@ -313,9 +313,11 @@ class EnsembleLogProb(object):
                 # (a shape the planned step does not serve -- e.g. a lag grid beyond its LDS budget, covpts > ~4 700:
                 #  the unplanned call has the fallbacks)
                 self._plan = None
-        # Fewer than 64 stars (one light curve above all): samples are packed ceil(64 / S) to a library call
-        # (SampleBatches) -- the GPU sees 64 systems per step whatever S is.
-        if self._plan is not None and batch_samples and hi - lo < 64:
+        # Samples go through SampleBatches: packed ceil(64 / S) to a library call when there are fewer than 64 stars (one
+        # light curve above all) -- the GPU sees 64 systems per step whatever S is --, one sample per call otherwise; either
+        # way the sample's moments come from sp_polar_moments_samples, with no host arithmetic (the per-sample upstream
+        # spends 0.5 ms of NumPy on the size integral and the Gauss-Jacobi rule whenever r or (a, b) change).
+        if self._plan is not None and batch_samples:
             more = engine_slots(ydeg, udeg, device, 2) if len(self._slots) + 1 + 2 <= MAX_STREAMS_SAMPLES else []
             self._batch = SampleBatches(self._slots + [self._up] + more, self._t, self._flux, stars, self._rta1,
                                         self._kw["covpts"], plan=self._plan, zmax=0.023)

@@ -224,6 +224,12 @@ def test_ensemble_log_prob_packs_samples(e15):
     packed = EnsembleLogProb(t, flux, ferr=1e-3, p=per)(sm)
     single = EnsembleLogProb(t, flux, ferr=1e-3, p=per, batch_samples=False)(sm)
     assert np.isfinite(packed).sum() >= 18 and same(packed, single, 1e-9)
+    # 64 stars and more: one sample per call, the same entry points
+    sts64 = [synthetic_star(s, 128) for s in range(70)]
+    t64, f64, p64 = np.array([s["t"] for s in sts64]), np.array([s["flux"] for s in sts64]), [s["p"] for s in sts64]
+    big = EnsembleLogProb(t64, f64, ferr=1e-3, p=p64)
+    assert big._batch is not None and big._batch.group == 1
+    assert same(big(sm[:5]), EnsembleLogProb(t64, f64, ferr=1e-3, p=p64, batch_samples=False)(sm[:5]), 1e-9)
     one = EnsembleLogProb(t[:1], flux[:1], ferr=1e-3, p=per[:1])
     assert one._batch is not None and one._batch.group == 64
     v = one(sm)

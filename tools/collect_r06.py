@@ -35,7 +35,7 @@ copy(last("stats_one/**/*kernel_stats.csv"), "r06_one_kernel_stats.csv")
 copy(last("stats_cfg5/**/*kernel_stats.csv"), "r06_cfg5_kernel_stats.csv")
 copy(last("stats_samples/**/*kernel_stats.csv"), "r06_samples_kernel_stats.csv")
 for name in ("one_step_trace.txt", "prof_elp.txt", "inflight_probe.txt", "grad_timing.txt", "cfg5_shape.txt",
-             "pmc_lds.txt", "stats_unplanned_inflight.txt", "mfma_budget.txt", "samples_bench.txt", "k_sweep.txt",
+             "pmc_lds.txt", "stats_unplanned_inflight.txt", "mfma_budget.txt", "samples_bench.txt", "k_sweep.txt", "small_k_probe.txt", "k_sweep_blocked_small.txt",
              "cfg5_one_step_trace.txt"):
     copy(os.path.join(O, name), "r06_" + name)
 
