@@ -112,16 +112,36 @@ class SampleBatches(object):
         cur = torch.cuda.current_stream(e0.device)
         start = torch.cuda.Event()
         start.record(cur)
+        # (the streams' first groups start STAGGERED, each behind the upstream of the one before: started together, six
+        #  streams of equal steps stay in lockstep -- all in their light upstream phase at once, then all in their
+        #  factorisations at once -- and the call runs at 71k evaluations/s instead of 90-99k, bimodally from run to run)
+        stagger = None
+        # (at most QUEUED groups of a stream wait behind the one that runs: a host that runs hundreds of steps ahead of
+        #  the GPU ends up blocked inside the runtime's launch path -- 0.8 instead of 0.16 ms of host time per step, 52-58k
+        #  evaluations/s instead of 95-100k, bimodally -- so it waits HERE, for a group of three steps back)
+        QUEUED = 3
+        pending = [[] for _ in self._slots]
         for gi in range(ngroups):
             k = gi % len(self._slots)
             (e, stream), b = self._slots[k], self._buf[k]
+            if len(pending[k]) >= QUEUED:
+                pending[k].pop(0).synchronize()
             with torch.cuda.stream(stream):
                 if gi < len(self._slots):
                     stream.wait_event(start)
+                    if stagger is not None:
+                        stream.wait_event(stagger)
                 e.polar_moments_samples(samples[gi * g:(gi + 1) * g], ez=b["ez"], Ez=b["Ez"], **self._ukw)
                 e.kernel_table_samples(b["ez"], b["Ez"], self._rta1, self._covpts, tab=b["tab"], meanvar=b["mv"])
+                if gi + 1 < min(ngroups, len(self._slots)):
+                    stagger = torch.cuda.Event()
+                    stagger.record(stream)
                 e.lnlike_ensemble_planned(self._plan, None, None, self._stars, b["tab"], b["mv"],
                                           norm_order=self._norm_order, zmax=self._zmax, out=raw[gi], workspace=b["ws"])
+                if ngroups > QUEUED * len(self._slots):
+                    ev = torch.cuda.Event()
+                    ev.record(stream)
+                    pending[k].append(ev)
         for k in range(min(ngroups, len(self._slots))):
             done = torch.cuda.Event()
             done.record(self._slots[k][1])
