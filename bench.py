@@ -268,7 +268,8 @@ def roofline_entry(kind, rec, extra=None):
 
 def bench_shape(torch, dist, ydeg, Kc, S, tspan, tau, u, conditional, F, steps, device, planned=False):
     """evals/s and whole-step roofline fraction of another BASELINE shape on this GPU (same
-    in-flight scheme, its own handles; 6 untimed steps first).  planned: the data set planned once (untimed)."""
+    in-flight scheme, its own handles; 6 untimed steps and 150 ms of untimed pre-warm steps first).  planned: the data
+    set planned once (untimed)."""
     from starry_process_amd.engine import engine_slots, make_stars
     from starry_process_amd.synthetic import synthetic_star
 
@@ -297,7 +298,8 @@ def bench_shape(torch, dist, ydeg, Kc, S, tspan, tau, u, conditional, F, steps, 
         for sl in slots:
             sl.plan = plan
     h = Harness(slots, torch.cuda.synchronize)
-    elapsed, _, _ = timed_steps(h, steps, 6, 0.0, None)
+    # (the same stated, untimed pre-warm as the headline's, 150 ms: a shape's timed region must not start on idle clocks)
+    elapsed, _, _ = timed_steps(h, steps, 6, 150.0, None)
     ms = 1e3 * elapsed / steps
     N = (ydeg + 1) ** 2 if conditional else 0
     fl, by = step_work(S, Kc, 1, N)
