@@ -216,16 +216,20 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 4) void small_lnlike_kernel(
   SMK_STAMP(8);
   if (NB == 2) {
     // X = T10 L00^-T: the wavefront's own sixteen rows, all four column blocks in registers before the first store
+    // (the strip's sixteen A fragments into registers first: every k step's fragment feeds the column blocks it reaches
+    //  -- L00^-T is triangular --, four steps per fence so that the B fragments' reads are not all gathered up front)
     d4 x[4];
+    double af[16];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-      d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll 2
-      for (int ks = 0; ks < 4 * (nb + 1); ++ks) {
-        const int k = 4 * ks + fg;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sB[(16 * wave + fr) * BLD + k], linv(16 * nb + fr, k), acc, 0, 0, 0);
-      }
-      x[nb] = acc;
+    for (int ks = 0; ks < 16; ++ks) af[ks] = sB[(16 * wave + fr) * BLD + 4 * ks + fg];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) x[nb] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+#pragma unroll
+      for (int nb = ks >> 2; nb < 4; ++nb)
+        x[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], linv(16 * nb + fr, 4 * ks + fg), x[nb], 0, 0, 0);
+      if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
