@@ -309,6 +309,9 @@ def bench_shape(torch, dist, ydeg, Kc, S, tspan, tau, u, conditional, F, steps, 
            "evals_per_s": S * steps / elapsed, "ms_per_step": ms,
            "whole_step_TFLOPs": fl / (ms * 1e-3) / 1e12,
            "whole_step_frac": fl / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+           # (SURVEY 8d's algorithmic bytes, 24 K^2 per star, over the step: the bound of short light curves -- K / 72 flop
+           #  per byte is below the ridge of ~10 for K < 700)
+           "algorithmic_TBs": by / (ms * 1e-3) / 1e12, "hbm_frac": by / (ms * 1e-3) / 1e12 / HBM_PEAK_TBS,
            "finite": bool(torch.isfinite(slots[0].out).all().item())}
     return res
 
@@ -337,7 +340,7 @@ def bench_k_sweep(torch, dist, F, device, Ks=(64, 128, 256, 512, 1000, 2048, 409
             try:
                 r = bench_shape(torch, dist, ydeg=15, Kc=Kc, S=S, tspan=4.0, tau=None, u=(0.0, 0.0), conditional=cond, F=F,
                                 steps=steps, device=device, planned=not cond)
-                rec[name] = {k: r[k] for k in ("evals_per_s", "ms_per_step", "whole_step_frac", "steps", "finite",
+                rec[name] = {k: r[k] for k in ("evals_per_s", "ms_per_step", "whole_step_frac", "hbm_frac", "steps", "finite",
                                                "planned_data")}
             except Exception as exc:
                 rec[name] = {"error": repr(exc)}

@@ -43,6 +43,12 @@ def test_no_device_is_an_error_not_a_fallback():
     x = np.zeros(8)
     assert L.sp_tensordotRz(h, _lib.hptr(x), _lib.hptr(x), 1, _lib.hptr(x), None) == -3
     assert L.sp_set_ylm_moments(h, _lib.hptr(x), _lib.hptr(x)) == -3
+    # (round 6's entry points as well)
+    assert L.sp_polar_moments_samples(h, 1, _lib.hptr(x), 1e-12, 1e-9, _lib.hptr(x), _lib.hptr(x), None) == -3
+    assert L.sp_kernel_table_samples(h, 1, _lib.hptr(x), _lib.hptr(x), _lib.hptr(x), 1, 300, _lib.hptr(x), _lib.hptr(x),
+                                     _lib.hptr(x), None) == -3
+    assert L.sp_set_size_basis(h, _lib.hptr(x), _lib.hptr(x), 4, 300.0) == -3
+    assert L.sp_plan_replicate(h, None, 2, None, ctypes.byref(ctypes.c_void_p())) == -3
     L.sp_destroy(h)
     with pytest.raises(_lib.SPError):
         from starry_process_amd.engine import Engine
