@@ -27,6 +27,7 @@
 #ifdef SP_SMALL_TRACE
 // (debug builds, tools/ab_build.sh trace -DSP_SMALL_TRACE: wall-clock stamps of the first 64 workgroups' phases)
 __device__ long long g_small_trace[64 * 16];
+__device__ long long g_small_diag[64];      // diag_block's own stamps (shader clock) of workgroup 0's first pivot block
 #define SMK_STAMP(k)                                                          \
   do {                                                                        \
     if (blockIdx.x < 64 && threadIdx.x == 0) g_small_trace[blockIdx.x * 16 + (k)] = wall_clock64(); \
@@ -34,6 +35,14 @@ __device__ long long g_small_trace[64 * 16];
 extern "C" int sp_debug_small_trace(long long *out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_small_trace), sizeof(long long) * 64 * 16) == hipSuccess ? SP_OK : SP_ERR_HIP;
 }
+extern "C" int sp_debug_small_diag(long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_small_diag), sizeof(long long) * 64) == hipSuccess ? SP_OK : SP_ERR_HIP;
+}
+#define SMK_DIAGDBG (blockIdx.x == 0 ? g_small_diag : nullptr)
+#else
+#define SMK_DIAGDBG nullptr
+#endif
+#ifdef SP_SMALL_TRACE
 #else
 #define SMK_STAMP(k)
 #endif
@@ -196,7 +205,7 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 4) void small_lnlike_kernel(
   //  deals consecutive ones to the XCDs and their CUs in turn -- start in step, and with the same roles their leaf
   //  chains would queue on ONE SIMD while three idle: the roles are rotated from workgroup to workgroup)
   const int tid_rot = (tid + 64 * ((blockIdx.x >> 8) & 3)) & 255;
-  int notpd = diag_block(sD, sRd, tid_rot);  // (ends behind a barrier)
+  int notpd = diag_block(sD, sRd, tid_rot, SMK_DIAGDBG);  // (ends behind a barrier)
   SMK_STAMP(3);
   if (tid < 64) sDg[tid] = sD[tid * BLD + tid];
   // Linv[n][k] of the block in sD / sRd (sp_diag.h: L^-T above the diagonal, the reciprocal diagonal apart)

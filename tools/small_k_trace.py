@@ -44,3 +44,14 @@ print("K %d, S %d: phases of workgroups 0 .. 63, us (mean / min / max); whole %.
 for a, b in zip(order[:-1], order[1:]):
     d = (tr[:, b] - tr[:, a]) * 0.01
     print("  %-36s %6.2f  %6.2f  %6.2f" % (names[b], d.mean(), d.min(), d.max()))
+
+# diag_block's own stamps (shader clock cycles) of workgroup 0's first pivot block: per block column kb the owner
+# wavefront's {start, leaf begins, leaf done, stores done, -}, then the next owner's {after the rows below, after its
+# part of the update}
+dg = np.zeros(64, dtype=np.int64)
+if hasattr(L, "sp_debug_small_diag") and L.sp_debug_small_diag(dg.ctypes.data_as(ctypes.c_void_p)) == 0:
+    d = dg.reshape(8, 8)[:4]
+    t0 = d[0, 0]
+    print("diag_block of workgroup 0, cycles from its start (block column: leaf start, leaf done, stored | rows below done, update done):")
+    for kb in range(4):
+        print("  kb %d: %6d %6d %6d | %6d %6d" % (kb, d[kb, 1] - t0, d[kb, 2] - t0, d[kb, 3] - t0, d[kb, 5] - t0, d[kb, 6] - t0))
