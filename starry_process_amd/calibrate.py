@@ -269,7 +269,7 @@ class EnsembleLogProb(object):
     def __init__(self, t, flux, ferr=1.0e-3, p=1.0, i=None, u=None, ydeg=15, baseline_log_var=0.0,
                  baseline_mean=0.0, apply_jac=True, normalized=True,
                  marginalize_over_inclination=True, covpts=None, device=None, depth=3, upstream_stream=True,
-                 batch_samples=True):
+                 batch_samples=True, out_of_bounds="raise"):
         import torch
         import torch.distributed as dist
 
@@ -323,6 +323,11 @@ class EnsembleLogProb(object):
         # alone -- phases, the kernel table's weights in the covariance's sum, the sums of the flux -- is taken once
         # (sp_plan_data), and every sample goes through the planned call: no pass over the K^2 entries of every
         # star's covariance before its factorisation.  One plan, read-only, shared by the slots.
+        if out_of_bounds not in ("raise", "inf"):
+            raise ValueError("out_of_bounds must be 'raise' or 'inf'")
+        # "inf": a sample outside the reference's bounds (which raise ValueError, ops/exceptions.py:30-48) is answered
+        # with -inf and not evaluated -- what a sampler's walkers need when they step out of the prior box
+        self._oob = out_of_bounds
         self._plan = self._batch = None
         if self._marg and normalized and hi - lo > 0 and K >= 2:
             from ._lib import SPError
@@ -353,6 +358,15 @@ class EnsembleLogProb(object):
         samples = np.atleast_2d(np.asarray(samples, dtype=np.float64))
         if samples.shape[1] != 5:
             raise ValueError("samples must be (n, 5): r, a, b, c, n")
+        if self._oob == "inf":
+            from .engine import samples_in_bounds
+
+            ok = samples_in_bounds(samples)
+            if not ok.all():
+                out = np.full(samples.shape[0], -np.inf)
+                if ok.any():
+                    out[ok] = self(samples[ok])
+                return out
         ns, nl = samples.shape[0], self._n_local
         e0 = self._slots[0][0]
         outs = e0.empty(ns, max(nl, 1))

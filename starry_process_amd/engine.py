@@ -13,7 +13,7 @@ from . import _lib
 from . import hostconst
 from ._lib import STAR_DTYPE, TEMPORAL, SPError, c_void_p, check, hptr
 
-__all__ = ["Engine", "DataPlan", "get_engine", "make_stars", "stars_for_samples", "sample_parameters"]
+__all__ = ["Engine", "DataPlan", "get_engine", "make_stars", "stars_for_samples", "sample_parameters", "samples_in_bounds"]
 
 
 def _torch():
@@ -47,6 +47,18 @@ def stars_for_samples(stars, B, ntab):
     out = np.tile(stars, int(B))
     out["table"] = (np.repeat(np.arange(int(B), dtype=np.int64), stars.shape[0]) * int(ntab) + out["table"]).astype(np.int32)
     return out
+
+
+def samples_in_bounds(samples, tol=1e-6):
+    """Boolean mask of the rows of samples [B, 5] = (r [degrees], a, b, c, n) inside the reference's bounds (r in [0, 90],
+    a, b in [0, 1], n >= 0, everything finite; size.py:68, latitude.py:176-197, contrast.py:21-33 through CheckBoundsOp's
+    tolerance): what ``sample_parameters`` raises ValueError for.  A sampler's walkers leave the box; the log-probability
+    callables can answer -inf for such rows instead of raising (``out_of_bounds="inf"``)."""
+    sm = np.atleast_2d(np.asarray(samples, dtype=np.float64))
+    r, a, b, n = sm[:, 0] * (np.pi / 180), sm[:, 1], sm[:, 2], sm[:, 4]
+    ok = np.all(np.isfinite(sm), axis=1)
+    ok &= (r >= -tol) & (r <= 0.5 * np.pi + tol) & (a >= -tol) & (a <= 1 + tol) & (b >= -tol) & (b <= 1 + tol) & (n >= -tol)
+    return ok
 
 
 def sample_parameters(samples, **kw):

@@ -269,6 +269,7 @@ class StarryProcess(object):
         baseline_mean=defaults["baseline_mean"],
         baseline_var=defaults["baseline_var"],
         depth=6,
+        out_of_bounds="raise",
     ):
         """``log_likelihood(t, flux, data_cov, ...)`` of THIS process's settings (degree, normalisation, lag grid,
         temporal kernel) at many hyperparameter vectors: samples (ns, 5) = rows of (r, a, b, c, n) -> (ns,) values, each
@@ -276,7 +277,8 @@ class StarryProcess(object):
         returns.  What a sampler does with the reference one call at a time (sp.py:1052-1062 driven by
         calibrate/sample.py:95-107) is here ONE batched device step per 64 samples (calibrate.SampleBatches) --
         marginalised, normalised processes with one spot radius and scalar or per-cadence data variance; anything
-        else is evaluated sample by sample."""
+        else is evaluated sample by sample.  ``out_of_bounds="inf"``: samples outside the reference's parameter bounds
+        (a ValueError there and, by default, here) get -inf and are not evaluated."""
         from .calibrate import MAX_STREAMS_SAMPLES, SampleBatches, clamp_depth
         from .engine import engine_slots
 
@@ -286,6 +288,19 @@ class StarryProcess(object):
         samples = np.atleast_2d(np.asarray(samples, dtype=np.float64))
         if samples.shape[1] != 5:
             raise ValueError("samples must be (ns, 5): r, a, b, c, n")
+        if out_of_bounds == "inf":
+            from .engine import samples_in_bounds
+
+            ok = samples_in_bounds(samples)
+            if not ok.all():
+                out = np.full(samples.shape[0], -np.inf)
+                if ok.any():
+                    out[ok] = np.asarray(self.log_likelihood_samples(t, flux, data_cov, samples[ok], i=i, p=p, u=u,
+                                                                     baseline_mean=baseline_mean, baseline_var=baseline_var,
+                                                                     depth=depth))
+                return Eager(out)
+        elif out_of_bounds != "raise":
+            raise ValueError("out_of_bounds must be 'raise' or 'inf'")
         flux = np.asarray(flux, dtype=np.float64)
         F = flux.reshape(1, K) if flux.ndim == 1 else flux.reshape(-1, K)
         data_cov = np.asarray(data_cov, dtype=np.float64)

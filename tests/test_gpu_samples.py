@@ -230,6 +230,12 @@ def test_ensemble_log_prob_packs_samples(e15):
     big = EnsembleLogProb(t64, f64, ferr=1e-3, p=p64)
     assert big._batch is not None and big._batch.group == 1
     assert same(big(sm[:5]), EnsembleLogProb(t64, f64, ferr=1e-3, p=p64, batch_samples=False)(sm[:5]), 1e-9)
+    soft = EnsembleLogProb(t, flux, ferr=1e-3, p=per, out_of_bounds="inf")
+    mixed = np.vstack([sm[:2], [[20.0, -0.2, 0.3, 0.1, 10.0]], sm[2:4]])
+    vm = soft(mixed)
+    assert vm[2] == -np.inf and same(vm[[0, 1, 3, 4]], packed[:4], 1e-12)
+    with pytest.raises(ValueError):
+        EnsembleLogProb(t, flux, ferr=1e-3, p=per)(mixed)
     one = EnsembleLogProb(t[:1], flux[:1], ferr=1e-3, p=per[:1])
     assert one._batch is not None and one._batch.group == 64
     v = one(sm)
@@ -295,6 +301,11 @@ def test_log_likelihood_samples_of_a_process():
     assert np.isfinite(got).sum() >= 3
     with pytest.raises(ValueError):
         sp.log_likelihood_samples(st["t"], st["flux"], 1e-6, [[95.0, 0.4, 0.27, 0.1, 10.0]], p=st["p"])
+    # out_of_bounds="inf": a walker outside the box gets -inf, the others their values
+    mixed = np.vstack([sm[:2], [[95.0, 0.4, 0.27, 0.1, 10.0]], sm[2:3], [[20.0, 0.4, 1.5, 0.1, 10.0]]])
+    v = np.asarray(sp.log_likelihood_samples(st["t"], st["flux"], 1e-6, mixed, p=st["p"], out_of_bounds="inf"))
+    w = np.asarray(sp.log_likelihood_samples(st["t"], st["flux"], 1e-6, sm[:3], p=st["p"]))
+    assert v[2] == -np.inf and v[4] == -np.inf and np.array_equal(v[[0, 1, 3]], w)
 
 
 def test_samples_bad_arguments(e15):

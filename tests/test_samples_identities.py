@@ -184,6 +184,19 @@ def test_host_helpers_of_a_sample_batch():
             sample_parameters([bad])
     with pytest.raises(ValueError):
         sample_parameters(np.zeros((2, 4)))
+    from starry_process_amd.engine import samples_in_bounds
+
+    rows = np.array([[20.0, 0.4, 0.27, 0.1, 10.0], [95.0, 0.4, 0.27, 0.1, 10.0], [20.0, 1.1, 0.27, 0.1, 10.0],
+                     [20.0, 0.4, -0.1, 0.1, 10.0], [20.0, 0.4, 0.27, 0.1, -1.0], [20.0, 0.4, 0.27, np.nan, 1.0],
+                     [0.0, 0.0, 1.0, -0.3, 0.0]])
+    assert list(samples_in_bounds(rows)) == [True, False, False, False, False, False, True]
+    for k, row in enumerate(rows):             # (the mask IS what sample_parameters raises for)
+        try:
+            sample_parameters([row])
+            raised = False
+        except ValueError:
+            raised = True
+        assert raised != bool(samples_in_bounds(rows)[k]), k
     stars = make_stars(3, period=[1.0, 2.0, 3.0], table=[0, 1, 0])
     rep = stars_for_samples(stars, 4, 2)
     assert rep.shape == (12,) and list(rep["table"]) == [0, 1, 0, 2, 3, 2, 4, 5, 4, 6, 7, 6]
