@@ -203,6 +203,9 @@ __device__ __forceinline__ void below_quad(double *sD, const double *sRd, const 
                                            int tid) {
   const int o = 16 * kb, nbelow = 48 - o;
   const int row = tid >> 2, q = tid & 3;
+  // (a wavefront holds sixteen rows: 3 - kb of the four have any -- the others leave, wavefront-uniform; they were
+  //  half of this function's instructions, which co-resident workgroups of the small-K kernel pay for)
+  if (16 * (tid >> 6) >= nbelow) return;
   const bool live = row < nbelow;
   double *p = sD + (o + 16 + (live ? row : 0)) * BLD + o + 2 * q;
   const d2v a = *reinterpret_cast<const d2v *>(p), b = *reinterpret_cast<const d2v *>(p + 8);
@@ -297,9 +300,12 @@ __device__ __forceinline__ void inverse_block_row(double *sD, const double *sRd,
 // behind the stores.  On return (behind a barrier) sD holds L below the diagonal, L^-T above it
 // (sD[r][c] = Linv[c][r] for r < c) and sRd the reciprocal diagonal.  Returns 1 in every thread of
 // wavefronts that saw a non-positive pivot (callers OR it through global memory).
+// INV = false: L alone -- the upper triangle stays zero, sRd is still the reciprocal diagonal (the small-K kernel's
+// blocks whose inverse nobody multiplies with: forming it was half of this function's vector instructions).
+template <bool INV = true>
 __device__ __forceinline__ int diag_block(double *sD, double *sRd, int tid_in = threadIdx.x,
                                           long long *dbg = nullptr) {
-  const bool inv = true;
+  const bool inv = INV;
   int notpd = 0;
 #pragma unroll 1
   for (int kb = 0; kb < 4; ++kb) {
@@ -357,14 +363,14 @@ __device__ __forceinline__ int diag_block(double *sD, double *sRd, int tid_in = 
     if (dbg && wave == (kb < 3 ? kb + 1 : 3) && lane == 0) dbg[8 * kb + 6] = clock64();
   }
   // the last block row of the inverse (nothing left to hide it behind)
-  {
+  if (INV) {
     int tid = tid_in;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = tid >> 6;
     inverse_block_row(sD, sRd, 3, wave == 3, wave < 3 ? wave : -1, lane);
+    __syncthreads();
   }
-  __syncthreads();
-  return notpd;
+  return notpd;    // (INV = false: the barrier behind the last leaf was the last one)
 }
 
 #endif

@@ -49,8 +49,12 @@ struct RedSrcMem {
   __device__ __forceinline__ double row(int m, int k) const { return red_ld<COHERENT>(Mx + (size_t)(K + m) * ld + k); }
 };
 
-// red: 48 doubles of LDS; s-indexed pointers are the star's own entries (null where the caller has none)
-template <bool COHERENT, class SRC>
+// red: 48 doubles of LDS; s-indexed pointers are the star's own entries (null where the caller has none).
+// NT: the threads that take part -- 256, the whole workgroup (barriers inside), or 64: the caller's FIRST WAVEFRONT
+// alone, the other three must not call (no barrier inside, `red` unused; the small-K kernel, whose stars are at most
+// 128 cadences long: four wavefronts through the logarithms, the shuffles and the scalar finish were a quarter of that
+// kernel's vector instructions, tools/small_k_pmc.sh).  U: entries per thread and pass of the first loop.
+template <bool COHERENT, class SRC, int NT = 256, int U = 4>
 __device__ __forceinline__ void lnlike_reduce_src(
     const SRC src, int K, int M, const int32_t *info_s,
     double *__restrict__ lnlike_s, uint32_t *status_s, uint32_t *status_out_s,
@@ -63,6 +67,11 @@ __device__ __forceinline__ void lnlike_reduce_src(
 #pragma unroll
     for (int a = 0; a < 8; ++a)
       for (int off = 32; off > 0; off >>= 1) v[a] += __shfl_down(v[a], off, 64);
+    if (NT == 64) {
+#pragma unroll
+      for (int a = 0; a < 8; ++a) v[a] = __shfl(v[a], 0, 64);
+      return;
+    }
     __syncthreads();
     if ((tid & 63) == 0) {
 #pragma unroll
@@ -79,11 +88,11 @@ __device__ __forceinline__ void lnlike_reduce_src(
   const bool dv = defer && dvec;
   // (four rows of loads in flight at a time: the diagonal is one cache line per entry, and one
   //  entry per round trip made this loop 5 us of a 9 us reduction)
-  for (int base = 0; base < K; base += 1024) {
-    double dg[4], r[4], pa[4], pb[4];
+  for (int base = 0; base < K; base += NT * U) {
+    double dg[U], r[U], pa[U], pb[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = base + tid + 256 * u;
+    for (int u = 0; u < U; ++u) {
+      const int i = base + tid + NT * u;
       const bool ok = i < K;
       const int ii = ok ? i : 0;
       dg[u] = src.diag(ii);
@@ -96,7 +105,7 @@ __device__ __forceinline__ void lnlike_reduce_src(
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       v[0] += log(dg[u]);
       const double rr = r[u], a = pa[u], b = pb[u];
       v[1] += a * a; v[2] += a * b; v[3] += b * b;
@@ -141,7 +150,7 @@ __device__ __forceinline__ void lnlike_reduce_src(
     if (m == 0) {
       w[0] = v[4]; w[1] = v[5]; w[2] = v[6];
     } else {
-      for (int k = tid; k < K; k += 256) {
+      for (int k = tid; k < K; k += NT) {
         const double r = src.row(m, k);
         w[0] += r * r;
         if (defer) w[1] += r * src.row(M, k);

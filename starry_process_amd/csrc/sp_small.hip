@@ -42,8 +42,14 @@ extern "C" int sp_debug_small_diag(long long *out) {
 #else
 #define SMK_DIAGDBG nullptr
 #endif
-#ifdef SP_SMALL_TRACE
-#else
+#if defined(SMK_STOP)
+// (debug builds, -DSMK_STOP=k: the workgroup returns at phase boundary k -- instruction counts of the phases from PMC
+//  differences, tools/small_k_pmc.sh; results are garbage)
+#define SMK_STAMP(k)        \
+  do {                      \
+    if ((k) == SMK_STOP) return; \
+  } while (0)
+#elif !defined(SP_SMALL_TRACE)
 #define SMK_STAMP(k)
 #endif
 
@@ -205,9 +211,30 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 4) void small_lnlike_kernel(
   //  deals consecutive ones to the XCDs and their CUs in turn -- start in step, and with the same roles their leaf
   //  chains would queue on ONE SIMD while three idle: the roles are rotated from workgroup to workgroup)
   const int tid_rot = (tid + 64 * ((blockIdx.x >> 8) & 3)) & 255;
-  int notpd = diag_block(sD, sRd, tid_rot, SMK_DIAGDBG);  // (ends behind a barrier)
+  // (K <= 64: nobody multiplies with the block's inverse -- the riding rows are substituted, ride_subst)
+  int notpd = diag_block<NB == 2>(sD, sRd, tid_rot, SMK_DIAGDBG);  // (ends behind a barrier)
   SMK_STAMP(3);
   if (tid < 64) sDg[tid] = sD[tid * BLD + tid];
+  // The riding rows of a block that has no inverse, y = L^-1 r by substitution: wavefront mr takes row mr, lane i holds
+  // s_i = r_i / L_ii; step c hands y_c = s_c to every lane (v_readlane) and s_i -= (L_ic / L_ii) y_c.  The block's
+  // diagonal is ZEROED first (it is in sDg) and its upper triangle is zero (diag_block<false>), so lanes i <= c are
+  // left alone and lane i ends with y_i: four vector instructions per step and row, no select.
+  auto ride_subst = [&](int c0) {
+    if (tid < 64) sD[tid * BLD + tid] = 0.0;
+    __syncthreads();
+    if (wave < nr) {
+      const double rdi = sRd[lane];
+      const double *Lrow = sD + lane * BLD;
+      double sv = sR[wave * KC + c0 + lane] * rdi;
+#pragma unroll
+      for (int c = 0; c < 64; c += 2) {
+        const d2v l = *reinterpret_cast<const d2v *>(Lrow + c);
+        sv = fma(-(l.x * rdi), read_lane(sv, c), sv);
+        sv = fma(-(l.y * rdi), read_lane(sv, c + 1), sv);
+      }
+      sR[wave * KC + c0 + lane] = sv;
+    }
+  };
   // Linv[n][k] of the block in sD / sRd (sp_diag.h: L^-T above the diagonal, the reciprocal diagonal apart)
   auto linv = [&](int n, int k) { return k < n ? sD[k * BLD + n] : (k == n ? sRd[k] : 0.0); };
   auto ride = [&](int c0) {              // R[:, c0 .. c0 + 63] <- R[:, c0 ..] L^-T   (value returned, stored by the caller)
@@ -221,7 +248,9 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 4) void small_lnlike_kernel(
     }
     return acc;
   };
-  double rnew = ride(0);
+  double rnew = 0.0;
+  if (NB == 2) rnew = ride(0);
+  else ride_subst(0);
   SMK_STAMP(8);
   if (NB == 2) {
     // X = T10 L00^-T: the wavefront's own sixteen rows, all four column blocks in registers before the first store
@@ -246,9 +275,9 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 4) void small_lnlike_kernel(
       for (int r = 0; r < 4; ++r) sB[(16 * wave + fg + 4 * r) * BLD + 16 * nb + fr] = x[nb][r];
   }
   SMK_STAMP(9);
-  __syncthreads();                       // (every reader of R's first half and of L00^-T is through)
-  if (tid < nr * 64) sR[(tid >> 6) * KC + (tid & 63)] = rnew;
   if (NB == 2) {
+    __syncthreads();                     // (every reader of R's first half and of L00^-T is through)
+    if (tid < nr * 64) sR[(tid >> 6) * KC + (tid & 63)] = rnew;
     __syncthreads();                     // X and the solved first half of R are in place
     SMK_STAMP(10);
     // R[:, 64 ..] -= R[:, .. 63] X^T
@@ -283,18 +312,19 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 4) void small_lnlike_kernel(
       }
     __syncthreads();                     // (diag_block wants a barrier behind the block's stores)
     SMK_STAMP(4);
-    notpd |= diag_block(sD, sRd, tid_rot);
+    notpd |= diag_block<false>(sD, sRd, tid_rot);
     SMK_STAMP(5);
     if (tid < 64) sDg[64 + tid] = sD[tid * BLD + tid];
-    rnew = ride(64);
-    __syncthreads();
-    if (tid < nr * 64) sR[(tid >> 6) * KC + 64 + (tid & 63)] = rnew;
+    ride_subst(64);
   }
   notpd = __syncthreads_or(notpd);
   SMK_STAMP(6);
   // ---- reduction ------------------------------------------------------------------------------------------------------
-  lnlike_reduce_src<false>(SmallSrc{sDg, sR, KC}, K, M, nullptr, lnlike + s, sStat, status_out ? status_out + s : nullptr,
-                           stars + s, sCoef, sRs, diag ? 1 : 0, sRed, tid, notpd);
+  // (the first wavefront alone: at most two entries a lane)
+  if (tid >= 64) return;
+  lnlike_reduce_src<false, SmallSrc, 64, NB>(SmallSrc{sDg, sR, KC}, K, M, nullptr, lnlike + s, sStat,
+                                             status_out ? status_out + s : nullptr, stars + s, sCoef, sRs, diag ? 1 : 0,
+                                             sRed, tid, notpd);
   SMK_STAMP(7);
 }
 

@@ -1,6 +1,6 @@
 """The small-K kernel (csrc/sp_small.hip) alone: time of the planned call against the number of stars -- one workgroup
 per star, so S = 256 is one workgroup per CU (its latency alone), 512 / 768 two / three per CU, beyond that rounds.
-python tools/small_k_probe.py [K ...]"""
+python tools/small_k_probe.py [K ...]        (SP_PROBE_S=256,3072 picks the star counts)"""
 import os
 import sys
 
@@ -19,7 +19,7 @@ e.set_moments(mom["default_mean_ylm"], mom["default_cov_ylm"])
 tab, mv = e.kernel_table(e.f64(e.rTA1L([0.0, 0.0])), 300)
 for K in [int(x) for x in sys.argv[1:]] or [64, 128]:
     base = [synthetic_star(s, K) for s in range(64)]
-    for S in (8, 256, 512, 768, 1536, 3072):
+    for S in [int(x) for x in os.environ.get("SP_PROBE_S", "8,256,512,768,1536,3072").split(",")]:
         sts = [base[s % 64] for s in range(S)]
         t_d = e.f64(np.array([s["t"] for s in sts]))
         f_d = e.f64(np.array([s["flux"] for s in sts])[:, None, :])
