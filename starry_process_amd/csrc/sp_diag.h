@@ -72,12 +72,13 @@ __device__ __forceinline__ double row_bcast(double v) {
 // a v_fma_f64 were two -- the leaf is bound by the instructions it issues, not by its pivot chain.  Same value
 // bit for bit (a product's sign is exact).  The caller keeps two wait states between the VALU write of b and
 // this read of it through DPP (s_nop 1: inline assembly is opaque to the hazard recogniser).
-template <int J, bool NOP = false>
+template <int J, int WAIT = 0>      // WAIT: idle wait states in front (s_nop WAIT - 1), 0 = none
 __device__ __forceinline__ void fmac_bcast(double &a, double b, double c) {
-  if (NOP)
-    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+  static_assert(WAIT >= 0 && WAIT <= 8, "s_nop takes up to 8 wait states");
+  if (WAIT > 0)
+    asm volatile("s_nop %4\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
                  : "+v"(a)
-                 : "v"(b), "v"(c), "n"(J));
+                 : "v"(b), "v"(c), "n"(J), "n"(WAIT > 0 ? WAIT - 1 : 0));
   else
     asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
                  : "+v"(a)
@@ -88,7 +89,7 @@ __device__ __forceinline__ void fmac_bcast(double &a, double b, double c) {
 template <int C, int J>
 struct LeafUpd {
   static __device__ __forceinline__ void run(double (&a)[16], double l) {
-    fmac_bcast<J, J == C + 2>(a[J], l, l);     // (the first of a column waits out the hazard, wherever it is scheduled)
+    fmac_bcast<J, (J == C + 2 ? 2 : 0)>(a[J], l, l);     // (the first of a column waits out the hazard, wherever it is scheduled)
     LeafUpd<C, J + 1>::run(a, l);
   }
 };
@@ -226,24 +227,43 @@ __device__ __forceinline__ void below_quad(double *sD, const double *sRd, const 
 // (matrix cores; the partial sum comes out of the MFMA in exactly the layout of the next B operand,
 // so nothing goes through LDS in between).  Storage: the UPPER triangle of sD, which the
 // factorisation never touches: sD[r][c] = Linv[c][r] for r < c; the diagonal of Linv is sRd.
+// M = L_cc^-1 by substitution on the identity, lane = row, FOUR columns per lane (columns 4 t + g for the lanes of
+// 16-lane group g: s[t] ends as M[i][4 t + g], the A fragment (step t) of an MFMA whose A operand is M).  The rows are
+// pre-scaled (Ls[k] = L_ik / L_ii, zero for k >= i), so the system has a unit diagonal: lane K's s IS x_K when step K
+// comes, and the step is ONE instruction per column -- s_i -= Ls_iK * s_K with the row broadcast folded into the
+// multiply-add (fmac_bcast, as in the leaf); lanes i <= K are left alone by the zeros of Ls, no select, no multiply on
+// the chain.  Column 4 t + g is zero above its diagonal: chain t starts at step 4 t.  (Rounds 2-5: multiply by 1 / L_KK,
+// select, two v_mov_dpp and a multiply-add per step and column -- 6 instructions where this has one; the block row's
+// wavefronts held the next leaf's barrier up for ~2 000 cycles per block column, and the last block row, which nothing
+// hides, was 2 us of the pivot block's 12.6.)
 template <int K>
 struct LeafInvStep {
-  // columns 4 t + g of the inverse for the lanes of 16-lane group g: res[t] = M[i][4 t + g], the A
-  // fragment (step t) of an MFMA whose A operand is M
-  static __device__ __forceinline__ void run(double (&s)[4], double (&res)[4], const double (&Lrow)[16],
-                                             double rd, int i) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const double m = s[t] * rd;                 // row K of the column: final in lane K
-      res[t] = (i == K) ? m : res[t];
-      s[t] = fma(-Lrow[K], row_bcast<K>(m), s[t]);
-    }
-    LeafInvStep<K + 1>::run(s, res, Lrow, rd, i);
+  static __device__ __forceinline__ void run(double (&s)[4], const double (&Ls)[16]) {
+    constexpr int NT = K / 4 + 1;      // chains that have started
+    // Two wait states between a VALU write of a register and its read through DPP -- and inline assembly is opaque to
+    // the compiler's hazard recogniser: it scheduled the select that INITIALISES a column (s[3]) directly in front of
+    // that column's first step, whose asm carried no idle states of its own because the chains' own spacing did not
+    // need them.  The inverse was then wrong in its TENTH digit in some instantiations: every comparison with the
+    // oracle passed, only the 1e-12 comparison of the two samplers (tests/test_gpu_facade.py) did not.  So EVERY
+    // instruction here brings at least two idle states (more while few chains are in turn: ~130 cycles per block row,
+    // of ~2 000 saved), and tools/check_dpp_hazard.py (tests/test_host.py) reads the compiled kernels for a write of a
+    // DPP source less than two wait states ahead of any v_fmac_f64_dpp.  (-DSP_INV_WAIT_MIN: the spacing that failed,
+    // for that check's own test.)
+#ifdef SP_INV_WAIT_MIN
+    constexpr int W = 0, W0 = K < 9 ? 2 : 0;
+#else
+    constexpr int W = NT == 1 ? 8 : (NT == 2 ? 4 : (NT == 3 ? 3 : 2)), W0 = W;
+#endif
+    fmac_bcast<K, W0>(s[0], s[0], Ls[K]);
+    if (NT > 1) fmac_bcast<K, W>(s[1], s[1], Ls[K]);
+    if (NT > 2) fmac_bcast<K, W>(s[2], s[2], Ls[K]);
+    if (NT > 3) fmac_bcast<K, W>(s[3], s[3], Ls[K]);
+    LeafInvStep<K + 1>::run(s, Ls);
   }
 };
 template <>
-struct LeafInvStep<16> {
-  static __device__ __forceinline__ void run(double (&)[4], double (&)[4], const double (&)[16], double, int) {}
+struct LeafInvStep<15> {
+  static __device__ __forceinline__ void run(double (&)[4], const double (&)[16]) {}
 };
 
 // block row c of Linv by ONE wavefront: `writer` stores M_c (strictly lower part, transposed into
@@ -252,23 +272,20 @@ __device__ __forceinline__ void inverse_block_row(double *sD, const double *sRd,
                                                   int j, int lane) {
   if (!writer && j < 0) return;
   const int i = lane & 15, g = lane >> 4, o = 16 * c;
-  double Lrow[16];
+  double Ls[16];
 #pragma unroll
   for (int k = 0; k < 16; k += 2) {
     const d2v v = *reinterpret_cast<const d2v *>(sD + (o + i) * BLD + o + k);
-    Lrow[k] = v.x;
-    Lrow[k + 1] = v.y;
+    Ls[k] = v.x;
+    Ls[k + 1] = v.y;
   }
-#pragma unroll
-  for (int k = 0; k < 16; ++k) Lrow[k] = k > i ? 0.0 : Lrow[k];   // (above the leaf's diagonal: not L)
   const double rd = sRd[o + i];
-  double s[4], res[4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    s[t] = (i == 4 * t + g) ? 1.0 : 0.0;
-    res[t] = 0.0;
-  }
-  LeafInvStep<0>::run(s, res, Lrow, rd, i);
+  for (int k = 0; k < 16; ++k) Ls[k] = k >= i ? 0.0 : Ls[k] * rd;   // (on and above the leaf's diagonal: not L)
+  double res[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) res[t] = (i == 4 * t + g) ? rd : 0.0;
+  LeafInvStep<0>::run(res, Ls);
   if (writer) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {

@@ -66,9 +66,9 @@ struct SmallSrc {                    // lnlike_reduce_src's view of the factored
   __device__ __forceinline__ double row(int m, int k) const { return rows[m * ldr + k]; }
 };
 
-// (wavefronts per SIMD the register budget is held to: two workgroups a CU for K > 64, four for K <= 64 -- what their LDS allows)
+// (wavefronts per SIMD the register budget is held to: three workgroups a CU for K > 64, four for K <= 64 -- what their LDS allows)
 template <int NB, int TK>
-__global__ __launch_bounds__(256, NB == 2 ? 2 : 4) void small_lnlike_kernel(
+__global__ __launch_bounds__(256, NB == 2 ? 3 : 4) void small_lnlike_kernel(
     int K, int M, PlanDev plan, const double *__restrict__ t, const sp_star *__restrict__ stars, int covpts,
     const double *__restrict__ tab, const double *__restrict__ meanvar, const double *__restrict__ flux,
     const double *__restrict__ diag, int order, double zmax, double *__restrict__ lnlike,
@@ -79,8 +79,9 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 4) void small_lnlike_kernel(
   const int nr = M + (diag ? 2 : 1);
   double *sD = lds;                              // 64 BLD  | sRd 64 | leaf 256           (SP_DIAG_LDS_DOUBLES)
   double *sRd = sD + 64 * BLD;
-  // region B: the spline table, then (NB == 2) tile (1, 0) / X.  NB == 1: no region of its own -- the table lies in the
-  // pivot block's place until the assembly is through (the tile is assembled in registers): 40 KB, four workgroups a CU
+  // region B: the spline table (NB == 2: tiles (1, 0) and (1, 1) are assembled after pivot block 0).  NB == 1: no region
+  // of its own -- the table lies in the pivot block's place until the assembly is through (the tile is assembled in
+  // registers): 40 KB, four workgroups a CU
   double *sB = NB == 2 ? lds + SP_DIAG_LDS_DOUBLES : lds;
   double *sTh = lds + SP_DIAG_LDS_DOUBLES + regionB;   // [KC] phases
   double *sTt = sTh + KC;                        // [KC] times
@@ -139,34 +140,31 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 4) void small_lnlike_kernel(
     sR[e] = v;
   }
   SMK_STAMP(1);
-  // ---- assembly: a thread's sixteen entries of a tile in the MFMA accumulator layout -------------------------------
+  // ---- assembly: sixteen entries of a thread, where a layout wants them ------------------------------------------------
   const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
   SplineGen g{sB, 2 * np, 6.283185307179586 / covpts, 1.0 / (6.283185307179586 / covpts), covpts};
   // (entries in batches of BT through SplineGen::many, one batch after the other: sixteen at once keep ~90 doubles of
-  //  gather temporaries alive beside the tiles held in registers -- 121 spilled registers in the K > 64 kernel)
+  //  gather temporaries alive)
   constexpr int BT = NB == 2 ? 4 : 8;
-  auto tile = [&](int ti, int tj, double (&w)[16]) {
+  // entry e of the thread is (rowf(e), colf(e)) of the star's matrix; skipf(e0): the batch from e0 is not wanted (zeros)
+  auto entries = [&](auto rowf, auto colf, auto skipf, double (&w)[16]) {
 #pragma unroll
     for (int e0 = 0; e0 < 16; e0 += BT) {
-      // (a diagonal tile's 16 x 16 blocks above the diagonal are never read: the wavefront's row strip is block row
-      //  `wave`, column blocks beyond it are skipped whole -- wavefront-uniform)
-      if (ti == tj && (e0 >> 2) > wave) {
+      if (skipf(e0)) {                    // (wavefront-uniform)
 #pragma unroll
         for (int q = 0; q < BT; ++q) w[e0 + q] = 0.0;
         continue;
       }
       double a[BT], b[BT], o[BT];
 #pragma unroll
-      for (int q = 0; q < BT; ++q) {      // e = 4 nb + r: row 16 wave + fg + 4 r, column 16 nb + fr
-        const int e = e0 + q;
-        a[q] = sTh[64 * ti + 16 * wave + fg + 4 * (e & 3)];
-        b[q] = sTh[64 * tj + 16 * (e >> 2) + fr];
+      for (int q = 0; q < BT; ++q) {
+        a[q] = sTh[rowf(e0 + q)];
+        b[q] = sTh[colf(e0 + q)];
       }
       g.many<BT>(a, b, o);
 #pragma unroll
       for (int q = 0; q < BT; ++q) {
-        const int e = e0 + q;
-        const int i = 64 * ti + 16 * wave + fg + 4 * (e & 3), j = 64 * tj + 16 * (e >> 2) + fr;
+        const int i = rowf(e0 + q), j = colf(e0 + q);
         double v = nobs == 1 ? var1 : o[q];
         if (TK != SP_TEMPORAL_NONE) v *= temporal_factor(TK, sTt[i], sTt[j], st.tau);
         if (i < nobs && j < nobs) {
@@ -174,37 +172,31 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 4) void small_lnlike_kernel(
         } else {
           v = i == j ? 1.0 : 0.0;
         }
-        w[e] = v;
+        w[e0 + q] = v;
       }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  double w10[16];
-  d4 a11[4];
-  if (NB == 2) {
-    double w11[16];
-    tile(1, 1, w11);
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) a11[nb] = d4{w11[4 * nb], w11[4 * nb + 1], w11[4 * nb + 2], w11[4 * nb + 3]};
-    __builtin_amdgcn_sched_barrier(0);
-    tile(1, 0, w10);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  {
-    double w00[16];
-    tile(0, 0, w00);
-    if (NB == 1) __syncthreads();        // (the table, in the block's place, has been read by everybody)
+  // a diagonal tile in the MFMA accumulator layout (e = 4 nb + r: row 16 wave + fg + 4 r, column 16 nb + fr): the
+  // wavefront's row strip is block row `wave`, the 16 x 16 blocks right of the diagonal are never read
+  auto diag_tile = [&](int ti, double (&w)[16]) {
+    entries([&](int e) { return 64 * ti + 16 * wave + fg + 4 * (e & 3); }, [&](int e) { return 64 * ti + 16 * (e >> 2) + fr; },
+            [&](int e0) { return (e0 >> 2) > wave; }, w);
+  };
+  auto store_lower = [&](const double (&w)[16]) {     // ... to the pivot block's place, zeros above the diagonal
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int row = 16 * wave + fg + 4 * (e & 3), col = 16 * (e >> 2) + fr;
-      sD[row * BLD + col] = col > row ? 0.0 : w00[e];
+      sD[row * BLD + col] = col > row ? 0.0 : w[e];
     }
+  };
+  {
+    double w00[16];
+    diag_tile(0, w00);
+    if (NB == 1) __syncthreads();        // (the table, in the block's place, has been read by everybody)
+    store_lower(w00);
   }
-  __syncthreads();                       // (the table has been read by everybody: region B may take tile (1, 0))
-  if (NB == 2) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) sB[(16 * wave + fg + 4 * (e & 3)) * BLD + 16 * (e >> 2) + fr] = w10[e];
-  }
+  __syncthreads();
   SMK_STAMP(2);
   // ---- pivot block 0 ------------------------------------------------------------------------------------------------
   // (wavefront w of diag_block owns block column w: workgroups that share a CU -- 256 apart in the grid, the hardware
@@ -235,81 +227,79 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 4) void small_lnlike_kernel(
       sR[wave * KC + c0 + lane] = sv;
     }
   };
-  // Linv[n][k] of the block in sD / sRd (sp_diag.h: L^-T above the diagonal, the reciprocal diagonal apart)
-  auto linv = [&](int n, int k) { return k < n ? sD[k * BLD + n] : (k == n ? sRd[k] : 0.0); };
-  auto ride = [&](int c0) {              // R[:, c0 .. c0 + 63] <- R[:, c0 ..] L^-T   (value returned, stored by the caller)
-    double acc = 0.0;
+  if (NB == 1) {
+    ride_subst(0);
+    SMK_STAMP(8);
+  } else {
+    // Linv[n][k] of the block in sD / sRd (sp_diag.h: L^-T above the diagonal, the reciprocal diagonal apart)
+    auto linv = [&](int n, int k) { return k < n ? sD[k * BLD + n] : (k == n ? sRd[k] : 0.0); };
+    // R[:, .. 63] <- R[:, .. 63] L00^-T (value kept, stored behind the barrier)
+    double rnew = 0.0;
     if (tid < nr * 64) {
       const int mr = tid >> 6, n = tid & 63;
-      const double *row = sR + mr * KC + c0;
-      acc = row[n] * sRd[n];
+      const double *row = sR + mr * KC;
+      rnew = row[n] * sRd[n];
 #pragma unroll 4
-      for (int k = 0; k < n; ++k) acc = fma(row[k], sD[k * BLD + n], acc);
+      for (int k = 0; k < n; ++k) rnew = fma(row[k], sD[k * BLD + n], rnew);
     }
-    return acc;
-  };
-  double rnew = 0.0;
-  if (NB == 2) rnew = ride(0);
-  else ride_subst(0);
-  SMK_STAMP(8);
-  if (NB == 2) {
-    // X = T10 L00^-T: the wavefront's own sixteen rows, all four column blocks in registers before the first store
-    // (the strip's sixteen A fragments into registers first: every k step's fragment feeds the column blocks it reaches
-    //  -- L00^-T is triangular --, four steps per fence so that the B fragments' reads are not all gathered up front)
+    SMK_STAMP(8);
+    // X = T10 L00^-T: tile (1, 0) is assembled NOW and straight into the A fragments of the wavefront's own sixteen
+    // rows (entry ks: row 64 + 16 wave + fr, column 4 ks + fg) -- it never lies in the LDS, and nothing of it is held
+    // across the pivot block: one tile of LDS per workgroup instead of two, three workgroups a CU.  Every k step's
+    // fragment feeds the column blocks it reaches (L00^-T is triangular), four steps per fence so that the B
+    // fragments' reads are not all gathered up front.
     d4 x[4];
-    double af[16];
+    {
+      double af[16];
+      entries([&](int e) { return 64 + 16 * wave + fr; }, [&](int e) { return 4 * e + fg; }, [](int) { return false; }, af);
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) af[ks] = sB[(16 * wave + fr) * BLD + 4 * ks + fg];
+      for (int nb = 0; nb < 4; ++nb) x[nb] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) x[nb] = d4{0.0, 0.0, 0.0, 0.0};
+      for (int ks = 0; ks < 16; ++ks) {
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-#pragma unroll
-      for (int nb = ks >> 2; nb < 4; ++nb)
-        x[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], linv(16 * nb + fr, 4 * ks + fg), x[nb], 0, 0, 0);
-      if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        for (int nb = ks >> 2; nb < 4; ++nb)
+          x[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], linv(16 * nb + fr, 4 * ks + fg), x[nb], 0, 0, 0);
+        if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
     }
+    SMK_STAMP(9);
+    __syncthreads();                     // (every reader of R's first half and of L00 / L00^-T is through)
+    if (tid < nr * 64) sR[(tid >> 6) * KC + (tid & 63)] = rnew;
+    // X takes the pivot block's place
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sB[(16 * wave + fg + 4 * r) * BLD + 16 * nb + fr] = x[nb][r];
-  }
-  SMK_STAMP(9);
-  if (NB == 2) {
-    __syncthreads();                     // (every reader of R's first half and of L00^-T is through)
-    if (tid < nr * 64) sR[(tid >> 6) * KC + (tid & 63)] = rnew;
+      for (int r = 0; r < 4; ++r) sD[(16 * wave + fg + 4 * r) * BLD + 16 * nb + fr] = x[nb][r];
     __syncthreads();                     // X and the solved first half of R are in place
     SMK_STAMP(10);
     // R[:, 64 ..] -= R[:, .. 63] X^T
     if (tid < nr * 64) {
       const int mr = tid >> 6, cc = tid & 63;
-      const double *r0 = sR + mr * KC, *xr = sB + cc * BLD;
+      const double *r0 = sR + mr * KC, *xr = sD + cc * BLD;
       double acc = r0[64 + cc];
 #pragma unroll 4
       for (int n = 0; n < 64; ++n) acc = fma(-r0[n], xr[n], acc);
       sR[mr * KC + 64 + cc] = acc;
     }
     SMK_STAMP(11);
-    // T11 -= X X^T (the blocks on or below the diagonal), then to the LDS for its factorisation
+    // T11 (assembled now, in accumulators) -= X X^T: the blocks on or below the diagonal
+    double w11[16];
+    diag_tile(1, w11);
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
       if (nb > wave) continue;
-      d4 acc = a11[nb];
+      d4 acc = d4{w11[4 * nb], w11[4 * nb + 1], w11[4 * nb + 2], w11[4 * nb + 3]};
 #pragma unroll 4
       for (int ks = 0; ks < 16; ++ks) {
         const int k = 4 * ks + fg;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-sB[(16 * wave + fr) * BLD + k], sB[(16 * nb + fr) * BLD + k], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-sD[(16 * wave + fr) * BLD + k], sD[(16 * nb + fr) * BLD + k], acc, 0, 0, 0);
       }
-      a11[nb] = acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w11[4 * nb + r] = acc[r];
     }
     SMK_STAMP(12);
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * wave + fg + 4 * r, col = 16 * nb + fr;
-        sD[row * BLD + col] = col > row ? 0.0 : a11[nb][r];
-      }
+    __syncthreads();                     // (every reader of X is through)
+    store_lower(w11);
     __syncthreads();                     // (diag_block wants a barrier behind the block's stores)
     SMK_STAMP(4);
     notpd |= diag_block<false>(sD, sRd, tid_rot);
@@ -335,8 +325,8 @@ bool sp_small_k_serves(int K, int M, int covpts, bool has_diag) {
   const int nr = M + (has_diag ? 2 : 1);
   if (K < 2 || K > 128 || nr > SMK_MAXR) return false;
   const int np = covpts + 4;
-  // the table lies in the region tile (1, 0) takes later; at most what leaves two workgroups a CU (K > 64) or three
-  // (K <= 64: in the pivot block's place)
+  // the table: in the pivot block's place (K <= 64) or in a region of its own, no larger (K > 64: 54 KB, three
+  // workgroups a CU, up to covpts = 390 with two riding rows)
   return 4 * np <= 64 * BLD;
 }
 
@@ -346,7 +336,7 @@ int sp_launch_small_lnlike(int S, int K, int M, const PlanDev &plan, const doubl
   if (!sp_small_k_serves(K, M, covpts, diag != nullptr)) return SP_ERR_INVALID;
   const int NB = K > 64 ? 2 : 1, KC = 64 * NB, np = covpts + 4, nr = M + (diag ? 2 : 1);
   // (K <= 64: the table lies in the pivot block's place -- no region of its own)
-  const int regionB = NB == 2 ? (4 * np < 64 * BLD ? 64 * BLD : 4 * np) : 0;
+  const int regionB = NB == 2 ? 4 * np : 0;
   const size_t doubles = (size_t)SP_DIAG_LDS_DOUBLES + regionB + 2 * KC + (size_t)nr * KC + KC + 48 + SP_RSCAL_HEAD + M + 1 + 8 + 2;
   const size_t lds = sizeof(double) * doubles;
 #define SP_SMALL(NBV, TKV)                                                                                        \

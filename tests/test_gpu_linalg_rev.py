@@ -19,6 +19,21 @@ def _spd(rng, K):
     return B.dot(B.T) + K * np.eye(K)
 
 
+@pytest.mark.parametrize("K", [100, 200, 1000])
+def test_cho_factor_forward_error(K):
+    """The blocked factor of a WELL-conditioned matrix (condition ~5) against LAPACK's to 5e-14 of its largest entry
+    (rounding alone: ~1e-15).  The rows below a pivot block are products with the block's explicit inverse
+    (sp_diag.h: inverse_block_row): the comparisons with the oracle (1e-8 of a log-likelihood) would not see an
+    inverse that is wrong in its tenth digit."""
+    from starry_process_amd.math import cho_factor
+
+    rng = np.random.RandomState(K)
+    C = _spd(rng, K)
+    L = np.array(cho_factor(C))
+    ref = np.linalg.cholesky(C)
+    assert np.abs(np.tril(L) - ref).max() < 5e-14 * np.abs(ref).max()
+
+
 def test_solve_and_L_op_match_reference():
     from starry_process_amd.math import Solve, cho_factor, cho_solve
 

@@ -194,3 +194,24 @@ int main(void) {
     env["LD_LIBRARY_PATH"] = tl + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True, env=env, timeout=120)
     assert out.stdout.startswith("abi ok")
+
+
+def test_inline_dpp_instructions_keep_their_wait_states():
+    """The v_fmac_f64_dpp chains of sp_diag.h are inline assembly, which the compiler's hazard recogniser does not look
+    into: tools/check_dpp_hazard.py compiles the kernels that use them and finds no VALU write of a DPP source less
+    than two wait states ahead of its read -- and does find them with the spacing that once failed on the GPU."""
+    import importlib.util
+    import shutil
+
+    if not shutil.which("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    spec = importlib.util.spec_from_file_location("check_dpp_hazard", os.path.join(ROOT, "tools", "check_dpp_hazard.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    res = chk.check()
+    for f, (seen, bad) in res.items():
+        assert seen > 500, f
+        assert bad == [], (f, bad[:3])
+    chk.FILES = ["sp_panel.hip"]
+    (seen, bad), = chk.check(["-DSP_INV_WAIT_MIN"]).values()
+    assert bad, "the check no longer sees the hazard it was written for"

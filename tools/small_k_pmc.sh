@@ -5,6 +5,7 @@
 #   bash tools/small_k_pmc.sh K phases             instruction counts by phase, S = 3072: the variants stop1 .. stop6
 #                                                  (bash tools/ab_build.sh stop$k -DSMK_STOP=$k for k in 1 2 3 8 6) return at a
 #                                                  phase boundary; differences of SQ_INSTS_* between them
+#                                                  (SP_STOPS="stop1 stop2 ...": another list, e.g. K > 64's phases)
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 K=${1:-64}
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT" || exit 1
@@ -20,7 +21,7 @@ run() {   # variant S pass-name counters
   rm -rf $O/$3/*/*kernel_trace.csv
 }
 if [ "$2" = phases ]; then
-  for V in stop1 stop2 stop3 stop8 stop6 ""; do
+  for V in ${SP_STOPS:-stop1 stop2 stop3 stop8 stop6} ""; do
     run "$V" 3072 v${V:-full}_p1 "$P1"
     run "$V" 3072 v${V:-full}_p2 "$P2"
   done
