@@ -1,29 +1,32 @@
 // diag_block(): Cholesky factor L of a 64 x 64 SPD block held in LDS, by one 256-thread workgroup,
 // and its inverse L^-1, formed in the shadow of the factorisation (callers: panel_diag_core,
-// sp_paneldiag.h, which writes both out).
+// sp_paneldiag.h, which writes both out; the small-K kernel, sp_small.hip).
 //
 // The block is cut in four block columns of 16; wavefront w owns block column w.
 //   factor_panel(w): the 16 x 16 diagonal leaf with lane = row (the four 16-lane DPP rows carry
 //     the same copy): column c is scaled by 1 / sqrt(pivot) in every lane at once and the rank-1
-//     step a_j -= l * l_j takes l_j from lane j by a DPP row broadcast (v_mov_b64_dpp
-//     row_newbcast) -- no LDS traffic, no scalar registers, no barrier inside the leaf.  fp64 VALU
-//     and fp64 MFMA have the same peak on gfx950, so nothing is lost by leaving the matrix cores
-//     here; the leaf is a latency chain of ~200 cycles per column.
-//   rows below the leaf: by all wavefronts, four lanes per row (below_quad).
+//     step a_j -= l * l_j takes l_j from lane j by a DPP row broadcast folded into the multiply-add
+//     (v_fmac_f64_dpp row_newbcast) -- no LDS traffic, no scalar registers, no barrier inside the
+//     leaf.  Then, still in registers, the leaf's INVERSE M = L_leaf^-1 by substitution on the
+//     identity with the same instruction (LeafInvStep: the rows pre-scaled to a unit diagonal, one
+//     multiply-add per step and column, four columns per lane): ~40 instructions.
+//   rows below the leaf: X = A M^T on the matrix cores, one 16-row block per wavefront (below_mfma;
+//     rounds 2-5: substitution, fifteen dependent steps each behind an LDS read, 1 700 cycles per
+//     block column).
 //   update: the tiles right of a published panel are updated on the MFMA from LDS; the owner of
 //     the next panel takes the one tile its leaf needs and starts factoring while the three other
-//     wavefronts share the rest -- and form the finished block row of the inverse.
-//   Two workgroup barriers per panel.  12 us alone on a CU.
+//     wavefronts share the rest -- and form the finished block row of the inverse from M.
+//   Two workgroup barriers per panel.
 //
 // LDS: sD[64 * BLD] (block in; L out in the lower part, L^-T in the upper) + sRd[64] (1 / L_cc,
-// which is also the diagonal of the inverse) + 16 x 16 scaled leaf for the substitution.
+// which is also the diagonal of the inverse) + the current leaf's 16 x 16 inverse.
 #ifndef SP_DIAG_H
 #define SP_DIAG_H
 
 #include <hip/hip_runtime.h>
 
 #define BLD 66   // LDS row of the 64x64 block: even (16-B aligned rows), 132 dwords = 4 mod 64 banks
-#define SP_DIAG_LDS_DOUBLES (64 * BLD + 64 + 256)
+#define SP_DIAG_LDS_DOUBLES (64 * BLD + 64 + 256)   // block, reciprocal diagonal, the current leaf's inverse
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2v __attribute__((ext_vector_type(2)));
@@ -125,108 +128,6 @@ struct LeafCol<15> {
   }
 };
 
-// Block column `kb` (columns o = 16 kb .. o + 15, rows o .. 63) by ONE wavefront.
-// Stage 1: the 16 x 16 diagonal leaf.  Lane i (mod 16) holds row i in 16
-//   registers; a column's entries reach the other rows through DPP row
-//   broadcasts (no LDS, no scalar registers, no barrier).
-// Stage 2: the rows below the leaf, one per lane, by substitution against the
-//   leaf (pre-scaled:  lt[k][c] = L_ck / L_cc  read from LDS at a uniform address).
-// Returns 1 if a pivot was not positive.
-__device__ __forceinline__ int factor_panel(double *sD, double *sRd, double *sLt, int kb,
-                                            int lane, long long *ts = nullptr) {
-  const int o = 16 * kb, i = lane & 15;
-  int notpd = 0;
-  if (ts) ts[0] = clock64();
-  {
-    double *prow = sD + (o + i) * BLD + o;
-    double a[16];
-#pragma unroll
-    for (int j = 0; j < 16; j += 2) {
-      const d2v v = *reinterpret_cast<const d2v *>(prow + j);
-      a[j] = v.x;
-      a[j + 1] = v.y;
-    }
-    const double p = row_bcast<0>(a[0]);
-    if (!(p > 0.0)) notpd = 1;
-    double rd_mine = 0.0;
-    if (ts) ts[1] = clock64();
-    LeafCol<0>::run(a, rsqrt_nr(p), rd_mine, notpd, i);
-    if (ts) ts[2] = clock64();
-    if (lane < 16) {
-#pragma unroll
-      for (int j = 0; j < 16; j += 2) {
-        d2v v;
-        v.x = j > i ? 0.0 : a[j];          // strict upper part of the leaf
-        v.y = j + 1 > i ? 0.0 : a[j + 1];
-        *reinterpret_cast<d2v *>(prow + j) = v;
-      }
-      sRd[o + i] = rd_mine;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) sLt[k * 16 + i] = k < i ? a[k] * rd_mine : 0.0;
-    }
-  }
-  if (ts) ts[3] = clock64();
-  if (ts) ts[4] = clock64();
-  return notpd;
-}
-
-// Stage 2 of a panel: the rows below the 16 x 16 leaf of block column kb, X = A L_leaf^-T,
-// by ALL wavefronts: four lanes per row (lane q of a quad holds the columns 2q, 2q+1, 8+2q,
-// 9+2q), x_k handed round the quad by DPP quad_perm, the pre-scaled leaf (sLt[k][c] =
-// L_ck / L_cc, zero for c <= k) read from LDS.  One lane per row in the panel's own wavefront
-// (the previous form) issued 120 multiply-adds and 64 LDS reads per lane: 1900 cycles on the
-// critical path against ~600 here plus the barrier that lets the other wavefronts in.
-template <int K>
-struct Below16Step {
-  static __device__ __forceinline__ void run(double (&x)[4], const double *sLt, int q) {
-    constexpr int QK = (K >> 1) & 3, REG = 2 * (K >> 3) + (K & 1);
-    constexpr int CTRL = QK * 0x55;   // quad_perm:[QK, QK, QK, QK]
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x[REG]), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x[REG]), CTRL, 0xf, 0xf, false);
-    const double xk = __hiloint2double(hi, lo);
-    if (K < 7) {   // columns 0..7 still have entries right of K
-      const d2v l0 = *reinterpret_cast<const d2v *>(sLt + K * 16 + 2 * q);
-      x[0] = fma(-xk, l0.x, x[0]);
-      x[1] = fma(-xk, l0.y, x[1]);
-    }
-    const d2v l1 = *reinterpret_cast<const d2v *>(sLt + K * 16 + 8 + 2 * q);
-    x[2] = fma(-xk, l1.x, x[2]);
-    x[3] = fma(-xk, l1.y, x[3]);
-    Below16Step<K + 1>::run(x, sLt, q);
-  }
-};
-template <>
-struct Below16Step<15> {
-  static __device__ __forceinline__ void run(double (&)[4], const double *, int) {}
-};
-
-__device__ __forceinline__ void below_quad(double *sD, const double *sRd, const double *sLt, int kb,
-                                           int tid) {
-  const int o = 16 * kb, nbelow = 48 - o;
-  const int row = tid >> 2, q = tid & 3;
-  // (a wavefront holds sixteen rows: 3 - kb of the four have any -- the others leave, wavefront-uniform; they were
-  //  half of this function's instructions, which co-resident workgroups of the small-K kernel pay for)
-  if (16 * (tid >> 6) >= nbelow) return;
-  const bool live = row < nbelow;
-  double *p = sD + (o + 16 + (live ? row : 0)) * BLD + o + 2 * q;
-  const d2v a = *reinterpret_cast<const d2v *>(p), b = *reinterpret_cast<const d2v *>(p + 8);
-  const d2v ra = *reinterpret_cast<const d2v *>(sRd + o + 2 * q);
-  const d2v rb = *reinterpret_cast<const d2v *>(sRd + o + 8 + 2 * q);
-  double x[4] = {a.x * ra.x, a.y * ra.y, b.x * rb.x, b.y * rb.y};
-  Below16Step<0>::run(x, sLt, q);
-  if (live) {
-    *reinterpret_cast<d2v *>(p) = d2v{x[0], x[1]};
-    *reinterpret_cast<d2v *>(p + 8) = d2v{x[2], x[3]};
-  }
-}
-
-// ---- inverse of the block, formed in the shadow of the factorisation (inv_out of diag_block) -----
-// Linv = L^-1 is built block row by block row (16 x 16 blocks) while the NEXT leaf is being factored
-// by its wavefront and the others would wait:  Linv_cc = M_c = L_cc^-1 (substitution on the identity,
-// lane = row, x_k handed round by DPP row broadcasts),  Linv_cj = -M_c sum_{k=j}^{c-1} L_ck Linv_kj
-// (matrix cores; the partial sum comes out of the MFMA in exactly the layout of the next B operand,
-// so nothing goes through LDS in between).  Storage: the UPPER triangle of sD, which the
-// factorisation never touches: sD[r][c] = Linv[c][r] for r < c; the diagonal of Linv is sRd.
 // M = L_cc^-1 by substitution on the identity, lane = row, FOUR columns per lane (columns 4 t + g for the lanes of
 // 16-lane group g: s[t] ends as M[i][4 t + g], the A fragment (step t) of an MFMA whose A operand is M).  The rows are
 // pre-scaled (Ls[k] = L_ik / L_ii, zero for k >= i), so the system has a unit diagonal: lane K's s IS x_K when step K
@@ -266,34 +167,96 @@ struct LeafInvStep<15> {
   static __device__ __forceinline__ void run(double (&)[4], const double (&)[16]) {}
 };
 
-// block row c of Linv by ONE wavefront: `writer` stores M_c (strictly lower part, transposed into
-// sD's upper triangle), `j` >= 0 forms the block Linv_cj
-__device__ __forceinline__ void inverse_block_row(double *sD, const double *sRd, int c, bool writer,
-                                                  int j, int lane) {
-  if (!writer && j < 0) return;
-  const int i = lane & 15, g = lane >> 4, o = 16 * c;
-  double Ls[16];
+// Block column `kb` (columns o = 16 kb .. o + 15): the leaf and its inverse, by ONE wavefront.
+// Stage 1: the 16 x 16 diagonal leaf.  Lane i (mod 16) holds row i in 16 registers; a column's entries reach the
+//   other rows through DPP row broadcasts (no LDS, no scalar registers, no barrier).  Rows to sD, 1 / L_ii to sRd.
+// Stage 2: M = L_leaf^-1 from the rows still in registers (LeafInvStep), to sM ([column][row], what below_mfma and
+//   inverse_block_row load as their fragment: M[i][4 t + g] for lane (i, g)); INV: its strictly lower part also
+//   transposed into sD's upper triangle, where the block's inverse lives.
+// Returns 1 if a pivot was not positive.
+template <bool INV>
+__device__ __forceinline__ int factor_panel(double *sD, double *sRd, double *sM, int kb,
+                                            int lane, long long *ts = nullptr) {
+  const int o = 16 * kb, i = lane & 15, g = lane >> 4;
+  int notpd = 0;
+  if (ts) ts[0] = clock64();
+  double *prow = sD + (o + i) * BLD + o;
+  double a[16];
 #pragma unroll
-  for (int k = 0; k < 16; k += 2) {
-    const d2v v = *reinterpret_cast<const d2v *>(sD + (o + i) * BLD + o + k);
-    Ls[k] = v.x;
-    Ls[k + 1] = v.y;
+  for (int j = 0; j < 16; j += 2) {
+    const d2v v = *reinterpret_cast<const d2v *>(prow + j);
+    a[j] = v.x;
+    a[j + 1] = v.y;
   }
-  const double rd = sRd[o + i];
+  const double p = row_bcast<0>(a[0]);
+  if (!(p > 0.0)) notpd = 1;
+  double rd_mine = 0.0;
+  if (ts) ts[1] = clock64();
+  LeafCol<0>::run(a, rsqrt_nr(p), rd_mine, notpd, i);
+  if (ts) ts[2] = clock64();
+  if (lane < 16) {
 #pragma unroll
-  for (int k = 0; k < 16; ++k) Ls[k] = k >= i ? 0.0 : Ls[k] * rd;   // (on and above the leaf's diagonal: not L)
+    for (int j = 0; j < 16; j += 2) {
+      d2v v;
+      v.x = j > i ? 0.0 : a[j];          // strict upper part of the leaf
+      v.y = j + 1 > i ? 0.0 : a[j + 1];
+      *reinterpret_cast<d2v *>(prow + j) = v;
+    }
+    sRd[o + i] = rd_mine;
+  }
+  // the rows scaled to a unit diagonal, in place (on and right of the diagonal: zero)
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a[k] = k >= i ? 0.0 : a[k] * rd_mine;
   double res[4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) res[t] = (i == 4 * t + g) ? rd : 0.0;
-  LeafInvStep<0>::run(res, Ls);
-  if (writer) {
+  for (int t = 0; t < 4; ++t) res[t] = (i == 4 * t + g) ? rd_mine : 0.0;
+  LeafInvStep<0>::run(res, a);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int col = 4 * t + g;
-      if (i > col) sD[(o + col) * BLD + o + i] = res[t];
-    }
+  for (int t = 0; t < 4; ++t) {
+    const int col = 4 * t + g;
+    sM[col * 16 + i] = res[t];
+    if (INV && i > col) sD[(o + col) * BLD + o + i] = res[t];
   }
+  if (ts) ts[3] = clock64();
+  if (ts) ts[4] = clock64();
+  return notpd;
+}
+
+// the leaf's inverse as every wavefront's fragment: res[t] = M[i][4 t + g] for lane (i, g) -- the B operand of
+// below_mfma (M^T[k = 4 t + g][n = i]) and the A operand of inverse_block_row
+__device__ __forceinline__ void load_leaf_inverse(const double *sM, int lane, double (&res)[4]) {
+  const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) res[t] = sM[(4 * t + g) * 16 + i];
+}
+
+// The rows below the 16 x 16 leaf of block column kb, X = A L_leaf^-T = A M^T, on the matrix cores: the 16-row
+// block ib = wavefront index (ib > kb; wavefronts up to kb have none), in place.
+__device__ __forceinline__ void below_mfma(double *sD, const double (&res)[4], int kb, int wave, int lane) {
+  if (wave <= kb) return;
+  const int o = 16 * kb;
+  double af[4];
+#pragma unroll
+  for (int st = 0; st < 4; ++st) af[st] = frag_rowmajor(sD, BLD, 16 * wave, o, st, lane);
+  d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int st = 0; st < 4; ++st) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[st], res[st], acc, 0, 0, 0);
+  acc_store(sD, BLD, 16 * wave, o, lane, acc);
+}
+
+// ---- inverse of the block, formed in the shadow of the factorisation ---------------------------------
+// Linv = L^-1 is built block row by block row (16 x 16 blocks) while the NEXT leaf is being factored
+// by its wavefront and the others would wait:  Linv_cc = M_c = L_cc^-1 (factor_panel),
+// Linv_cj = -M_c sum_{k=j}^{c-1} L_ck Linv_kj (matrix cores; the partial sum comes out of the MFMA in
+// exactly the layout of the next B operand, so nothing goes through LDS in between).  Storage: the
+// UPPER triangle of sD, which the factorisation never touches: sD[r][c] = Linv[c][r] for r < c; the
+// diagonal of Linv is sRd.
+// block Linv_cj (j < c) of block row c of the inverse by ONE wavefront, from the leaf's inverse M_c (res: its fragment,
+// load_leaf_inverse)
+__device__ __forceinline__ void inverse_block_row(double *sD, const double *sRd, int c, int j, int lane,
+                                                  const double (&res)[4]) {
   if (j < 0) return;
+  const int i = lane & 15, g = lane >> 4, o = 16 * c;
   d4 S = d4{0.0, 0.0, 0.0, 0.0};
   for (int k = j; k < c; ++k) {
 #pragma unroll
@@ -322,26 +285,30 @@ __device__ __forceinline__ void inverse_block_row(double *sD, const double *sRd,
 template <bool INV = true>
 __device__ __forceinline__ int diag_block(double *sD, double *sRd, int tid_in = threadIdx.x,
                                           long long *dbg = nullptr) {
-  const bool inv = INV;
   int notpd = 0;
+  double *sM = sRd + 64;
 #pragma unroll 1
   for (int kb = 0; kb < 4; ++kb) {
-    // (a laundered copy of the thread index per block column: the lane-derived predicates of the leaf, the
-    //  substitution and the inverse -- (i == C), (k > i), ... some 60 of them -- are loop invariants, and hoisted
-    //  out of this loop they are 120 scalar registers held across it: 100 of them spilled to vector lanes and
-    //  reloaded inside the loops of the critical chain.  Recomputing a compare costs one instruction.)
+    // (a laundered copy of the thread index per block column: the lane-derived predicates of the leaf and the
+    //  inverse -- (i == C), (k >= i), ... some 60 of them -- are loop invariants, and hoisted out of this loop they
+    //  are 120 scalar registers held across it: 100 of them spilled to vector lanes and reloaded inside the loops of
+    //  the critical chain.  Recomputing a compare costs one instruction.)
     int tid = tid_in;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = tid >> 6;
     if (wave == kb) {
       long long ts[5];
-      notpd |= factor_panel(sD, sRd, sRd + 64, kb, lane, dbg ? ts : nullptr);
+      notpd |= factor_panel<INV>(sD, sRd, sM, kb, lane, dbg ? ts : nullptr);
       if (dbg && lane == 0)
         for (int q = 0; q < 5; ++q) dbg[8 * kb + q] = ts[q];
     }
     __syncthreads();
+    // (every wavefront takes the leaf's inverse NOW: the next owner overwrites sM behind the next barrier, while the
+    //  others may still be forming this block row of the inverse)
+    double res[4];
+    load_leaf_inverse(sM, lane, res);
     if (kb < 3) {
-      below_quad(sD, sRd, sRd + 64, kb, tid);
+      below_mfma(sD, res, kb, wave, lane);
       __syncthreads();
     }
     if (dbg && wave == (kb < 3 ? kb + 1 : 3) && lane == 0) dbg[8 * kb + 5] = clock64();
@@ -374,18 +341,14 @@ __device__ __forceinline__ int diag_block(double *sD, double *sRd, int tid_in = 
             ++t;
           }
         // ... and block row kb of the inverse, while the next leaf is being factored
-        if (inv) inverse_block_row(sD, sRd, kb, hw == 0, (hw < kb) ? hw : -1, lane);
+        if (INV) inverse_block_row(sD, sRd, kb, (hw < kb) ? hw : -1, lane, res);
       }
+    } else if (INV) {
+      // the last block row of the inverse (nothing left to hide it behind)
+      inverse_block_row(sD, sRd, 3, wave < 3 ? wave : -1, lane, res);
+      __syncthreads();
     }
     if (dbg && wave == (kb < 3 ? kb + 1 : 3) && lane == 0) dbg[8 * kb + 6] = clock64();
-  }
-  // the last block row of the inverse (nothing left to hide it behind)
-  if (INV) {
-    int tid = tid_in;
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63, wave = tid >> 6;
-    inverse_block_row(sD, sRd, 3, wave == 3, wave < 3 ? wave : -1, lane);
-    __syncthreads();
   }
   return notpd;    // (INV = false: the barrier behind the last leaf was the last one)
 }
