@@ -148,13 +148,8 @@ struct LeafInvStep {
     // oracle passed, only the 1e-12 comparison of the two samplers (tests/test_gpu_facade.py) did not.  So EVERY
     // instruction here brings at least two idle states (more while few chains are in turn: ~130 cycles per block row,
     // of ~2 000 saved), and tools/check_dpp_hazard.py (tests/test_host.py) reads the compiled kernels for a write of a
-    // DPP source less than two wait states ahead of any v_fmac_f64_dpp.  (-DSP_INV_WAIT_MIN: the spacing that failed,
-    // for that check's own test.)
-#ifdef SP_INV_WAIT_MIN
-    constexpr int W = 0, W0 = K < 9 ? 2 : 0;
-#else
+    // DPP source less than two wait states ahead of any v_fmac_f64_dpp.
     constexpr int W = NT == 1 ? 8 : (NT == 2 ? 4 : (NT == 3 ? 3 : 2)), W0 = W;
-#endif
     fmac_bcast<K, W0>(s[0], s[0], Ls[K]);
     if (NT > 1) fmac_bcast<K, W>(s[1], s[1], Ls[K]);
     if (NT > 2) fmac_bcast<K, W>(s[2], s[2], Ls[K]);

@@ -196,10 +196,10 @@ int main(void) {
     assert out.stdout.startswith("abi ok")
 
 
-def test_inline_dpp_instructions_keep_their_wait_states():
+def test_inline_dpp_instructions_keep_their_wait_states(tmp_path):
     """The v_fmac_f64_dpp chains of sp_diag.h are inline assembly, which the compiler's hazard recogniser does not look
     into: tools/check_dpp_hazard.py compiles the kernels that use them and finds no VALU write of a DPP source less
-    than two wait states ahead of its read -- and does find them with the spacing that once failed on the GPU."""
+    than two wait states ahead of its read; the scan is checked on a hand-written listing of the case it was written for."""
     import importlib.util
     import shutil
 
@@ -212,6 +212,20 @@ def test_inline_dpp_instructions_keep_their_wait_states():
     for f, (seen, bad) in res.items():
         assert seen > 500, f
         assert bad == [], (f, bad[:3])
-    chk.FILES = ["sp_panel.hip"]
-    (seen, bad), = chk.check(["-DSP_INV_WAIT_MIN"]).values()
-    assert bad, "the check no longer sees the hazard it was written for"
+    # the scan itself, on a hand-written listing: the select directly in front of the DPP read (what the compiler did
+    # once to a column of the pivot block's inverse), the same with idle states in between, and an unrelated register
+    lst = tmp_path / "x.s"
+    lst.write_text("\n".join([
+        "v_cndmask_b32_e64 v10, 0, v18, s[4:5]",
+        "v_fmac_f64_dpp v[10:11], v[10:11], -v[38:39] row_newbcast:12 row_mask:0xf bank_mask:0xf",
+        "v_cndmask_b32_e64 v12, 0, v18, s[4:5]",
+        "s_nop 1",
+        "v_fmac_f64_dpp v[12:13], v[12:13], -v[38:39] row_newbcast:12 row_mask:0xf bank_mask:0xf",
+        "v_mul_f64 v[20:21], v[2:3], v[4:5]",
+        "v_fmac_f64_dpp v[14:15], v[14:15], -v[38:39] row_newbcast:12 row_mask:0xf bank_mask:0xf",
+        "v_mul_f64 v[16:17], v[2:3], v[4:5]",
+        "v_add_f64 v[30:31], v[2:3], v[4:5]",
+        "v_fmac_f64_dpp v[16:17], v[16:17], -v[38:39] row_newbcast:12 row_mask:0xf bank_mask:0xf"]) + "\n")
+    seen, bad = chk.scan(str(lst))
+    assert seen == 4 and len(bad) == 2
+    assert bad[0][0].startswith("v_cndmask_b32_e64 v10") and bad[1][0].startswith("v_mul_f64 v[16:17]")
