@@ -146,3 +146,51 @@ def test_small_k_failure_semantics(engine):
     v, st = e.lnlike_ensemble_planned(plan, None, None, e.stars_to_device(other), tab, mv)
     v, st = v.cpu().numpy(), st.cpu().numpy()
     assert np.isnan(v[2]) and (st[2] & 8) and np.isfinite(v[0]) and not st[0]
+
+
+@pytest.mark.parametrize("K", [48, 64, 100, 128])
+def test_small_k_four_riding_rows(engine, K):
+    """Two light curves per star AND per-cadence variances: four riding rows (residuals, ones, variances), the most the
+    kernel serves -- every wavefront substitutes a row (K <= 64 and the second block of K > 64) -- against the blocked
+    path (1e-10) and the oracle (1e-8)."""
+    from oracle.sp_oracle import OracleProcess
+    from starry_process_amd.engine import make_stars
+
+    e = engine
+    S, M = 5, 2
+    rng = np.random.RandomState(K)
+    sts = [synthetic_star(s, K) for s in range(S)]
+    t = np.array([s["t"] for s in sts])
+    flux = np.array([[s["flux"], s["flux"][::-1] * 0.5 + 1e-3 * rng.randn(K)] for s in sts])
+    diag = 1e-6 * (1 + rng.rand(S, K))
+    stars = make_stars(S, period=[s["p"] for s in sts], data_var=1e-6, baseline_var=1e-4)
+    tab, mv = e.kernel_table(e.f64(e.rTA1L([0.0, 0.0])), 300)
+    (v1, s1), (v0, s0) = both_paths(e, t, flux, stars, tab, mv, diag=diag)
+    assert not s1.any() and not s0.any() and np.all(np.isfinite(v1))
+    assert np.max(np.abs(v1 / v0 - 1)) < 1e-10
+    mom = golden("moments_L15")
+    op = OracleProcess(mom["default_mean_ylm"], mom["default_cov_ylm"], ydeg=15)
+    ref = op.log_likelihood(t[2], flux[2], diag[2], p=sts[2]["p"], baseline_var=1e-4)
+    assert abs(v1[2] / ref - 1) < TOL, (K, v1[2], ref)
+
+
+@pytest.mark.parametrize("K", [40, 96])
+def test_small_k_more_stars_than_cus(engine, K):
+    """1 100 stars: workgroups 256 apart in the grid share a CU and take the pivot block's roles in rotated order
+    (sp_small.hip: tid_rot), four rotations in all -- every star equals its value in the blocked path, and the stars
+    are copies of 11 different ones, so a star's value must not depend on its rotation either."""
+    from starry_process_amd.engine import make_stars
+
+    e = engine
+    base = [synthetic_star(s, K) for s in range(11)]
+    S = 1100
+    sts = [base[s % 11] for s in range(S)]
+    t = np.array([s["t"] for s in sts])
+    flux = np.array([s["flux"] for s in sts])[:, None, :]
+    stars = make_stars(S, period=[s["p"] for s in sts], data_var=1e-6)
+    tab, mv = e.kernel_table(e.f64(e.rTA1L([0.0, 0.0])), 300)
+    (v1, s1), (v0, s0) = both_paths(e, t, flux, stars, tab, mv)
+    assert not s1.any() and not s0.any()
+    assert np.max(np.abs(v1 / v0 - 1)) < 1e-10
+    for k in range(11):
+        assert np.unique(v1[k::11]).size == 1, k
