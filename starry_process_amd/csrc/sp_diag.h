@@ -199,6 +199,8 @@ __device__ __forceinline__ int factor_panel(double *sD, double *sRd, double *sM,
     }
     sRd[o + i] = rd_mine;
   }
+  // (the last leaf of a block without an inverse: nothing below it, nobody wants M)
+  if (!INV && kb == 3) return notpd;
   // the rows scaled to a unit diagonal, in place (on and right of the diagonal: zero)
 #pragma unroll
   for (int k = 0; k < 16; ++k) a[k] = k >= i ? 0.0 : a[k] * rd_mine;
