@@ -8,16 +8,21 @@
 // the normalisation's coefficients from yp . wbar), the factorisation, the riding rows' solves, the reduction of
 // sp_reduce.h -- happens in the LDS and registers of one workgroup; nothing of the system ever reaches memory:
 //
-//   tile (0, 0) -> LDS, factored in place by diag_block (sp_diag.h: L below the diagonal, L^-T above it);
-//   K > 64: tile (1, 0) -> LDS (in the spline table's place once the assembly is through), X = T10 L00^-T on the matrix
-//           cores (the wavefront's own 16-row strip, in place); tile (1, 1) in MFMA accumulators from its assembly on,
-//           -= X X^T there, then to the LDS for diag_block;
-//   the riding rows [r_0 .. r_{M-1}, 1, (d)] in LDS: R <- R L^-T by substitution against L^-T;
-//   lnlike_reduce_src on the LDS copies.
+//   tile (0, 0) -> LDS, factored in place by diag_block (sp_diag.h) -- WITHOUT its inverse for K <= 64;
+//   K > 64: tile (1, 0) is assembled after pivot block 0, straight into the MFMA A fragments of the wavefront's own
+//           sixteen rows; X = T10 L00^-T on the matrix cores (the one block whose inverse is used) takes the pivot
+//           block's place in the LDS once L00 is dead; tile (1, 1) is assembled into accumulators, -= X X^T there, stored
+//           over X and factored without an inverse;
+//   the riding rows [r_0 .. r_{M-1}, 1, (d)] in LDS: against a block with an inverse a product
+//           with L^-T, against one without a substitution (ride_subst: one wavefront per row, lane = cadence);
+//   lnlike_reduce_src on the LDS copies, in the first wavefront alone.
 //
-// 77 KB of LDS per workgroup for K > 64 (two per CU), 40 KB for K <= 64 (four; measured: keeping tile (1, 0) in
-// registers in fragment order would leave three for K > 64 too, and needs more than 256 registers); the same values as the blocked planned
-// step to rounding (tests/test_gpu_small.py: 1e-10 against it, 1e-8 against the oracle).
+// ONE 64 x 64 tile of LDS per workgroup: 40 KB for K <= 64 (the spline table lies in the tile's place until the
+// assembly is through: four workgroups a CU), 52 KB for K > 64 (a table region of its own, since two tiles are assembled
+// after the first factorisation: three).  What decided the form was an instruction budget by phase (tools/small_k_pmc.sh:
+// builds that return at a phase boundary, -DSMK_STOP=k, and SQ_INSTS_VALU differences): half of a K = 64 star's vector
+// instructions formed an inverse nobody multiplied with, a quarter were the reduction run by four wavefronts.  The same
+// values as the blocked planned step to rounding (tests/test_gpu_small.py: 1e-10 against it, 1e-8 against the oracle).
 #include "sp_internal.h"
 #include "sp_cov.h"
 #include "sp_asm.h"

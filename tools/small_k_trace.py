@@ -33,12 +33,13 @@ L = ctypes.CDLL(_lib.LIB_PATH)
 buf = np.zeros(64 * 16, dtype=np.int64)
 assert L.sp_debug_small_trace(buf.ctypes.data_as(ctypes.c_void_p)) == 0
 tr = buf.reshape(64, 16).astype(float)
-# stamps: 0 start, 1 prologue done, 2 assembly done + tile (0, 0) in LDS, 3 pivot block 0 factored, 8 rows' first half
-# solved (registers), 9 X in registers, 10 X / rows in LDS, 11 rows' second half updated, 12 tile (1, 1) updated,
+# stamps: 0 start, 1 prologue done, 2 tile (0, 0) assembled and in LDS, 3 pivot block 0 factored, 8 rows' first half
+# solved, 9 tile (1, 0) assembled and X in registers, 10 X / rows in LDS, 11 rows' second half updated, 12 tile (1, 1)
+# assembled and updated,
 # 4 tile (1, 1) in LDS, 5 pivot block 1 factored, 6 rows solved, 7 reduced
 order = [0, 1, 2, 3, 8, 9, 10, 11, 12, 4, 5, 6, 7] if K > 64 else [0, 1, 2, 3, 8, 6, 7]
 names = {1: "prologue (loads, m, coefficients)", 2: "assembly", 3: "pivot block 0 (diag_block)", 8: "rows: first half solve",
-         9: "X = T10 L00^-T", 10: "barriers + stores", 11: "rows: second half update", 12: "T11 -= X X^T", 4: "T11 to LDS",
+         9: "tile (1, 0) assembled + X = T10 L00^-T", 10: "barriers + X to LDS", 11: "rows: second half update", 12: "tile (1, 1) assembled, -= X X^T", 4: "T11 to LDS",
          5: "pivot block 1 (diag_block)", 6: "rows: solve / barriers", 7: "reduction"}
 print("K %d, S %d: phases of workgroups 0 .. 63, us (mean / min / max); whole %.1f us" % (K, S, np.mean(tr[:, 7] - tr[:, 0]) * 0.01))
 for a, b in zip(order[:-1], order[1:]):
