@@ -25,69 +25,111 @@ __device__ __forceinline__ double wsum(double v) {
   return v;
 }
 
-// upper 64 x 64 tiles <- transposes of the lower ones ([S, Kr, Kr]; grid (ntr (ntr - 1) / 2, S))
-__global__ __launch_bounds__(256) void mirror_lower_kernel(double *__restrict__ A, int Kr) {
-  __shared__ double tile[64][65];
-  const int t = blockIdx.x;
-  int ti = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f) + 1;   // strictly-lower tile index t -> (ti > tj)
-  while (ti * (ti - 1) / 2 > t) --ti;
-  while ((ti + 1) * ti / 2 <= t) ++ti;
-  const int tj = t - ti * (ti - 1) / 2;
-  double *M = A + (size_t)blockIdx.y * Kr * Kr;
-  const int c = threadIdx.x & 63, r4 = threadIdx.x >> 6;
-  for (int r = r4; r < 64; r += 4) tile[r][c] = M[(size_t)(64 * ti + r) * Kr + 64 * tj + c];
-  __syncthreads();
-  for (int r = r4; r < 64; r += 4) M[(size_t)(64 * tj + r) * Kr + 64 * ti + c] = tile[c][r];
-}
-
-// C^-1 [p, q, 1, r_0 .. r_{M-1}] per star (C^-1 symmetric: thread i sums over the ROWS j of its column, coalesced),
-// four vectors per pass over the inverse: vec[s][0..M+2][K] = C^-1 p, C^-1 q, C^-1 1, alpha_m = C^-1 r_m.
-// grid (Kr / 64, S, ceil((M + 3) / 4)); one light curve per star is one pass, as before.
+// C^-1 [p, q, 1, r_0 .. r_{M-1}] per star from the LOWER tiles of C^-1 alone (the inverse comes out of the blocked
+// factorisation as its lower tiles, the diagonal ones complete; rounds 4-5 mirrored them into the upper ones first -- 8 MB
+// written and 8 more read per star -- and summed down the columns of the full matrix, one row per memory round trip:
+// 0.12 + 0.17 ms of the 2.36 ms sweep at 64 x 1000).  Four vectors per pass (v0 = 4 * pass): vec[s][0..M+2][K] =
+// C^-1 p, C^-1 q, C^-1 1, alpha_m = C^-1 r_m.
+// One workgroup per lower tile (ta >= tb), grid (ntr (ntr + 1) / 2, S): the tile is read ONCE (sixteen loads per thread in
+// flight) and gives both of its products,
+//   down its columns: sum_r T[r][c] x[64 ta + r]  -> entries 64 tb + c of the result, slot ta;
+//   along its rows:   sum_c T[r][c] x[64 tb + c]  -> entries 64 ta + r, slot tb   (through the LDS; not for a diagonal tile,
+//                                                    which is complete and counted once),
+// into part[s][slot][k][K]: every (block of the result, slot) has exactly one writer, and grad_matvec_reduce_kernel adds
+// the slots in a fixed order.
 __global__ __launch_bounds__(256) void grad_matvec_kernel(
-    int K, int Kr, int M, const double *__restrict__ Cinv, const double *__restrict__ flux,
+    int K, int Kr, int M, int v0, const double *__restrict__ Cinv, const double *__restrict__ flux,
     const sp_star *__restrict__ stars, const SpCoef *__restrict__ coef, const double *__restrict__ qv,
-    int normalized, double *__restrict__ vec) {
+    int normalized, double *__restrict__ part) {
   __shared__ double red[4][4][64];
-  const int s = blockIdx.y, i = blockIdx.x * 64 + (threadIdx.x & 63), jq = threadIdx.x >> 6;
-  const int v0 = 4 * blockIdx.z, NV = M + 3;
-  const double *Ci = Cinv + (size_t)s * Kr * Kr;
-  const double shift = coef[s].gpmean + stars[s].baseline_mean;
-  double a[4] = {0.0, 0.0, 0.0, 0.0};
-  if (v0 == 0) {
-    // the first pass: p, q, ones and the first light curve's residuals -- all there is with one light curve per star
-    const double *f0 = flux + (size_t)s * M * K;
-    for (int j = jq; j < K; j += 4) {
-      const double c = Ci[(size_t)j * Kr + i];
-      const double q = normalized ? qv[(size_t)s * K + j] : 0.0;
-      a[0] += c * (1.0 - q);
-      a[1] += c * q;
-      a[2] += c;
-      a[3] += c * (f0[j] - shift);
-    }
-  } else {
-    // further passes: the residuals of light curves v0 - 3 .. v0 (past the last: the last one again, not stored)
-    const double *fl[4];
+  __shared__ double tile[64][65];
+  __shared__ double xs[2][4][64];         // [0]: entries 64 ta + ., [1]: entries 64 tb + .
+  const int s = blockIdx.y, c = threadIdx.x & 63, jq = threadIdx.x >> 6, ntr = Kr / 64;
+  const int t = blockIdx.x;
+  int ta = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);     // row tile (ta >= tb)
+  while (ta * (ta + 1) / 2 > t) --ta;
+  while ((ta + 1) * (ta + 2) / 2 <= t) ++ta;
+  const int tb = t - ta * (ta + 1) / 2;
+  const double *T = Cinv + (size_t)s * Kr * Kr + (size_t)(64 * ta) * Kr + 64 * tb;
+  double v[16];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int m = v0 + k - 3;
-      fl[k] = flux + ((size_t)s * M + (m < M ? m : M - 1)) * K;
-    }
-    for (int j = jq; j < K; j += 4) {
-      const double c = Ci[(size_t)j * Kr + i];
+  for (int u = 0; u < 16; ++u) v[u] = T[(size_t)(jq + 4 * u) * Kr + c];
+  if (threadIdx.x < 128) {
+    // entry j of the pass's four vectors (the first pass: p, q, ones and the first light curve's residuals -- all there
+    // is with one light curve per star; further passes: the residuals of light curves v0 - 3 .. v0, past the last the
+    // last one again, not stored); zero beyond the K cadences
+    const int which = threadIdx.x >> 6, j = 64 * (which == 0 ? ta : tb) + c;
+    const double shift = coef[s].gpmean + stars[s].baseline_mean;
+    double x[4] = {0.0, 0.0, 0.0, 0.0};
+    if (j < K) {
+      if (v0 == 0) {
+        const double q = normalized ? qv[(size_t)s * K + j] : 0.0;
+        x[0] = 1.0 - q;
+        x[1] = q;
+        x[2] = 1.0;
+        x[3] = flux[(size_t)s * M * K + j] - shift;
+      } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) a[k] += c * (fl[k][j] - shift);
+        for (int k = 0; k < 4; ++k) {
+          const int m = v0 + k - 3;
+          x[k] = flux[((size_t)s * M + (m < M ? m : M - 1)) * K + j] - shift;
+        }
+      }
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xs[which][k][c] = x[k];
   }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) red[k][jq][threadIdx.x & 63] = a[k];
+  for (int u = 0; u < 16; ++u) tile[jq + 4 * u][c] = v[u];
   __syncthreads();
-  if (jq == 0 && i < K) {
+  double *P = part + (size_t)s * ntr * 4 * K;
+  // down the columns
+  {
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a[k] += v[u] * xs[0][k][jq + 4 * u];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[k][jq][c] = a[k];
+  }
+  __syncthreads();
+  if (jq == 0 && 64 * tb + c < K) {
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (v0 + k < NV)
-        vec[((size_t)s * NV + v0 + k) * K + i] = (red[k][0][threadIdx.x] + red[k][1][threadIdx.x]) +
-                                                 (red[k][2][threadIdx.x] + red[k][3][threadIdx.x]);
+      P[((size_t)ta * 4 + k) * K + 64 * tb + c] = (red[k][0][c] + red[k][1][c]) + (red[k][2][c] + red[k][3][c]);
   }
+  if (ta == tb) return;
+  // along the rows: thread (c, jq) is row c of the tile, columns cc = jq mod 4
+  __syncthreads();
+  {
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int cc = jq; cc < 64; cc += 4) {
+      const double w = tile[c][cc];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a[k] += w * xs[1][k][cc];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[k][jq][c] = a[k];
+  }
+  __syncthreads();
+  if (jq == 0 && 64 * ta + c < K) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      P[((size_t)tb * 4 + k) * K + 64 * ta + c] = (red[k][0][c] + red[k][1][c]) + (red[k][2][c] + red[k][3][c]);
+  }
+}
+
+// vec[s][v0 + k][i] = sum over the slots, in their order; grid (ceil(K / 256), S, 4)
+__global__ __launch_bounds__(256) void grad_matvec_reduce_kernel(int K, int ntr, int NV, int v0,
+                                                                 const double *__restrict__ part, double *__restrict__ vec) {
+  const int s = blockIdx.y, k = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= K || v0 + k >= NV) return;
+  const double *P = part + (size_t)s * ntr * 4 * K + (size_t)k * K + i;
+  double a = 0.0;
+  for (int sl = 0; sl < ntr; ++sl) a += P[(size_t)sl * 4 * K];
+  vec[((size_t)s * NV + v0 + k) * K + i] = a;
 }
 
 // one workgroup per star: the dot products, lnL, the scalar adjoints and the vector w (into vec[s][0], over C^-1 p);
@@ -308,13 +350,15 @@ int sp_launch_grad_sweep(int S, int K, int Kr, int M, double *Cinv, const double
                          double *partial, double *lnlike, double *ybar, double *meanbar, uint32_t *status,
                          hipStream_t st) {
   const int ntr = Kr / 64, np = covpts + 4;
-  if (ntr > 1) {
-    hipLaunchKernelGGL(mirror_lower_kernel, dim3(ntr * (ntr - 1) / 2, S), dim3(256), 0, st, Cinv, Kr);
+  // (part: the scatter's partial tables later -- [S][ntr][4][K] doubles of it here, sp_api.hip: grad_layout)
+  for (int v0 = 0; v0 < M + 3; v0 += 4) {
+    hipLaunchKernelGGL(grad_matvec_kernel, dim3(ntr * (ntr + 1) / 2, S), dim3(256), 0, st, K, Kr, M, v0, Cinv, flux, stars,
+                       (const SpCoef *)coef, qv, normalized, partial);
+    SP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(grad_matvec_reduce_kernel, dim3((K + 255) / 256, S, 4), dim3(256), 0, st, K, ntr, M + 3, v0, partial,
+                       vec);
     SP_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(grad_matvec_kernel, dim3(ntr, S, (M + 3 + 3) / 4), dim3(256), 0, st, K, Kr, M, Cinv, flux, stars,
-                     (const SpCoef *)coef, qv, normalized, vec);
-  SP_LAUNCH_CHECK();
   hipLaunchKernelGGL(grad_scalars_kernel, dim3(S), dim3(256), 0, st, K, Kr, M, Cinv, flux, stars, (const SpCoef *)coef,
                      qv, diag, logdet, info, normalized, order, zmax, vec, dots, lnlike, meanbar, hcoef, status);
   SP_LAUNCH_CHECK();
