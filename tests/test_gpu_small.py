@@ -194,3 +194,32 @@ def test_small_k_more_stars_than_cus(engine, K):
     assert np.max(np.abs(v1 / v0 - 1)) < 1e-10
     for k in range(11):
         assert np.unique(v1[k::11]).size == 1, k
+
+
+@pytest.mark.parametrize("K", [60, 100])
+def test_small_k_large_table(K):
+    """covpts = 1000: the largest spline tables the one-kernel path serves (K <= 64: in the pivot block's place in the
+    LDS, K > 64: a region of its own, 77 KB per workgroup) -- equal to the blocked path, within 1e-8 of the oracle."""
+    from oracle.sp_oracle import OracleProcess
+    from starry_process_amd.engine import Engine, make_stars
+
+    e = Engine(15, 2, 0)
+    mom = golden("moments_L15")
+    e.set_moments(mom["default_mean_ylm"], mom["default_cov_ylm"])
+    S, covpts = 6, 1000
+    sts = [synthetic_star(s, K) for s in range(S)]
+    t_d = e.f64(np.array([s["t"] for s in sts]))
+    f_d = e.f64(np.array([s["flux"] for s in sts])[:, None, :])
+    s_d = e.stars_to_device(make_stars(S, period=[s["p"] for s in sts], data_var=1e-6))
+    tab, mv = e.kernel_table(e.f64(e.rTA1L([0.0, 0.0])), covpts)
+    plan = e.plan_data(t_d, f_d, s_d, covpts=covpts)
+    out = []
+    for on in (1, 0):
+        small_k(on)
+        v, st = e.lnlike_ensemble_planned(plan, None, None, s_d, tab, mv)
+        assert not st.cpu().numpy().any()
+        out.append(v.cpu().numpy().copy())
+    assert np.max(np.abs(out[0] / out[1] - 1)) < 1e-10
+    op = OracleProcess(mom["default_mean_ylm"], mom["default_cov_ylm"], ydeg=15, covpts=covpts)
+    ref = op.log_likelihood(sts[3]["t"], sts[3]["flux"], 1e-6, p=sts[3]["p"])
+    assert abs(out[0][3] / ref - 1) < TOL
